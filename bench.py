@@ -1,0 +1,224 @@
+"""bench.py -- env-steps/s (zone-updates/s) of the batched building-thermal step on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): 65 536 replicas per GPU of the
+SB1-physics building on the reference's 3x3-room floor plan R9 (68x98 control volumes, 9
+zones), per-building initial temperatures 294 + N(0,1) K (seed 7, clipped to [285,305]),
+random setpoint actions U[-1,1]^2 per building per step (torch.Generator seed 1234+rank),
+shared sinusoid weather 273-283 K, step-function occupancy, start 2023-07-06 07:00.
+A "step" is one BatchedEnvironment.step(): one launch of the fused HIP step kernel over
+the whole batch, inputs already resident in HBM.  Synthetic data, float64 arithmetic.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; under torchrun one rank per GPU
+(weak scaling: 65 536 buildings per GPU, no data-path collective; one RCCL all_gather of
+the per-building returns after the rollout, timed separately).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import datetime as dt
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+from sbsim_amd import _ffi  # noqa: E402
+from sbsim_amd.environment import BatchedEnvironment, SimConfig  # noqa: E402
+from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def r9_plan() -> FloorPlan:
+  return FloorPlan.from_file_input(rectangular_floor_plan((3, 3), (20, 30)), Materials.sb1(), 10.0, 300.0)
+
+
+def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, acts: np.ndarray,
+                 target_cpu_seconds: float = 20.0):
+  """Times the CPU oracle ("port": oracle/sb_oracle.c, float64, reference operation order,
+  OpenMP over buildings) on a bounded sample of the same workload, and uses the same sample
+  as an in-run parity check of the GPU path.  The oracle is the checker and the baseline,
+  never the product."""
+  from oracle import oracle as orc
+  c = env.config
+  oplan = orc.OraclePlan(plan.conductivity, plan.density, plan.heat_capacity, plan.exterior_space,
+                         plan.zone_cell_lists(), plan.diffusers, plan.cv_size_cm, plan.floor_height_cm)
+  oprm = orc.OracleParams(
+      dt=c.time_step_sec, conv_threshold=c.convergence_threshold, iter_limit=c.iteration_limit,
+      vav_max_air_flow=c.vav_max_air_flow_rate, vav_max_water_flow=c.vav_reheat_max_water_flow_rate,
+      ahu_recirc=c.ahu_recirculation, ahu_heat_sp=c.ahu_heating_air_temp_setpoint,
+      ahu_cool_sp=c.ahu_cooling_air_temp_setpoint, ahu_dp=c.ahu_fan_differential_pressure,
+      ahu_eff=c.ahu_fan_efficiency, blr_setpoint=c.boiler_reheat_water_setpoint,
+      blr_head=c.boiler_water_pump_differential_head, blr_pump_eff=c.boiler_water_pump_efficiency,
+      comfort_lo=c.comfort_temp_window[0], comfort_hi=c.comfort_temp_window[1],
+      eco_lo=c.eco_temp_window[0], eco_hi=c.eco_temp_window[1],
+      blr_heating_rate=c.boiler_heating_rate, blr_cooling_rate=c.boiler_cooling_rate, ahu_has_weather=1)
+  threads = max(1, min(orc.lib().sbo_max_threads(), os.cpu_count() or 1))
+  nb = min(init.shape[0], max(8, 4 * threads))
+  batch = orc.OracleBatch(oplan, oprm, init[:nb])
+  lo, hi = c.action_ranges
+  ts = env._start_timestamp
+  step = dt.timedelta(seconds=c.time_step_sec)
+  prev = None
+  n_steps, t_cpu, sweeps = 0, 0.0, 0
+  max_steps = acts.shape[0]
+  while n_steps < max_steps:
+    env._prev_thermostat_ts = prev
+    si = env.make_step_in(ts)
+    ins = []
+    for b in range(nb):
+      a = acts[n_steps, b]
+      native = [np.float32((float(a[0]) + 1.0) / 2.0 * (lo[1] - lo[0]) + lo[0]),
+                np.float32((float(a[1]) + 1.0) / 2.0 * (hi[1] - hi[0]) + hi[0])]
+      ins.append(orc.make_step_in(
+          now_ts=300.0 * n_steps, t_amb_now=si.t_amb_now, h_conv=env.weather.convection_coefficient,
+          t_amb_next=si.t_amb_next, comfort_now=si.comfort_now, comfort_prev=max(si.comfort_prev, 0),
+          comfort_next=si.comfort_next, occupancy=np.full(oplan.Z, si.occupancy), observe=1,
+          e_price=si.e_price, e_carbon=si.e_carbon, g_price=si.g_price, g_carbon=si.g_carbon,
+          action=native))
+    t0 = time.perf_counter()
+    outs = batch.step(ins, n_threads=threads)
+    t_cpu += time.perf_counter() - t0
+    sweeps += sum(outs[b].n_sweeps for b in range(nb))
+    n_steps += 1
+    prev, ts = ts, ts + step
+    if t_cpu * threads >= target_cpu_seconds or t_cpu > 60.0:
+      break
+  env._prev_thermostat_ts = None
+  zones = oplan.Z
+  value = nb * n_steps * zones / t_cpu
+  grids = np.stack([b.grid() for b in batch.buildings])
+  return dict(value=value, unit="zone-updates/s", cores=threads, kind="port",
+              sample=f"{nb} buildings x {n_steps} steps of the bench workload "
+                     f"({sweeps / (nb * n_steps):.2f} sweeps/step), oracle/sb_oracle.c with OpenMP "
+                     f"over buildings, {t_cpu:.2f} s wall",
+              env_steps_per_s=nb * n_steps / t_cpu), grids, n_steps, nb
+
+
+def main() -> None:
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=24)
+  ap.add_argument("--warmup", type=int, default=12)
+  ap.add_argument("--buildings", type=int, default=65536, help="buildings PER GPU")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  distributed = world > 1
+  if distributed:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+
+  B, K, W = args.buildings, args.steps, args.warmup
+  plan = r9_plan()
+  env = BatchedEnvironment(plan, B, device=local_rank, holiday_calendar="us", collect_info=True,
+                           num_days_in_episode=3)
+  H, Wd = plan.shape
+  Z = env.sim.Z
+  rs = np.random.RandomState(7 + rank)
+  t_init = np.clip(294.0 + rs.randn(B), 285.0, 305.0)
+  init = torch.tensor(t_init, dtype=torch.float64, device=dev)[:, None].expand(B, H * Wd).contiguous()
+  env.reset()
+  env.sim.reset(temps=init)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(1234 + rank)
+  total = W + K
+  actions = torch.rand((total, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+  returns = torch.zeros((B,), dtype=torch.float32, device=dev)
+
+  def barrier():
+    if distributed:
+      dist.barrier()
+    torch.cuda.synchronize(dev)
+
+  for t in range(W):
+    ts = env.step(actions[t])
+    returns += ts.reward
+  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+  sweeps = torch.zeros((), dtype=torch.float64, device=dev)
+  barrier()
+  t0 = time.perf_counter()
+  for t in range(K):
+    si = env.make_step_in(env.current_simulation_timestamp)
+    ev[t][0].record()           # HIP events on the stream the kernel is launched on
+    env.sim.step(actions[W + t], si, env._obs, env._reward, env._info)
+    ev[t][1].record()
+    env._prev_thermostat_ts = env._now
+    env._now = env._now + env._step_interval
+    returns += env._reward
+    sweeps += env._info[:, 4].double().sum()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  kernel_ms = [a.elapsed_time(b) for a, b in ev]
+
+  t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+  gather_ms = 0.0
+  if distributed:
+    dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    torch.cuda.synchronize(dev)
+    g0 = time.perf_counter()
+    out = [torch.empty_like(returns) for _ in range(world)]
+    dist.all_gather(out, returns)           # end-of-rollout return gather over xGMI
+    torch.cuda.synchronize(dev)
+    gather_ms = (time.perf_counter() - g0) * 1e3
+  elapsed = float(t_all.item())
+
+  if rank == 0:
+    li = env.sim.launch_info
+    env_steps_per_s = world * B * K / elapsed
+    avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
+    alg_bytes = li["algorithmic_bytes_per_env_step"] * B
+    achieved = alg_bytes / avg_kernel_s / 1e9
+    result = {
+        "metric": "zone-updates/sec (env-steps/sec x 9 zones) at batch=64k buildings per GPU",
+        "value": env_steps_per_s * Z, "unit": "zone-updates/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "env_steps_per_s": env_steps_per_s,
+        "config": {"workload": "BASELINE.json configs[1]: 64k replicated SB1-physics buildings on floor plan R9 "
+                               "(68x98 CVs, 9 zones), random setpoint actions, sinusoid weather",
+                   "buildings_per_gpu": B, "grid": [H, Wd], "zones": Z,
+                   "mean_sweeps_per_env_step": float(sweeps.item()) / (B * K),
+                   "parallelism": f"{world} x independent building shards, no data-path collective",
+                   "return_gather_ms": gather_ms, "launch": li},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "k_step", "avg_kernel_ms": avg_kernel_s * 1e3,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "state_bytes_per_launch_fp64": li["state_bytes_per_env_step"] * B},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      nb_s = 256
+      acts_cpu = actions[:, :nb_s].cpu().numpy()
+      base, grids, n_s, nb = cpu_baseline(env, plan, np.broadcast_to(t_init[:nb_s, None], (nb_s, H * Wd)).copy(),
+                                          acts_cpu)
+      # in-run parity: replay the same sample on the GPU and compare grids
+      env2 = BatchedEnvironment(plan, nb, device=local_rank, holiday_calendar="us")
+      env2.reset()
+      env2.sim.reset(temps=init[:nb].contiguous())
+      for t in range(n_s):
+        env2.step(actions[t, :nb].contiguous())
+      dT = float(np.abs(env2.sim.temps().cpu().numpy() - grids).max())
+      env2.close()
+      base["parity_max_abs_dT_K"] = dT
+      result["cpu_baseline"] = base
+    print(json.dumps(result))
+  env.close()
+  if distributed:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,116 @@
+"""ctypes binding of the C ABI in include/sbsim_amd.h (host code stays Python; HIP does the work).
+
+There is deliberately no fallback: if the shared library is missing or no MI355X is
+visible the constructors raise.  Nothing in this package imports ``oracle``."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsbsim_amd.so")
+
+SB_NUM_ACTIONS = 2
+SB_NUM_AUX = 7
+SB_INFO_STRIDE = 8
+SB_NUM_SCALARS = 16
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_fp = C.POINTER(C.c_float)
+
+
+class PlanDesc(C.Structure):
+  _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Z", C.c_int32), ("n_classes", C.c_int32),
+              ("cell_class", C.POINTER(C.c_uint8)), ("class_coef", _dp), ("class_zone", _ip),
+              ("zone_off", _ip), ("zone_cells", _ip)]
+
+
+PARAM_FIELDS = [
+    ("dt", C.c_double), ("conv_threshold", C.c_double), ("iter_limit", C.c_int32),
+    ("ahu_has_weather", C.c_int32),
+    ("vav_max_air_flow", C.c_double), ("vav_max_water_flow", C.c_double),
+    ("ahu_recirc", C.c_double), ("ahu_heat_sp", C.c_double), ("ahu_cool_sp", C.c_double),
+    ("ahu_dp", C.c_double), ("ahu_eff", C.c_double), ("ahu_max_flow", C.c_double),
+    ("blr_setpoint", C.c_double), ("blr_head", C.c_double), ("blr_pump_eff", C.c_double),
+    ("blr_heating_rate", C.c_double), ("blr_cooling_rate", C.c_double),
+    ("blr_conv", C.c_double), ("blr_len", C.c_double), ("blr_radius", C.c_double),
+    ("blr_capacity", C.c_double), ("blr_ins_k", C.c_double), ("blr_ins_thick", C.c_double),
+    ("comfort_lo", C.c_double), ("comfort_hi", C.c_double), ("eco_lo", C.c_double),
+    ("eco_hi", C.c_double),
+    ("max_prod", C.c_double), ("min_prod", C.c_double), ("max_elec", C.c_double),
+    ("max_gas", C.c_double), ("prod_delta", C.c_double), ("prod_stiff", C.c_double),
+    ("w_prod", C.c_double), ("w_cost", C.c_double), ("w_carbon", C.c_double),
+    ("act_lo", C.c_double * SB_NUM_ACTIONS), ("act_hi", C.c_double * SB_NUM_ACTIONS),
+]
+
+
+class Params(C.Structure):
+  _fields_ = PARAM_FIELDS
+
+
+class ObsLayout(C.Structure):
+  _fields_ = [("n_obs", C.c_int32), ("col_ahu", C.c_int32), ("col_boiler", C.c_int32),
+              ("col_aux", C.c_int32), ("col_zone", _ip), ("mean", _dp), ("sigma", _dp)]
+
+
+class StepIn(C.Structure):
+  _fields_ = [("t_amb_now", C.c_double), ("t_amb_next", C.c_double), ("t_amb_dev", C.c_void_p),
+              ("comfort_now", C.c_int32), ("comfort_prev", C.c_int32),
+              ("comfort_next", C.c_int32), ("has_action", C.c_int32),
+              ("occupancy", C.c_double), ("occupancy_dev", C.c_void_p),
+              ("e_price", C.c_double), ("e_carbon", C.c_double),
+              ("g_price", C.c_double), ("g_carbon", C.c_double),
+              ("aux", C.c_float * SB_NUM_AUX)]
+
+
+class LaunchInfo(C.Structure):
+  _fields_ = [("waves_per_workgroup", C.c_int32), ("workgroups", C.c_int32),
+              ("lds_bytes_per_workgroup", C.c_int32), ("sweep_steps", C.c_int32),
+              ("algorithmic_bytes_per_env_step", C.c_int64),
+              ("state_bytes_per_env_step", C.c_int64)]
+
+
+EXPORTS = ("sb_abi_version", "sb_last_error", "sb_create", "sb_destroy", "sb_get_launch_info",
+           "sb_reset", "sb_observe", "sb_step", "sb_get_temps", "sb_get_zone_temps",
+           "sb_get_scalars", "sb_get_modes", "sb_get_zone_power")
+
+_lib = None
+
+
+class SbsimError(RuntimeError):
+  pass
+
+
+def load():
+  """Loads libsbsim_amd.so; raises if it has not been built (no silent fallback)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise SbsimError(
+        f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950).  sbsim_amd has no CPU fallback.")
+  L = C.CDLL(LIB_PATH)
+  vp = C.c_void_p
+  L.sb_abi_version.restype = C.c_int
+  L.sb_last_error.restype = C.c_char_p
+  L.sb_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(Params), C.POINTER(ObsLayout),
+                          C.c_int32, C.c_int32, C.POINTER(vp)]
+  L.sb_destroy.argtypes = [vp]
+  L.sb_destroy.restype = None
+  L.sb_get_launch_info.argtypes = [vp, C.POINTER(LaunchInfo)]
+  L.sb_reset.argtypes = [vp, C.c_double, vp, vp]
+  L.sb_observe.argtypes = [vp, C.POINTER(C.c_float), C.c_double, vp, vp]
+  L.sb_step.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp]
+  for name in ("sb_get_temps", "sb_get_zone_temps", "sb_get_scalars", "sb_get_modes",
+               "sb_get_zone_power"):
+    getattr(L, name).argtypes = [vp, vp, vp]
+  _lib = L
+  return L
+
+
+def check(rc: int, what: str) -> None:
+  if rc != 0:
+    msg = load().sb_last_error()
+    raise SbsimError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

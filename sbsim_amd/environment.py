@@ -1,0 +1,444 @@
+"""Vectorised drop-in for sbsim's RL environment: ``reset()`` / ``step(action)`` over B buildings.
+
+Mirrors ``smart_control/environment/environment.py`` ``Environment`` (a TF-Agents
+``PyEnvironment``) for the simulator-backed configuration of
+``configs/resources/sb1/sim_config.gin``, with a leading batch axis:
+
+    reference                                   here
+    ---------                                   ----
+    Environment._reset()  (:1165-1212)          BatchedEnvironment.reset()
+    Environment._step(a)  (:1228-1370)          BatchedEnvironment.step(a)      a: [B, A] in [-1, 1]
+    action_spec()/observation_spec() (:1215-1221)   same names; shapes without the batch axis
+    steps_per_episode (:522), current_simulation_timestamp (:816), discount_factor
+
+Every step is ONE HIP kernel launch through the C ABI (include/sbsim_amd.h) on the current
+torch stream; observations, rewards and actions stay in HBM as torch tensors.  Calendar,
+weather, occupancy and tariffs are resolved on the host once per step (all buildings share
+the simulator clock) by ``sbsim_amd.host_inputs``.  Episode bookkeeping follows
+``environment.py:427-435,1311-1368``: an episode is N transitions plus one terminal step;
+a ``step`` after termination resets.  Action rejection (``RejectionSimulatorBuilding``)
+and metrics writing are out of scope.
+"""
+from __future__ import annotations
+
+import collections
+import ctypes as C
+import dataclasses
+import datetime as dt
+import math
+from typing import Dict, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _ffi, host_inputs
+from .floorplan import CompiledPlan, FloorPlan, Materials
+
+TimeStep = collections.namedtuple("TimeStep", ["step_type", "reward", "discount", "observation"])
+STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2   # tf_agents.trajectories.time_step.StepType
+
+
+@dataclasses.dataclass(frozen=True)
+class ArraySpec:
+  shape: Tuple[int, ...]
+  dtype: np.dtype
+  name: str
+  minimum: Optional[float] = None
+  maximum: Optional[float] = None
+
+
+# air_handler.py:66-95, boiler.py:69-79, vav.py:54-64: observable fields in sorted order.
+_AHU_FIELDS = ("cooling_request_count", "differential_pressure_setpoint",
+               "discharge_fan_speed_percentage_command", "outside_air_flowrate_sensor",
+               "outside_air_temperature_sensor", "supply_air_cooling_temperature_setpoint",
+               "supply_air_flowrate_sensor", "supply_air_heating_temperature_setpoint",
+               "supply_fan_speed_percentage_command")
+_BOILER_FIELDS = ("heating_request_count", "supply_water_setpoint",
+                  "supply_water_temperature_sensor")
+_VAV_FIELDS = ("supply_air_damper_percentage_command", "supply_air_flowrate_setpoint",
+               "zone_air_temperature_sensor")
+_AUX_FIELDS = ("hod_cos_000", "hod_sin_000", "dow_cos_000", "dow_sin_000",
+               "comfort_mode_now", "comfort_mode_soon", "num_occupants")
+ACTION_NAMES = ("supply_water_setpoint", "supply_air_heating_temperature_setpoint")
+
+
+@dataclasses.dataclass
+class SimConfig:
+  """Scalar configuration: the constructor arguments of the reference's Simulator, Hvac
+  devices, SetpointSchedule and SetpointEnergyCarbonRegretFunction.  ``sb1()`` gives
+  ``configs/resources/sb1/sim_config.gin:23-250``."""
+  time_step_sec: float = 300.0
+  convergence_threshold: float = 0.1
+  iteration_limit: int = 100
+  cv_size_cm: float = 10.0
+  floor_height_cm: float = 300.0
+  initial_temp: float = 294.0
+  materials: Materials = dataclasses.field(default_factory=Materials.sb1)
+  # schedule
+  morning_start_hour: int = 6
+  evening_start_hour: int = 19
+  comfort_temp_window: Tuple[float, float] = (294.0, 297.0)
+  eco_temp_window: Tuple[float, float] = (289.0, 298.0)
+  schedule_holidays: Tuple[int, ...] = ()
+  time_zone: str = "US/Pacific"
+  # devices
+  vav_max_air_flow_rate: float = 0.035
+  vav_reheat_max_water_flow_rate: float = 0.03
+  ahu_recirculation: float = 0.3
+  ahu_heating_air_temp_setpoint: float = 285.0
+  ahu_cooling_air_temp_setpoint: float = 298.0
+  ahu_fan_differential_pressure: float = 10000.0
+  ahu_fan_efficiency: float = 0.9
+  ahu_max_air_flow_rate: float = 8.67
+  ahu_has_weather_sensor: bool = True
+  boiler_reheat_water_setpoint: float = 360.0
+  boiler_water_pump_differential_head: float = 6.0
+  boiler_water_pump_efficiency: float = 0.98
+  boiler_heating_rate: float = 0.5
+  boiler_cooling_rate: float = 0.1
+  boiler_convection_coefficient: float = 5.6
+  boiler_tank_length: float = 2.0
+  boiler_tank_radius: float = 0.5
+  boiler_water_capacity: float = 1.5
+  boiler_insulation_conductivity: float = 0.067
+  boiler_insulation_thickness: float = 0.06
+  # reward
+  max_productivity_personhour_usd: float = 300.0
+  min_productivity_personhour_usd: float = 100.0
+  max_electricity_rate: float = 160000.0
+  max_natural_gas_rate: float = 400000.0
+  productivity_midpoint_delta: float = 0.5
+  productivity_decay_stiffness: float = 4.3
+  productivity_weight: float = 0.2
+  energy_cost_weight: float = 0.4
+  carbon_emission_weight: float = 0.4
+  # action normalisation (bounded_action_normalizer.py; sim_config.gin:229-237)
+  action_ranges: Tuple[Tuple[float, float], ...] = ((310.0, 355.0), (285.0, 300.0))
+
+  @staticmethod
+  def sb1() -> "SimConfig":
+    return SimConfig()
+
+  def schedule(self) -> host_inputs.SetpointSchedule:
+    return host_inputs.SetpointSchedule(
+        self.morning_start_hour, self.evening_start_hour, self.comfort_temp_window,
+        self.eco_temp_window, set(self.schedule_holidays), self.time_zone)
+
+  def to_params(self) -> _ffi.Params:
+    p = _ffi.Params()
+    p.dt, p.conv_threshold, p.iter_limit = self.time_step_sec, self.convergence_threshold, self.iteration_limit
+    p.ahu_has_weather = int(self.ahu_has_weather_sensor)
+    p.vav_max_air_flow, p.vav_max_water_flow = self.vav_max_air_flow_rate, self.vav_reheat_max_water_flow_rate
+    p.ahu_recirc, p.ahu_heat_sp, p.ahu_cool_sp = (self.ahu_recirculation, self.ahu_heating_air_temp_setpoint,
+                                                  self.ahu_cooling_air_temp_setpoint)
+    p.ahu_dp, p.ahu_eff, p.ahu_max_flow = (self.ahu_fan_differential_pressure, self.ahu_fan_efficiency,
+                                           self.ahu_max_air_flow_rate)
+    p.blr_setpoint, p.blr_head, p.blr_pump_eff = (self.boiler_reheat_water_setpoint,
+                                                  self.boiler_water_pump_differential_head,
+                                                  self.boiler_water_pump_efficiency)
+    p.blr_heating_rate, p.blr_cooling_rate = self.boiler_heating_rate, self.boiler_cooling_rate
+    p.blr_conv, p.blr_len, p.blr_radius = (self.boiler_convection_coefficient, self.boiler_tank_length,
+                                           self.boiler_tank_radius)
+    p.blr_capacity, p.blr_ins_k, p.blr_ins_thick = (self.boiler_water_capacity,
+                                                    self.boiler_insulation_conductivity,
+                                                    self.boiler_insulation_thickness)
+    p.comfort_lo, p.comfort_hi = self.comfort_temp_window
+    p.eco_lo, p.eco_hi = self.eco_temp_window
+    p.max_prod, p.min_prod = self.max_productivity_personhour_usd, self.min_productivity_personhour_usd
+    p.max_elec, p.max_gas = self.max_electricity_rate, self.max_natural_gas_rate
+    p.prod_delta, p.prod_stiff = self.productivity_midpoint_delta, self.productivity_decay_stiffness
+    p.w_prod, p.w_cost, p.w_carbon = self.productivity_weight, self.energy_cost_weight, self.carbon_emission_weight
+    for i, (lo, hi) in enumerate(self.action_ranges):
+      p.act_lo[i], p.act_hi[i] = lo, hi
+    return p
+
+
+# Observation normalisation constants of sim_config.gin:252-590 that apply to simulated
+# devices: field name -> (sample_mean, sample_variance).  Unknown fields get (0, 1)
+# (observation_normalizer.py:57-66).
+SB1_OBSERVATION_NORMALIZATION: Dict[str, Tuple[float, float]] = {
+    "differential_pressure_setpoint": (83810.269540, 14889040.603647),
+    "outside_air_flowrate_sensor": (3.701930, 20.300565),
+    "outside_air_temperature_sensor": (291.244931, 12.904175),
+    "supply_air_flowrate_sensor": (177.520026, 50499.153481),
+    "supply_fan_speed_percentage_command": (26.543748, 575.094979),
+    "supply_water_setpoint": (310.0, 2500.0),
+    "supply_water_temperature_sensor": (321.520315, 658.413066),
+    "zone_air_temperature_sensor": (190.0, 408.113303),
+}
+
+
+def observation_field_names(zone_names: Sequence[str], ahu_has_weather: bool,
+                            ahu_id: str = "air_handler_id", boiler_id: str = "boiler_id"):
+  """environment.py:543-553,783-813: (device_id, field) sorted, then auxiliary features.
+  Returns (names, col_ahu, col_boiler, col_zone[Z], col_aux)."""
+  devices = [(ahu_id, "ahu", -1), (boiler_id, "blr", -1)]
+  devices += [(f"vav_{z}", "vav", i) for i, z in enumerate(zone_names)]
+  names, col_ahu, col_blr, col_zone = [], -1, -1, [0] * len(zone_names)
+  for dev_id, kind, zi in sorted(devices, key=lambda d: d[0]):
+    if kind == "ahu":
+      col_ahu = len(names)
+      fields = [f for f in _AHU_FIELDS if ahu_has_weather or f != "outside_air_temperature_sensor"]
+    elif kind == "blr":
+      col_blr = len(names)
+      fields = _BOILER_FIELDS
+    else:
+      col_zone[zi] = len(names)
+      fields = _VAV_FIELDS
+    names += [f"{dev_id}/{f}" for f in fields]
+  col_aux = len(names)
+  names += list(_AUX_FIELDS)
+  return names, col_ahu, col_blr, col_zone, col_aux
+
+
+class BatchedSimulator:
+  """Thin owner of the C-ABI handle: B building instances of one floor plan on one GPU.
+
+  Counterpart of ``SimulatorBuilding`` + ``Simulator`` + reward function for the batched
+  path (simulator_building.py:44-315); tensors in, tensors out."""
+
+  def __init__(self, plan: FloorPlan, config: SimConfig, n_buildings: int, h_conv: float,
+               device: int = 0,
+               observation_normalization: Optional[Mapping[str, Tuple[float, float]]] = None,
+               zone_names: Optional[Sequence[str]] = None):
+    self._lib = _ffi.load()
+    if not torch.cuda.is_available():
+      raise _ffi.SbsimError("sbsim_amd needs a HIP device (MI355X); there is no CPU path")
+    self.plan, self.config, self.B, self.device = plan, config, int(n_buildings), int(device)
+    self.compiled: CompiledPlan = plan.compile(config.time_step_sec, h_conv)
+    cp = self.compiled
+    self.Z, self.H, self.W = cp.Z, cp.H, cp.W
+    zone_names = list(zone_names or plan.zone_names or [f"room_{i + 1}" for i in range(cp.Z)])
+    (self.field_names, col_ahu, col_blr, col_zone, col_aux) = observation_field_names(
+        zone_names, config.ahu_has_weather_sensor)
+    self.O = len(self.field_names)
+    norm = dict(observation_normalization or {})
+    mean = np.zeros(self.O)
+    sigma = np.ones(self.O)
+    for i, name in enumerate(self.field_names[:col_aux]):
+      mu, var = norm.get(name.split("/", 1)[1], (0.0, 1.0))
+      # ContinuousVariableInfo fields are proto floats (smart_control_normalization.proto)
+      mu, var = float(np.float32(mu)), float(np.float32(var))
+      mean[i] = mu
+      sigma[i] = math.sqrt(var) if var > 0.0 else 0.0
+    self._keep = dict(
+        cls=np.ascontiguousarray(cp.cell_class), coef=np.ascontiguousarray(cp.class_coef),
+        czone=np.ascontiguousarray(cp.class_zone), zoff=np.ascontiguousarray(cp.zone_off),
+        zcells=np.ascontiguousarray(cp.zone_cells), colz=np.asarray(col_zone, dtype=np.int32),
+        mean=mean, sigma=sigma)
+    k = self._keep
+    pd_ = _ffi.PlanDesc(cp.H, cp.W, cp.Z, cp.n_classes,
+                        k["cls"].ctypes.data_as(C.POINTER(C.c_uint8)),
+                        k["coef"].ctypes.data_as(_ffi._dp), k["czone"].ctypes.data_as(_ffi._ip),
+                        k["zoff"].ctypes.data_as(_ffi._ip), k["zcells"].ctypes.data_as(_ffi._ip))
+    ol = _ffi.ObsLayout(self.O, col_ahu, col_blr, col_aux, k["colz"].ctypes.data_as(_ffi._ip),
+                        mean.ctypes.data_as(_ffi._dp), sigma.ctypes.data_as(_ffi._dp))
+    params = config.to_params()
+    h = C.c_void_p()
+    with torch.cuda.device(self.device):
+      _ffi.check(self._lib.sb_create(C.byref(pd_), C.byref(params), C.byref(ol), self.B, self.device,
+                                     C.byref(h)), "sb_create")
+    self._h = h
+    self.tdev = torch.device("cuda", self.device)
+    info = _ffi.LaunchInfo()
+    _ffi.check(self._lib.sb_get_launch_info(self._h, C.byref(info)), "sb_get_launch_info")
+    self.launch_info = {f[0]: getattr(info, f[0]) for f in _ffi.LaunchInfo._fields_}
+
+  def close(self) -> None:
+    if getattr(self, "_h", None):
+      self._lib.sb_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def _stream(self) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
+
+  # ---- Simulator.reset() ----
+  def reset(self, initial_temp: Optional[float] = None, temps: Optional[torch.Tensor] = None) -> None:
+    ptr = None
+    if temps is not None:
+      if temps.dtype != torch.float64 or tuple(temps.shape) != (self.B, self.H * self.W) or not temps.is_contiguous():
+        raise ValueError("temps must be a contiguous float64 [B, H*W] tensor")
+      ptr = C.c_void_p(temps.data_ptr())
+    t0 = self.config.initial_temp if initial_temp is None else float(initial_temp)
+    _ffi.check(self._lib.sb_reset(self._h, t0, ptr, self._stream()), "sb_reset")
+
+  def observe(self, aux: Sequence[float], t_amb: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = out if out is not None else torch.empty((self.B, self.O), dtype=torch.float32, device=self.tdev)
+    a = (C.c_float * _ffi.SB_NUM_AUX)(*[float(x) for x in aux])
+    _ffi.check(self._lib.sb_observe(self._h, a, float(t_amb), C.c_void_p(out.data_ptr()), self._stream()),
+               "sb_observe")
+    return out
+
+  def step(self, actions: Optional[torch.Tensor], step_in: _ffi.StepIn, obs: torch.Tensor,
+           reward: torch.Tensor, info: Optional[torch.Tensor] = None) -> None:
+    if actions is not None:
+      if actions.dtype != torch.float32 or tuple(actions.shape) != (self.B, _ffi.SB_NUM_ACTIONS):
+        raise ValueError(f"actions must be float32 [{self.B}, {_ffi.SB_NUM_ACTIONS}]")
+      if not actions.is_contiguous():
+        actions = actions.contiguous()
+    _ffi.check(self._lib.sb_step(
+        self._h, C.c_void_p(actions.data_ptr()) if actions is not None else None, C.byref(step_in),
+        C.c_void_p(obs.data_ptr()) if obs is not None else None, C.c_void_p(reward.data_ptr()),
+        C.c_void_p(info.data_ptr()) if info is not None else None, self._stream()), "sb_step")
+
+  # ---- parity taps ----
+  def _get(self, fn, shape, dtype):
+    out = torch.empty(shape, dtype=dtype, device=self.tdev)
+    _ffi.check(fn(self._h, C.c_void_p(out.data_ptr()), self._stream()), fn.__name__)
+    return out
+
+  def temps(self) -> torch.Tensor:
+    return self._get(self._lib.sb_get_temps, (self.B, self.H, self.W), torch.float64)
+
+  def zone_temps(self) -> torch.Tensor:
+    return self._get(self._lib.sb_get_zone_temps, (self.B, self.Z), torch.float64)
+
+  def scalars(self) -> torch.Tensor:
+    return self._get(self._lib.sb_get_scalars, (self.B, _ffi.SB_NUM_SCALARS), torch.float64)
+
+  def modes(self) -> torch.Tensor:
+    return self._get(self._lib.sb_get_modes, (self.B, self.Z), torch.int32)
+
+  def zone_power(self) -> torch.Tensor:
+    return self._get(self._lib.sb_get_zone_power, (self.B, self.Z), torch.float64)
+
+
+class BatchedEnvironment:
+  """B lock-stepped sbsim environments behind ``reset()`` / ``step(action)``."""
+
+  def __init__(self, plan: FloorPlan, n_buildings: int, config: Optional[SimConfig] = None,
+               weather=None, occupancy=None, start_timestamp=dt.datetime(2023, 7, 6, 7, 0, 0),
+               num_days_in_episode: float = 3, discount_factor: float = 1.0, device: int = 0,
+               observation_normalization: Optional[Mapping[str, Tuple[float, float]]] = None,
+               occupancy_normalization_constant: float = 0.0, holiday_calendar="us",
+               electricity_energy_cost=None, natural_gas_energy_cost=None, collect_info: bool = False):
+    if discount_factor <= 0 or discount_factor > 1:
+      raise ValueError("Discount factor must be in (0,1]")   # environment.py:454-455
+    self.config = config or SimConfig.sb1()
+    self.weather = weather or host_inputs.WeatherController(273.0, 283.0, convection_coefficient=100.0)
+    self.occupancy = occupancy or host_inputs.StepFunctionOccupancy(
+        dt.timedelta(hours=9), dt.timedelta(hours=17), 10.0, 0.1, holiday_calendar=holiday_calendar)
+    self.schedule = self.config.schedule()
+    self.electricity = electricity_energy_cost or host_inputs.ElectricityEnergyCost(
+        holiday_calendar=holiday_calendar)
+    self.gas = natural_gas_energy_cost or host_inputs.NaturalGasEnergyCost()
+    self.discount_factor = float(discount_factor)
+    self._start_timestamp = host_inputs.as_datetime(start_timestamp)
+    self._occ_norm = float(occupancy_normalization_constant)
+    h_conv = self.weather.get_air_convection_coefficient(self._start_timestamp)
+    self.sim = BatchedSimulator(plan, self.config, n_buildings, h_conv, device,
+                                observation_normalization)
+    self.batch_size = self.sim.B
+    self._step_interval = dt.timedelta(seconds=self.config.time_step_sec)
+    # environment.py:427-435
+    self._num_timesteps_in_episode = int(dt.timedelta(days=num_days_in_episode) / self._step_interval)
+    self._action_spec = ArraySpec((_ffi.SB_NUM_ACTIONS,), np.dtype(np.float32), "action", -1.0, 1.0)
+    self._observation_spec = ArraySpec((self.sim.O,), np.dtype(np.float32), "observation")
+    self.field_names = self.sim.field_names
+    dev = self.sim.tdev
+    self._obs = torch.zeros((self.batch_size, self.sim.O), dtype=torch.float32, device=dev)
+    self._reward = torch.zeros((self.batch_size,), dtype=torch.float32, device=dev)
+    self._info = (torch.zeros((self.batch_size, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device=dev)
+                  if collect_info else None)
+    self._discount = torch.full((self.batch_size,), self.discount_factor, dtype=torch.float32, device=dev)
+    self._zero = torch.zeros((self.batch_size,), dtype=torch.float32, device=dev)
+    self._episode_ended = False
+    self._step_count = 0
+    self._episode_count = 0
+    self._prev_thermostat_ts = None   # Thermostat._previous_timestamp survives reset()
+    self._now = self._start_timestamp
+    self._needs_reset = True
+
+  # ---- specs / properties (environment.py:522-540,1215-1221) ----
+  def action_spec(self) -> ArraySpec:
+    return self._action_spec
+
+  def observation_spec(self) -> ArraySpec:
+    return self._observation_spec
+
+  @property
+  def batched(self) -> bool:
+    return True
+
+  @property
+  def steps_per_episode(self) -> int:
+    return self._num_timesteps_in_episode
+
+  @property
+  def current_simulation_timestamp(self) -> dt.datetime:
+    return self._now
+
+  @property
+  def info(self) -> Optional[torch.Tensor]:
+    return self._info
+
+  # ---- host-side step inputs ----
+  def _aux(self, ts: dt.datetime):
+    """environment.py:916-956 auxiliary features at the observation time."""
+    hod = host_inputs.get_radian_time(ts, hour_of_day=True)
+    dow = host_inputs.get_radian_time(ts, hour_of_day=False)
+    n_occ = 0.0   # simulator_building.py:305-315
+    for _ in range(self.sim.Z):
+      n_occ += self.occupancy.average_zone_occupancy("", ts - dt.timedelta(minutes=5), ts)
+    n_occ = int(n_occ)
+    return [np.float32(np.cos(hod)), np.float32(np.sin(hod)), np.float32(np.cos(dow)),
+            np.float32(np.sin(dow)), np.float32(self.schedule.is_comfort_mode(ts)),
+            np.float32(self.schedule.is_comfort_mode(ts + dt.timedelta(minutes=60))),
+            np.float32((n_occ - self._occ_norm) / (self._occ_norm + 1))]
+
+  def make_step_in(self, ts: dt.datetime, has_action: bool = True) -> _ffi.StepIn:
+    nxt = ts + self._step_interval
+    si = _ffi.StepIn()
+    si.t_amb_now = self.weather.get_current_temp(ts)
+    si.t_amb_next = self.weather.get_current_temp(nxt)
+    si.comfort_now = int(self.schedule.is_comfort_mode(ts))
+    si.comfort_prev = (-1 if self._prev_thermostat_ts is None
+                       else int(self.schedule.is_comfort_mode(self._prev_thermostat_ts)))
+    si.comfort_next = int(self.schedule.is_comfort_mode(nxt))
+    si.has_action = int(has_action)
+    si.occupancy = self.occupancy.average_zone_occupancy("", nxt, nxt + self._step_interval)
+    start_utc = host_inputs.reward_start_time_utc(nxt)
+    si.e_price, si.e_carbon = self.electricity.rates(start_utc)
+    si.g_price, si.g_carbon = self.gas.rates(start_utc)
+    for i, v in enumerate(self._aux(nxt)):
+      si.aux[i] = float(v)
+    return si
+
+  # ---- PyEnvironment API ----
+  def reset(self) -> TimeStep:
+    """environment.py:1165-1212."""
+    self.sim.reset()
+    self._now = self._start_timestamp
+    self._episode_ended = False
+    self._episode_count += 1
+    self._step_count = 0
+    self._needs_reset = False
+    self.sim.observe(self._aux(self._now), self.weather.get_current_temp(self._now), self._obs)
+    first = torch.full((self.batch_size,), STEP_FIRST, dtype=torch.int32, device=self.sim.tdev)
+    return TimeStep(first, self._zero, torch.ones_like(self._discount), self._obs)
+
+  def step(self, action: torch.Tensor) -> TimeStep:
+    """environment.py:1228-1370."""
+    if self._needs_reset or self._episode_ended:
+      return self.reset()
+    si = self.make_step_in(self._now)
+    self.sim.step(action, si, self._obs, self._reward, self._info)
+    self._prev_thermostat_ts = self._now
+    self._now = self._now + self._step_interval
+    self._episode_ended = self._step_count >= self._num_timesteps_in_episode   # :1366-1368
+    dev = self.sim.tdev
+    if self._episode_ended:
+      last = torch.full((self.batch_size,), STEP_LAST, dtype=torch.int32, device=dev)
+      return TimeStep(last, self._reward, self._zero, self._obs)
+    self._step_count += 1
+    mid = torch.full((self.batch_size,), STEP_MID, dtype=torch.int32, device=dev)
+    return TimeStep(mid, self._reward, self._discount, self._obs)
+
+  def close(self) -> None:
+    self.sim.close()

@@ -1,0 +1,235 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference-generated goldens
+and against the CPU oracle on seeded inputs.
+
+Tolerances (BASELINE.json north_star: "temperatures within 1e-4 C of reference"):
+  * control-volume and zone temperatures: |dT| <= 1e-4 K is the contract; the kernel
+    computes in float64 (reassociated sums, reciprocal multiply, fma) so the OBSERVED
+    bound asserted here is 1e-8 K, and Gauss-Seidel sweep counts must be EQUAL;
+  * fp32 proto fields (energy rates, reward): relative 2e-6 / absolute 1e-6;
+  * cumulative energy over the day: relative 1e-6.
+"""
+import ctypes as C
+import datetime as dt
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as orc  # noqa: E402  (checker only)
+from sbsim_amd import _ffi  # noqa: E402
+from sbsim_amd.environment import (BatchedEnvironment, BatchedSimulator, SimConfig,  # noqa: E402
+                                   observation_field_names)
+from sbsim_amd.floorplan import FloorPlan, Material, Materials  # noqa: E402
+from tests.golden_util import load, oracle_params, oracle_plan  # noqa: E402
+
+T_TOL = 1e-8
+TEST_SMALL = Materials(Material(50., 700., 1.), Material(2., 500., 1800.), Material(.05, 500., 3000.))
+
+
+def _need_gpu():
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+
+
+def _plan(p):
+  return FloorPlan(conductivity=p["conductivity"], heat_capacity=p["heat_capacity"],
+                   density=p["density"], exterior_space=p["exterior_space"],
+                   zone_label=p["zone_label"], diffusers=p["diffusers"],
+                   cv_size_cm=float(p["cv_size_cm"]), floor_height_cm=float(p["floor_height_cm"]),
+                   zone_names=tuple(str(z) for z in p["zone_names"]))
+
+
+def _step_in(g, t, has_action=True, occupancy=None):
+  si = _ffi.StepIn()
+  si.t_amb_now, si.t_amb_next = float(g["t_amb_now"][t]), float(g["t_amb_next"][t])
+  si.comfort_now, si.comfort_prev, si.comfort_next = (int(g["comfort_now"][t]), int(g["comfort_prev"][t]),
+                                                      int(g["comfort_next"][t]))
+  si.has_action = int(has_action)
+  si.occupancy = float(g["occupancy"][t]) if occupancy is None else occupancy
+  si.e_price, si.e_carbon = float(g["e_price"][t]), float(g["e_carbon"][t])
+  si.g_price, si.g_carbon = float(g["g_price"][t]), float(g["g_carbon"][t])
+  return si
+
+
+@pytest.mark.parametrize("tag", ["random", "const"])
+def test_one_day_rollout_against_reference_golden(tag):
+  """BASELINE.json configs[0] semantics on the GPU: SB1 physics on R9, 288 steps."""
+  _need_gpu()
+  g = load(f"h2_sb1_r9_{tag}.npz")
+  B = 5
+  sim = BatchedSimulator(_plan(load("plan_r9_sb1.npz")), SimConfig.sb1(), B, float(g["h_conv"]))
+  sim.reset()
+  obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  T = len(g["n_sweeps"])
+  col = observation_field_names([str(z) for z in g["zone_names"]], True)
+  names, col_aux = col[0], col[4]
+  assert [n for n in names[:col_aux]] == [str(n) for n in g["obs_names"]]
+  worst_t, worst_r = 0.0, 0.0
+  for t in range(T):
+    act = torch.tensor(np.tile(g["actions_norm"][t], (B, 1)), dtype=torch.float32, device="cuda")
+    sim.step(act, _step_in(g, t), obs, rew, info)
+    i = info.cpu().numpy().astype(np.float64)
+    zt = sim.zone_temps().cpu().numpy()
+    assert (i[:, 4] == g["n_sweeps"][t]).all(), (t, i[:, 4], g["n_sweeps"][t])
+    worst_t = max(worst_t, np.abs(zt - g["zone_temp_post"][t]).max())
+    assert np.abs(zt - g["zone_temp_post"][t]).max() < T_TOL, t
+    ref_rates = g["rates"][t].astype(np.float64)
+    assert np.allclose(i[:, :4], ref_rates, rtol=2e-6, atol=1e-6), (t, i[0, :4], ref_rates)
+    r = rew.cpu().numpy().astype(np.float64)
+    worst_r = max(worst_r, np.abs(r - float(g["reward"][t])).max())
+    assert np.abs(r - float(g["reward"][t])).max() < 1e-6, t
+    # native observation values (identity normalisation) == the proto's fp32 values
+    o = obs.cpu().numpy()
+    assert np.allclose(o[:, :col_aux], g["obs"][t], rtol=1e-6, atol=1e-6), t
+    if t + 1 in (1, 144):
+      assert np.abs(sim.temps().cpu().numpy() - g[f"grid_{t + 1}"]).max() < T_TOL
+  grid = sim.temps().cpu().numpy()
+  assert np.abs(grid - g["final_grid"]).max() < T_TOL
+  sc = sim.scalars().cpu().numpy()
+  ref_cum = g["rates"].astype(np.float64).sum(axis=0) * 300.0
+  assert np.allclose(sc[:, 12:16], ref_cum, rtol=1e-6)
+  assert np.allclose(sc[:, 8], g["blr_tank_temp"][-1], atol=1e-9)
+  print(f"[{tag}] max |dT_zone| = {worst_t:.3e} K, max |d reward| = {worst_r:.3e}")
+
+
+@pytest.mark.parametrize("name,golden", [("small_test", "h1_small_test.npz"),
+                                         ("weird_test", "h1_weird_test.npz"),
+                                         ("r9_test", "h1_r9_test_cold200.npz")])
+def test_thermostat_only_rollouts_on_reference_test_plans(name, golden):
+  """Bare Simulator.step_sim() goldens: odd shapes (W odd, n<=1 cells), 100-sweep steps,
+  and the reference KAT 301.895482 (simulator_flexible_floor_plan_test.py:1275-1312)."""
+  _need_gpu()
+  g = load(golden)
+  p = load(f"plan_{name}.npz")
+  import json
+  prm = json.loads(str(g["params_json"]))
+  cfg = SimConfig(
+      time_step_sec=prm["dt"], convergence_threshold=prm["conv_threshold"], iteration_limit=prm["iter_limit"],
+      comfort_temp_window=(prm["comfort_lo"], prm["comfort_hi"]), eco_temp_window=(prm["eco_lo"], prm["eco_hi"]),
+      vav_max_air_flow_rate=prm["vav_max_air_flow"], vav_reheat_max_water_flow_rate=prm["vav_max_water_flow"],
+      ahu_recirculation=prm["ahu_recirc"], ahu_heating_air_temp_setpoint=prm["ahu_heat_sp"],
+      ahu_cooling_air_temp_setpoint=prm["ahu_cool_sp"], ahu_fan_differential_pressure=prm["ahu_dp"],
+      ahu_fan_efficiency=prm["ahu_eff"], ahu_max_air_flow_rate=prm["ahu_max_flow"], ahu_has_weather_sensor=False,
+      boiler_reheat_water_setpoint=prm["blr_setpoint"], boiler_water_pump_differential_head=prm["blr_head"],
+      boiler_water_pump_efficiency=prm["blr_pump_eff"], boiler_heating_rate=prm["blr_heating_rate"],
+      boiler_cooling_rate=prm["blr_cooling_rate"], initial_temp=float(g["initial_temp"]))
+  B = 3
+  sim = BatchedSimulator(_plan(p), cfg, B, float(g["h_conv"]))
+  sim.reset()
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  comfort = g["comfort"]
+  for t in range(len(g["n_sweeps"])):
+    si = _ffi.StepIn()
+    si.t_amb_now = si.t_amb_next = float(g["t_amb"])
+    si.comfort_now, si.comfort_next = int(comfort[t]), int(comfort[t + 1])
+    si.comfort_prev = int(comfort[t - 1]) if t else -1
+    si.has_action = 0
+    si.occupancy, si.e_price, si.e_carbon, si.g_price, si.g_carbon = 1.0, 1e-8, 1e-8, 1e-8, 1e-8
+    sim.step(None, si, None, rew, info)
+    i = info.cpu().numpy()
+    assert (i[:, 4] == g["n_sweeps"][t]).all(), (t, i[:, 4], g["n_sweeps"][t])
+    assert np.abs(sim.zone_temps().cpu().numpy() - g["zone_temp_post"][t]).max() < T_TOL, t
+    sc = sim.scalars().cpu().numpy()
+    assert np.abs(sc[:, 7] - g["blr_return_temp"][t]).max() < 1e-9, t
+    assert (sim.modes().cpu().numpy() == g["mode"][t]).all(), t
+  assert np.abs(sim.temps().cpu().numpy() - g["final_grid"]).max() < T_TOL
+  if name == "r9_test":
+    assert abs(float(g["blr_return_temp"][0]) - 301.895482) < 1e-5
+
+
+def test_divergent_buildings_against_oracle():
+  """Config-2 style: per-building initial temperatures and per-building random actions;
+  every building is checked against its own CPU-oracle twin."""
+  _need_gpu()
+  g = load("h2_sb1_r9_random.npz")
+  p = load("plan_r9_sb1.npz")
+  B, T = 24, 40
+  rs = np.random.RandomState(7)
+  init = np.clip(294.0 + rs.randn(B, 1, 1) + 0.3 * rs.randn(B, 68, 98), 285.0, 305.0)
+  acts = rs.uniform(-1, 1, size=(T, B, 2)).astype(np.float32)
+  sim = BatchedSimulator(_plan(p), SimConfig.sb1(), B, float(g["h_conv"]))
+  sim.reset(temps=torch.tensor(init.reshape(B, -1), dtype=torch.float64, device="cuda"))
+  plan, prm = oracle_plan(p), oracle_params(g["params_json"])
+  twins = [orc.OracleBuilding(plan, prm, 0.0, reset_temps=init[b].reshape(-1)) for b in range(B)]
+  obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  rng_w, rng_a = (310.0, 355.0), (285.0, 300.0)
+  for t in range(T):
+    sim.step(torch.tensor(acts[t], device="cuda"), _step_in(g, t + 100), obs, rew, info)
+    i = info.cpu().numpy().astype(np.float64)
+    zt = sim.zone_temps().cpu().numpy()
+    r = rew.cpu().numpy()
+    for b in range(B):
+      a = acts[t, b]
+      native = [np.float32((float(a[0]) + 1.0) / 2.0 * (rng_w[1] - rng_w[0]) + rng_w[0]),
+                np.float32((float(a[1]) + 1.0) / 2.0 * (rng_a[1] - rng_a[0]) + rng_a[0])]
+      tt = t + 100
+      o = twins[b].step(
+          now_ts=300.0 * t, t_amb_now=float(g["t_amb_now"][tt]), h_conv=float(g["h_conv"]),
+          t_amb_next=float(g["t_amb_next"][tt]), comfort_now=bool(g["comfort_now"][tt]),
+          comfort_prev=g["comfort_prev"][tt] == 1, comfort_next=bool(g["comfort_next"][tt]),
+          occupancy=float(g["occupancy"][tt]), e_price=float(g["e_price"][tt]),
+          e_carbon=float(g["e_carbon"][tt]), g_price=float(g["g_price"][tt]),
+          g_carbon=float(g["g_carbon"][tt]), action=native, observe=True)
+      assert i[b, 4] == o["n_sweeps"], (t, b, i[b, 4], o["n_sweeps"])
+      assert np.abs(zt[b] - o["zone_temp_post"]).max() < T_TOL, (t, b)
+      ref = np.array([o["blower_rate"], o["ac_rate"], o["gas_rate"], o["pump_rate"]], np.float64)
+      assert np.allclose(i[b, :4], ref, rtol=2e-6, atol=1e-6), (t, b)
+      assert abs(float(r[b]) - o["reward"]) < 1e-6, (t, b)
+  grid = sim.temps().cpu().numpy()
+  for b in range(B):
+    assert np.abs(grid[b] - twins[b].grid()).max() < T_TOL, b
+
+
+def test_environment_api_episode_bookkeeping():
+  """environment.py:1165-1212,1311-1368: restart / N transitions / termination / auto-reset,
+  plus observation normalisation and auxiliary features."""
+  _need_gpu()
+  g = load("h2_sb1_r9_const.npz")
+  from sbsim_amd.environment import SB1_OBSERVATION_NORMALIZATION
+  env = BatchedEnvironment(_plan(load("plan_r9_sb1.npz")), 4, num_days_in_episode=5 * 300 / 86400.0,
+                           holiday_calendar=None, observation_normalization=SB1_OBSERVATION_NORMALIZATION,
+                           collect_info=True)
+  assert env.action_spec().shape == (2,) and env.observation_spec().shape == (46,)
+  assert env.steps_per_episode == 5
+  ts = env.reset()
+  assert int(ts.step_type[0]) == 0 and ts.observation.shape == (4, 46)
+  a = torch.tensor(np.tile(g["actions_norm"][0], (4, 1)), device="cuda")
+  kinds = []
+  for k in range(7):
+    ts = env.step(a)
+    kinds.append(int(ts.step_type[0]))
+    if k == 0:
+      o = ts.observation.cpu().numpy()[0]
+      names = env.field_names
+      j = names.index("boiler_id/supply_water_setpoint")
+      assert abs(o[j] - (340.0 - 310.0) / 50.0) < 1e-6
+      j = names.index("vav_room_1/zone_air_temperature_sensor")
+      assert abs(o[j] - (np.float32(g["zone_temp_pre"][0][0]) - 190.0) / np.sqrt(np.float32(408.113303))) < 1e-5
+      assert abs(float(ts.reward[0]) - float(g["reward"][0])) < 1e-6
+      assert abs(o[names.index("hod_cos_000")] - np.cos(2 * np.pi * (7 * 3600 + 300) / 86400.0)) < 1e-6
+  # 5 transitions, the terminal step, then the auto-reset (FIRST)
+  assert kinds == [1, 1, 1, 1, 1, 2, 0], kinds
+  env.close()
+
+
+def test_abi_error_paths():
+  _need_gpu()
+  L = _ffi.load()
+  assert L.sb_abi_version() == 1
+  h = C.c_void_p()
+  assert L.sb_create(None, None, None, 1, 0, C.byref(h)) == -1
+  assert b"null" in L.sb_last_error()
+  p = load("plan_small_test.npz")
+  cfg = SimConfig(ahu_heating_air_temp_setpoint=300.0, ahu_cooling_air_temp_setpoint=290.0)
+  with pytest.raises(_ffi.SbsimError, match="cooling_air_temp_setpoint"):
+    BatchedSimulator(_plan(p), cfg, 2, 12.0)
+  sim = BatchedSimulator(_plan(p), SimConfig(), 2, 12.0)
+  with pytest.raises(ValueError):
+    sim.step(torch.zeros((3, 2), device="cuda"), _ffi.StepIn(), None, torch.zeros(2, device="cuda"))
