@@ -152,6 +152,10 @@ int sb_get_scalars(sb_handle *h, double *out_dev, void *stream);
 int sb_get_modes(sb_handle *h, int32_t *out_dev /* [B][Z] */, void *stream);
 int sb_get_zone_power(sb_handle *h, double *out_dev /* [B][Z] VAV power applied */, void *stream);
 
+/* Developer aid: when SBSIM_PHASE_TIMING is set at sb_create, the step kernel stamps the
+ * shader clock at its phase boundaries for building 0; copies 16 int64 to a HOST buffer. */
+int sb_debug_phase_cycles(sb_handle *h, long long *out_host);
+
 #ifdef __cplusplus
 }
 #endif

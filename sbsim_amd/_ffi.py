@@ -73,7 +73,7 @@ class LaunchInfo(C.Structure):
 
 EXPORTS = ("sb_abi_version", "sb_last_error", "sb_create", "sb_destroy", "sb_get_launch_info",
            "sb_reset", "sb_observe", "sb_step", "sb_get_temps", "sb_get_zone_temps",
-           "sb_get_scalars", "sb_get_modes", "sb_get_zone_power")
+           "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles")
 
 _lib = None
 
@@ -106,6 +106,7 @@ def load():
   for name in ("sb_get_temps", "sb_get_zone_temps", "sb_get_scalars", "sb_get_modes",
                "sb_get_zone_power"):
     getattr(L, name).argtypes = [vp, vp, vp]
+  L.sb_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_longlong)]
   _lib = L
   return L
 

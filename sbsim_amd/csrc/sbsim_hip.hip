@@ -34,7 +34,7 @@ constexpr double kRhoWater = 1000.0; // utils/constants.py:46
 constexpr double kGravity = 9.8;     // utils/constants.py:47
 constexpr int kNScal = 16;
 constexpr int kChunk = 8;            // sweep steps per software-pipelined chunk
-constexpr int kCoef = 6;             // doubles per class row in LDS: bU bD bL bR ap (pad)
+constexpr int kPad = 8;              // doubles (bytes for cls) of padding around each grid in HBM
 
 thread_local std::string g_err;
 
@@ -53,18 +53,19 @@ int fail(int code, const std::string &msg) {
 // Everything a kernel needs, passed by value.
 struct Dev {
   int B, H, W, Z, N, Np, ncls, pitch, NL;
-  int S, nsteps;           // band stride (max(W,64)) and sweep steps per sweep
+  int S, nsteps;           // band stride (max(W+8,64)) and sweep steps per sweep
   unsigned S_magic;        // floor(2^32 / S) + 1
+  int nbands, fast;        // fast: register/DPP sweep is legal for this shape
   int lds_wave_doubles;    // per-wave LDS region, in doubles
-  int off_gtab, off_zscr, off_zmode; // offsets inside the per-wave region (doubles)
+  int off_agtab, off_zscr, off_zmode; // offsets inside the per-wave region (doubles)
   // static tables
-  const uint8_t *cls;      // [N]
+  const uint8_t *cls;      // [kPad + N + kPad], grid at +kPad
   const double *ctab;      // [ncls][8]
   const int *czone;        // [ncls]
   const int *zone_off;     // [Z+1]
   const int *zone_cells_l; // LDS index of every zone cell
   // state
-  double *temp;            // [B][Np]
+  double *temp;            // [B][Np], grid at +kPad (zero padding both sides)
   double *zmean;           // [B][Z] zone means of the current grid
   double *zair;            // [B][Z] Vav._zone_air_temperature
   double *damper;          // [B][Z]
@@ -75,6 +76,7 @@ struct Dev {
   int O, col_ahu, col_blr, col_aux;
   const int *col_zone;
   const double *obs_mean, *obs_sigma;
+  long long *dbg;          // optional [16] phase time stamps of wave 0's first building
   sb_params p;
 };
 
@@ -120,11 +122,35 @@ __device__ __forceinline__ int default_control(int mode, double tz, double hsp, 
 }
 
 // ---------------------------------------------------------------- the sweep
-// Lane l owns rows l, l+64, ... ("bands"); at step d it updates column y = d - l - band*S
-// of row band*64 + l.  Cell (x,y) is therefore updated after (x-1,y) and (x,y-1) and
-// before (x+1,y) and (x,y+1): the reference's row-major in-place order
-// (simulator.py:302-314).  T' = ap*Tprev + g + bU*U + bD*D + bL*L + bR*R, see
-// sbsim_amd/floorplan.py for how the three reference formulas fold into that.
+// Lane l owns rows l, l+64, ... ("bands"); its cells form one sequence of positions
+// v = band*S + y and at step d it updates position v = d - l.  Cell (x,y) is therefore
+// updated after (x-1,y) and (x,y-1) and before (x+1,y) and (x,y+1): the reference's
+// row-major in-place order (simulator.py:302-314).  Every update is
+//     T' = ap*Tprev + g + bU*U + bD*D + bL*L + bR*R
+// (sbsim_amd/floorplan.py folds the corner / edge / interior / exterior formulas into
+// per-class coefficients; missing neighbours have b = 0, so any finite value may stand in).
+//
+// LDS tables: btab[c] = {bU,bD,bL,bR} (shared by the workgroup), agtab[c] = {ap, g} (per
+// wave: g depends on the building's ambient temperature and VAV power); row `ncls` of both
+// is all zeros and is what idle lanes look up, so they compute exactly 0.
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
+
+// lane l <- lane l-1 (lane 0 keeps its own value) / lane l <- lane l+1 (lane 63 keeps).
+__device__ __forceinline__ double wave_shr1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// -- generic sweep: every neighbour through LDS; legal for any shape (fallback) ----------
 struct Chunk {
   double P[kChunk];
   int li[kChunk]; // LDS index, -1 when the lane is idle at that step
@@ -140,15 +166,15 @@ __device__ __forceinline__ void load_chunk(const Dev &a, const double *__restric
     int y = v - band * a.S;
     int r = band * 64 + lane;
     bool act = (v >= 0) && (y < a.W) && (r < a.H);
-    int g = r * a.W + y;
+    int g = act ? r * a.W + y : 0;
     ch.li[k] = act ? (r * a.pitch + y) : -1;
-    ch.P[k] = act ? Pg[g] : 0.0;
-    ch.c[k] = act ? (int)a.cls[g] : 0;
+    ch.P[k] = Pg[g];
+    ch.c[k] = (int)a.cls[kPad + g];
   }
 }
 
-__device__ double sweep(const Dev &a, double *E, const double *gtab, const double *ctabL,
-                        const double *__restrict__ Pg, int lane) {
+__device__ double sweep_generic(const Dev &a, double *E, const double *agtab, const double *btab,
+                                const double *__restrict__ Pg, int lane) {
   double dmax = 0.0;
   const int pitch = a.pitch, last = a.NL - 1;
   Chunk cur, nxt;
@@ -160,17 +186,16 @@ __device__ double sweep(const Dev &a, double *E, const double *gtab, const doubl
     for (int k = 0; k < kChunk; ++k) {
       const int li = cur.li[k];
       if (li >= 0) {
-        const double *co = ctabL + cur.c[k] * kCoef;
-        const double bU = co[0], bD = co[1], bL = co[2], bR = co[3], ap = co[4];
-        const double gg = gtab[cur.c[k]];
+        const double *bt = btab + cur.c[k] * 4;
+        const double *ag = agtab + cur.c[k] * 2;
         const double U = E[max(li - pitch, 0)], D = E[min(li + pitch, last)];
         const double L = E[max(li - 1, 0)], R = E[min(li + 1, last)];
         const double old = E[li];
-        double nv = fma(ap, cur.P[k], gg);
-        nv = fma(bD, D, nv);
-        nv = fma(bR, R, nv);
-        nv = fma(bL, L, nv);
-        nv = fma(bU, U, nv);
+        double nv = fma(ag[0], cur.P[k], ag[1]);
+        nv = fma(bt[1], D, nv);
+        nv = fma(bt[3], R, nv);
+        nv = fma(bt[2], L, nv);
+        nv = fma(bt[0], U, nv);
         dmax = fmax(dmax, fabs(nv - old));
         E[li] = nv;
       }
@@ -178,6 +203,170 @@ __device__ double sweep(const Dev &a, double *E, const double *gtab, const doubl
     }
   }
   return wave_max(dmax);
+}
+
+// -- fast sweep ------------------------------------------------------------------------
+// A single wavefront issues about one instruction every 5 cycles and only 3 buildings fit
+// in a CU's LDS, so the sweep is instruction-issue bound: the loop below is written to
+// need as few instructions per control volume as possible.
+//   * L is the lane's previous result (register); U is the previous result of lane l-1,
+//     one DPP wave_shr:1 move per 32-bit half.  Lane 0 has no source lane and keeps the
+//     DPP `old` operand, which is pre-loaded with the band-seam value from LDS (MULTI).
+//   * R (old value one column ahead in the lane's own row -- next step it is the cell's own
+//     old value) and D (old value one row down) are plain ds_read_b64 with immediate
+//     offsets from per-chunk base addresses; guard doubles around E keep every address
+//     legal without clamping.
+//   * Coefficients, ap*Tprev+g, R, D and the seam value are gathered one 8-step chunk
+//     ahead into the slot that was just consumed; Tprev and the class bytes two chunks
+//     ahead (three-stage software pipeline G -> L -> C): nothing in the loop waits on memory.
+//   * Idle lanes run the same arithmetic on whatever (finite) values their addresses hold;
+//     only the LDS store and the max-delta update are masked (per-slot lane masks in SGPRs).
+// Requires S >= W + 8 (one row segment per chunk) and, when H > 64, S - 63 > 16 (the seam
+// row is written at least 17 steps before lane 0 prefetches it).
+constexpr int kGuard = 16; // finite guard doubles before and after E in LDS
+
+struct StageG {
+  double P[kChunk];
+  unsigned long long cw; // 8 class bytes
+  int li0;               // LDS index of position 0 of the chunk (may point before the row)
+  int liD0, liU0;        // same position one row down / one row up (row clamped to the grid)
+  bool act[kChunk];      // position k is a real cell
+};
+struct StageL {
+  double A[kChunk], bU[kChunk], bD[kChunk], bL[kChunk], bR[kChunk], Rn[kChunk], Dn[kChunk], Ee[kChunk];
+};
+
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <bool FIRST>
+__device__ __forceinline__ void stage_g(const Dev &a, const double *E, const double *__restrict__ Pg,
+                                        int ch, int lane, StageG &g) {
+  const int v0 = ch * kChunk - lane;
+  const int vl = v0 + kChunk - 1;
+  const int band = (int)__umulhi((unsigned)max(vl, 0), a.S_magic);
+  const int y0 = v0 - band * a.S;
+  const int r = band * 64 + lane;
+  const bool row_ok = (vl >= 0) && (r < a.H);
+#pragma unroll
+  for (int k = 0; k < kChunk; ++k) g.act[k] = row_ok && (y0 + k >= 0) && (y0 + k < a.W);
+  const int ra = min(r, a.H - 1);
+  // position 0 of the chunk relative to the row (negative while the row has not started);
+  // clamped only so that addresses stay inside the guards / padding
+  const int y0a = clampi(vl >= 0 ? y0 : v0, -kChunk, a.W);
+  g.li0 = ra * a.pitch + y0a;
+  g.liD0 = min(ra + 1, a.H - 1) * a.pitch + y0a;
+  g.liU0 = max(ra - 1, 0) * a.pitch + y0a;
+  const int g0 = ra * a.W + y0a; // in [-8, N]: the grid is padded by kPad on both sides
+  __builtin_memcpy(&g.cw, a.cls + kPad + g0, 8);
+  if (FIRST) { // first sweep: the estimate still equals the previous temperatures
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) g.P[k] = E[g.li0 + k];
+  } else {
+    const dbl2u *src = (const dbl2u *)(Pg + g0);
+#pragma unroll
+    for (int k = 0; k < kChunk / 2; ++k) {
+      dbl2u v = src[k];
+      g.P[2 * k] = v.x;
+      g.P[2 * k + 1] = v.y;
+    }
+  }
+}
+
+// Gathers slot K of the NEXT chunk (described by g) into l.  R of a position is the old
+// value of the lane's NEXT position; for the chunk's last slot that position belongs to the
+// chunk after (base index li0_after), which may sit in another band row.
+template <bool MULTI, int K>
+__device__ __forceinline__ void load_slot(const double *E, const double *agtab, const double *btab,
+                                          const StageG &g, int li0_after, StageL &l) {
+  const int c = (int)((g.cw >> (8 * K)) & 0xffull);
+  const double2 b01 = *(const double2 *)(btab + c * 4);
+  const double2 b23 = *(const double2 *)(btab + c * 4 + 2);
+  const double2 ag = *(const double2 *)(agtab + c * 2);
+  l.bU[K] = b01.x; l.bD[K] = b01.y; l.bL[K] = b23.x; l.bR[K] = b23.y;
+  l.A[K] = fma(ag.x, g.P[K], ag.y);
+  l.Rn[K] = K == kChunk - 1 ? E[li0_after] : E[g.li0 + K + 1];
+  l.Dn[K] = E[g.liD0 + K];
+  if (MULTI) l.Ee[K] = E[g.liU0 + K];
+}
+
+// lane l <- lane l-1's x; lane 0 (no source lane) keeps `seam`.
+__device__ __forceinline__ double shr1_seam(double x, double seam) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(seam), __double2loint(x), 0x138, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(seam), __double2hiint(x), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// One Gauss-Seidel update of the lane's current cell (slot K of the current chunk).
+template <bool MULTI, int K>
+__device__ __forceinline__ void update_slot(double *E, const StageL &l, int li0, bool act,
+                                            double &nv, double &oldv, double &dmax) {
+  const double U = shr1_seam(nv, MULTI ? l.Ee[K] : 0.0);
+  double t = fma(l.bD[K], l.Dn[K], l.A[K]);
+  t = fma(l.bR[K], l.Rn[K], t);
+  t = fma(l.bL[K], nv, t);
+  const double nvn = fma(l.bU[K], U, t);
+  if (act) {
+    E[li0 + K] = nvn;
+    dmax = fmax(dmax, fabs(nvn - oldv));
+  }
+  oldv = l.Rn[K];
+  nv = nvn;
+}
+
+// Computes the chunk held in l (li0/act) while refilling each freed slot with chunk `nx`.
+template <bool MULTI>
+__device__ __forceinline__ void run_chunk(double *E, const double *agtab, const double *btab,
+                                          StageL &l, int li0, const bool (&act)[kChunk],
+                                          const StageG &nx, int li0_after, double &nv, double &oldv,
+                                          double &dmax) {
+#define SB_SLOT(K)                                              \
+  update_slot<MULTI, K>(E, l, li0, act[K], nv, oldv, dmax);      \
+  load_slot<MULTI, K>(E, agtab, btab, nx, li0_after, l);
+  SB_SLOT(0) SB_SLOT(1) SB_SLOT(2) SB_SLOT(3) SB_SLOT(4) SB_SLOT(5) SB_SLOT(6) SB_SLOT(7)
+#undef SB_SLOT
+}
+
+template <bool FIRST, bool MULTI>
+__device__ double sweep_fast(const Dev &a, double *E, const double *agtab, const double *btab,
+                             const double *__restrict__ Pg, int lane) {
+  double dmax = 0.0, nv = 0.0;
+  const int nch = (a.nsteps + kChunk - 1) / kChunk;
+  StageG g0, g1;
+  StageL l;
+  stage_g<FIRST>(a, E, Pg, 0, lane, g0);
+  stage_g<FIRST>(a, E, Pg, 1, lane, g1);
+#define SB_LOAD0(K) load_slot<MULTI, K>(E, agtab, btab, g0, g1.li0, l);
+  SB_LOAD0(0) SB_LOAD0(1) SB_LOAD0(2) SB_LOAD0(3) SB_LOAD0(4) SB_LOAD0(5) SB_LOAD0(6) SB_LOAD0(7)
+#undef SB_LOAD0
+  double oldv = E[g0.li0];
+  int li0 = g0.li0;
+  bool act[kChunk];
+#pragma unroll
+  for (int k = 0; k < kChunk; ++k) act[k] = g0.act[k];
+  for (int ch = 0; ch < nch; ch += 2) {
+    stage_g<FIRST>(a, E, Pg, ch + 2, lane, g0);
+    run_chunk<MULTI>(E, agtab, btab, l, li0, act, g1, g0.li0, nv, oldv, dmax);
+    li0 = g1.li0;
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) act[k] = g1.act[k];
+    stage_g<FIRST>(a, E, Pg, ch + 3, lane, g1);
+    run_chunk<MULTI>(E, agtab, btab, l, li0, act, g0, g1.li0, nv, oldv, dmax);
+    li0 = g0.li0;
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) act[k] = g0.act[k];
+  }
+  return wave_max(dmax);
+}
+
+__device__ __forceinline__ double sweep(const Dev &a, double *E, const double *agtab,
+                                        const double *btab, const double *__restrict__ Pg,
+                                        int lane, bool first) {
+  if (!a.fast) return sweep_generic(a, E, agtab, btab, Pg, lane);
+  if (a.nbands > 1)
+    return first ? sweep_fast<true, true>(a, E, agtab, btab, Pg, lane)
+                 : sweep_fast<false, true>(a, E, agtab, btab, Pg, lane);
+  return first ? sweep_fast<true, false>(a, E, agtab, btab, Pg, lane)
+               : sweep_fast<false, false>(a, E, agtab, btab, Pg, lane);
 }
 
 // ---------------------------------------------------------------- observation row
@@ -190,34 +379,45 @@ __device__ __forceinline__ void put_obs(const Dev &a, float *row, int col, doubl
   row[col] = (float)v;
 }
 
+// S: the building's scalar state (kNScal doubles), wave-uniform, in registers or memory.
 __device__ void write_obs(const Dev &a, int b, int lane, float *obs, const float *aux,
-                          double t_amb_obs) {
+                          double t_amb_obs, const double *S) {
   float *row = obs + (size_t)b * a.O;
-  const double *S = a.scal + (size_t)b * kNScal;
   for (int z = lane; z < a.Z; z += 64) {
     int c0 = a.col_zone[z];
     put_obs(a, row, c0 + 0, a.damper[(size_t)b * a.Z + z]); // supply_air_damper_percentage_command
     put_obs(a, row, c0 + 1, a.p.vav_max_air_flow);          // supply_air_flowrate_setpoint
     put_obs(a, row, c0 + 2, a.zair[(size_t)b * a.Z + z]);   // zone_air_temperature_sensor
   }
-  if (lane == 0) {
-    const double flow = S[2], count = S[3];
-    int c = a.col_ahu; // air_handler.py:66-95, fields in sorted order
-    put_obs(a, row, c++, count);                          // cooling_request_count
-    put_obs(a, row, c++, a.p.ahu_dp);                     // differential_pressure_setpoint
-    put_obs(a, row, c++, flow / a.p.ahu_max_flow);        // discharge_fan_speed_percentage_command
-    put_obs(a, row, c++, (1.0 - a.p.ahu_recirc) * flow);  // outside_air_flowrate_sensor
-    if (a.p.ahu_has_weather) put_obs(a, row, c++, t_amb_obs); // outside_air_temperature_sensor
-    put_obs(a, row, c++, S[1]);                           // supply_air_cooling_temperature_setpoint
-    put_obs(a, row, c++, flow);                           // supply_air_flowrate_sensor
-    put_obs(a, row, c++, S[0]);                           // supply_air_heating_temperature_setpoint
-    put_obs(a, row, c++, flow / a.p.ahu_max_flow);        // supply_fan_speed_percentage_command
-    c = a.col_blr; // boiler.py:69-79
-    put_obs(a, row, c++, S[6]);                           // heating_request_count
-    put_obs(a, row, c++, S[4]);                           // supply_water_setpoint
-    put_obs(a, row, c++, S[8]);                           // supply_water_temperature_sensor
-    for (int i = 0; i < SB_NUM_AUX; ++i) row[a.col_aux + i] = aux[i];
+  // device columns: one lane per field (air_handler.py:66-95 / boiler.py:69-79, sorted order)
+  const int n_ahu = a.p.ahu_has_weather ? 9 : 8;
+  if (lane < n_ahu + 3) {
+    const double flow = S[2];
+    int f = lane; // field index in the 9-entry AHU list (index 4 = outside_air_temperature_sensor)
+    if (!a.p.ahu_has_weather && f >= 4 && f < n_ahu) f += 1;
+    double v;
+    int col;
+    if (lane < n_ahu) {
+      col = a.col_ahu + lane;
+      switch (f) {
+        case 0: v = S[3]; break;                              // cooling_request_count
+        case 1: v = a.p.ahu_dp; break;                        // differential_pressure_setpoint
+        case 2: v = flow / a.p.ahu_max_flow; break;           // discharge_fan_speed_percentage_command
+        case 3: v = (1.0 - a.p.ahu_recirc) * flow; break;     // outside_air_flowrate_sensor
+        case 4: v = t_amb_obs; break;                         // outside_air_temperature_sensor
+        case 5: v = S[1]; break;                              // supply_air_cooling_temperature_setpoint
+        case 6: v = flow; break;                              // supply_air_flowrate_sensor
+        case 7: v = S[0]; break;                              // supply_air_heating_temperature_setpoint
+        default: v = flow / a.p.ahu_max_flow; break;          // supply_fan_speed_percentage_command
+      }
+    } else {
+      const int j = lane - n_ahu;
+      col = a.col_blr + j;
+      v = j == 0 ? S[6] : (j == 1 ? S[4] : S[8]); // heating_request_count, supply_water_setpoint, ..._sensor
+    }
+    put_obs(a, row, col, v);
   }
+  if (lane < SB_NUM_AUX) row[a.col_aux + lane] = aux[lane];
 }
 
 // ---------------------------------------------------------------- kernels
@@ -229,7 +429,8 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps) {
     double *T = a.temp + (size_t)b * a.Np;
     double s = 0.0;
     for (int i = lane; i < a.Np; i += 64) {
-      double v = i < a.N ? (temps ? temps[(size_t)b * a.N + i] : initial_temp) : 0.0;
+      const int g = i - kPad;
+      double v = (g >= 0 && g < a.N) ? (temps ? temps[(size_t)b * a.N + g] : initial_temp) : 0.0;
       T[i] = v;
       s += v;
     }
@@ -268,7 +469,8 @@ __global__ void k_observe(Dev a, float *obs, float aux0, float aux1, float aux2,
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (blockDim.x >> 6);
   const float aux[SB_NUM_AUX] = {aux0, aux1, aux2, aux3, aux4, aux5, aux6};
-  for (int b = wave; b < a.B; b += nwaves) write_obs(a, b, lane, obs, aux, t_amb);
+  for (int b = wave; b < a.B; b += nwaves)
+    write_obs(a, b, lane, obs, aux, t_amb, a.scal + (size_t)b * kNScal);
 }
 
 extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -279,24 +481,32 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
   const int wpb = blockDim.x >> 6;
   const int wave = blockIdx.x * wpb + wib;
   const int nwaves = gridDim.x * wpb;
-  // LDS: [ctabL: ncls*kCoef] then per wave [E: NL | gtab: ncls | zscr: 3*Z | zmode: Z ints]
-  double *ctabL = lds;
-  double *mine = lds + ((a.ncls * kCoef + 1) & ~1) + (size_t)wib * a.lds_wave_doubles;
-  double *E = mine;
-  double *gtab = mine + a.off_gtab;
-  double *zscr = mine + a.off_zscr; // [0..Z) tz_pre, [Z..2Z) q / valve*tzs, [2Z..3Z) tzs
-  int *zmode = (int *)(mine + a.off_zmode);
-  for (int i = threadIdx.x; i < a.ncls * kCoef; i += blockDim.x) {
-    int c = i / kCoef, j = i - c * kCoef;
-    ctabL[i] = j < 5 ? a.ctab[c * 8 + j] : 0.0;
+  // LDS: [btab: (ncls+1)*4] then per wave [E: NL | agtab: (ncls+1)*2 | zscr: 3*Z | zmode: Z ints]
+  double *btab = lds;
+  int *zoffL = (int *)(lds + (a.ncls + 1) * 4); // [Z+1] zone_off, shared
+  double *mine = lds + (a.ncls + 1) * 4 + ((a.Z + 2) >> 1) + (size_t)wib * a.lds_wave_doubles;
+  double *E = mine + kGuard; // [guard | E: NL | guard]: the guards stay zero (finite) forever
+  for (int i = lane; i < kGuard; i += 64) {
+    mine[i] = 0.0;
+    mine[kGuard + a.NL + i] = 0.0;
   }
+  double *agtab = mine + a.off_agtab;
+  double *zscr = mine + a.off_zscr; // [0..Z) tz_pre, [Z..2Z) q / post means, [2Z..3Z) tzs
+  int *zmode = (int *)(mine + a.off_zmode);
+  for (int i = threadIdx.x; i < (a.ncls + 1) * 4; i += blockDim.x) {
+    const int c = i >> 2, j = i & 3;
+    btab[i] = c < a.ncls ? a.ctab[c * 8 + j] : 0.0;
+  }
+  for (int i = threadIdx.x; i <= a.Z; i += blockDim.x) zoffL[i] = a.zone_off[i];
   __syncthreads();
 
   const sb_params &p = a.p;
   const sb_step_in &in = s.in;
+#define SB_STAMP(i) do { if (a.dbg && b == 0 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
   for (int b = wave; b < a.B; b += nwaves) {
+    SB_STAMP(0);
     double *S = a.scal + (size_t)b * kNScal;
-    double *T = a.temp + (size_t)b * a.Np;
+    double *T = a.temp + (size_t)b * a.Np + kPad; // T[-kPad..-1] and T[N..N+kPad) are zero
     const size_t zb = (size_t)b * a.Z;
     const double t_now = in.t_amb_dev ? in.t_amb_dev[2 * b] : in.t_amb_now;
     const double t_next = in.t_amb_dev ? in.t_amb_dev[2 * b + 1] : in.t_amb_next;
@@ -328,16 +538,28 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
     const double mixed = p.ahu_recirc * recirc + (1 - p.ahu_recirc) * t_now;
     const double t_sa = ahu_supply(mixed, heat_sp, cool_sp);
 
-    for (int c = lane; c < a.ncls; c += 64) {
-      const int zc = a.czone[c];
-      const double q = zc >= 0 ? zscr[a.Z + zc] : 0.0;
-      gtab[c] = fma(a.ctab[c * 8 + 6], q, a.ctab[c * 8 + 5] * t_now);
+    for (int c = lane; c <= a.ncls; c += 64) {
+      double ap = 0.0, gg = 0.0;
+      if (c < a.ncls) {
+        const int zc = a.czone[c];
+        const double q = zc >= 0 ? zscr[a.Z + zc] : 0.0;
+        ap = a.ctab[c * 8 + 4];
+        gg = fma(a.ctab[c * 8 + 6], q, a.ctab[c * 8 + 5] * t_now);
+      }
+      agtab[2 * c] = ap;
+      agtab[2 * c + 1] = gg;
     }
-    // grid -> LDS
+    SB_STAMP(1);
+    // grid -> LDS.  Even W: one flat copy by LDS-DMA (global_load_lds_dwordx4: 1 KiB per
+    // wave instruction, no VGPR round trip, every piece in flight at once).
     if (a.pitch == a.W) {
-      const double2 *src = (const double2 *)T;
-      double2 *dst = (double2 *)E;
-      for (int i = lane; i < a.Np / 2; i += 64) dst[i] = src[i];
+      for (int i = 0; i < a.N; i += 128) {
+        if (i + 2 * lane < a.N)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(T + i + 2 * lane),
+              (__attribute__((address_space(3))) void *)(E + i), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       for (int i = lane; i < a.N; i += 64) E[lds_index(a, i)] = T[i];
       for (int x = lane; x < a.H; x += 64)
@@ -345,13 +567,15 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
     }
     __builtin_amdgcn_wave_barrier();
 
+    SB_STAMP(2);
     int n_sweeps = 0, converged = 0;
     for (int it = 0; it < p.iter_limit; ++it) { // simulator.py:348-368
-      const double md = sweep(a, E, gtab, ctabL, T, lane);
+      const double md = sweep(a, E, agtab, btab, T, lane, it == 0);
       ++n_sweeps;
       if (md <= p.conv_threshold) { converged = 1; break; }
     }
 
+    SB_STAMP(3);
     // ---- VAV outputs from the PRE-update zone temperatures (simulator.py:433-448) ----
     for (int z = lane; z < a.Z; z += 64) {
       const int mode = zmode[z];
@@ -403,15 +627,17 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
       tank = blr_sp;
     }
 
+    SB_STAMP(4);
     // ---- grid back to HBM, new means (feed reward_info now and the next step) ----
     double gsum = 0.0;
     if (a.pitch == a.W) {
       const double2 *src = (const double2 *)E;
       double2 *dst = (double2 *)T;
-      for (int i = lane; i < a.Np / 2; i += 64) {
+#pragma unroll 8
+      for (int i = lane; i < a.N / 2; i += 64) {
         double2 v = src[i];
         dst[i] = v;
-        gsum += (2 * i < a.N ? v.x : 0.0) + (2 * i + 1 < a.N ? v.y : 0.0);
+        gsum += v.x + v.y;
       }
     } else {
       for (int i = lane; i < a.N; i += 64) {
@@ -423,18 +649,45 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
     gsum = wave_sum(gsum);
     const double recirc2 = gsum / (double)a.N;
 
+    SB_STAMP(5);
     // ---- reward_info (simulator.py:457-576) + regret reward, on fp32 proto fields ----
     const double hsp2 = (double)(float)(in.comfort_next ? p.comfort_lo : p.eco_lo);
     const double csp2 = (double)(float)(in.comfort_next ? p.comfort_hi : p.eco_hi);
     double prod_part = 0.0, occ_part = 0.0;
     for (int z0 = 0; z0 < a.Z; z0 += 64) {
       const int z = z0 + lane;
-      for (int zz = z0; zz < min(z0 + 64, a.Z); ++zz) { // zone means: whole wave per zone
-        double zs = 0.0;
-        const int c0 = a.zone_off[zz], c1 = a.zone_off[zz + 1];
-        for (int i = c0 + lane; i < c1; i += 64) zs += E[a.zone_cells_l[i]];
-        zs = wave_sum(zs);
-        if (lane == zz - z0) zscr[a.Z + zz] = zs / (double)(c1 - c0);
+      const int zend = min(z0 + 64, a.Z);
+      for (int zb0 = z0; zb0 < zend; zb0 += 8) { // zone means, 8 zones per batch
+        // index loads of a whole batch are issued together and one iteration ahead, so the
+        // loop runs at LDS-gather speed instead of one global-load latency per iteration
+        double part[8];
+        int c0[8], n[8], idx[8], nidx[8];
+        int maxn = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int zz = min(zb0 + j, zend - 1);
+          c0[j] = zoffL[zz];
+          n[j] = zb0 + j < zend ? zoffL[zz + 1] - c0[j] : 0;
+          maxn = max(maxn, n[j]);
+          part[j] = 0.0;
+          nidx[j] = lane < n[j] ? a.zone_cells_l[c0[j] + lane] : -1;
+        }
+        for (int it = 0; it < maxn; it += 64) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            idx[j] = nidx[j];
+            const int i = it + 64 + lane;
+            nidx[j] = i < n[j] ? a.zone_cells_l[c0[j] + i] : -1;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) part[j] += idx[j] >= 0 ? E[idx[j]] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[j] = wave_sum(part[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (zb0 + j < zend && lane == j) zscr[a.Z + zb0 + j] = part[j] / (double)n[j];
+        }
       }
       __builtin_amdgcn_wave_barrier();
       if (z < a.Z) {
@@ -451,6 +704,7 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
         occ_part += occ;
       }
     }
+    SB_STAMP(6);
     const double cumulative = wave_sum(prod_part);
     const double total_occ = wave_sum(occ_part);
 
@@ -499,11 +753,18 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
         I[4] = (float)n_sweeps; I[5] = (float)converged; I[6] = (float)t_sa; I[7] = (float)reward;
       }
     }
-    __threadfence_block(); // S / zair / damper written above are read back by write_obs
+    SB_STAMP(7);
+    if (s.obs) { // every lane holds the (wave-uniform) scalars: no round trip through memory
+      const double Sv[kNScal] = {heat_sp, cool_sp, ahu_flow, (double)ahu_count, blr_sp, blr_flow,
+                                 (double)blr_count, blr_return, tank, tank_change, duration, recirc2,
+                                 0.0, 0.0, 0.0, 0.0};
+      write_obs(a, b, lane, s.obs, in.aux, t_next, Sv);
+    }
     __builtin_amdgcn_wave_barrier();
-    if (s.obs) write_obs(a, b, lane, s.obs, in.aux, t_next);
-    __builtin_amdgcn_wave_barrier();
+    SB_STAMP(8);
+    if (a.dbg && b == 0 && lane == 0) a.dbg[9] = n_sweeps;
   }
+#undef SB_STAMP
 }
 
 __global__ void k_copy_temps(Dev a, double *out) {
@@ -511,7 +772,7 @@ __global__ void k_copy_temps(Dev a, double *out) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     size_t b = i / a.N;
-    out[i] = a.temp[b * a.Np + (i - b * a.N)];
+    out[i] = a.temp[b * a.Np + kPad + (i - b * a.N)];
   }
 }
 
@@ -531,6 +792,7 @@ struct sb_handle {
   DevBuf<uint8_t> cls;
   DevBuf<double> ctab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma;
   DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone;
+  DevBuf<long long> dbg;
 };
 
 namespace {
@@ -578,24 +840,28 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   Dev &d = h->d;
   d.B = n_buildings; d.H = plan->H; d.W = plan->W; d.Z = plan->Z;
   d.N = plan->H * plan->W;
-  d.Np = (d.N + 1) & ~1;
+  d.Np = ((d.N + 1) & ~1) + 2 * kPad;
   d.ncls = plan->n_classes;
   d.pitch = (plan->W + 1) & ~1; // even pitch: skewed ds_read_b64 is bank-conflict free
   d.NL = d.H * d.pitch;
-  d.S = std::max(plan->W, 64);
+  d.S = std::max(plan->W + kChunk, 64); // >= kChunk idle positions between a lane's rows
   d.S_magic = (unsigned)((1ull << 32) / (unsigned)d.S) + 1u;
   const int nbands = (d.H + 63) / 64;
   const int rows_last = d.H - (nbands - 1) * 64;
   d.nsteps = (nbands - 1) * d.S + rows_last + d.W - 1;
+  d.nbands = nbands;
+  // the DPP sweep prefetches the band-seam row up to 2 chunks early (see sweep_fast)
+  d.fast = (nbands == 1) || (d.S - 63 > 2 * kChunk);
+  if (const char *e = getenv("SBSIM_FORCE_GENERIC_SWEEP")) d.fast = d.fast && !(e[0] == '1');
   d.p = *params;
 
-  // per-wave LDS region (doubles): E | gtab | zscr(3Z) | zmode(Z ints)
-  int off = (d.NL + 1) & ~1;
-  d.off_gtab = off; off += (d.ncls + 1) & ~1;
+  // per-wave LDS region (doubles): E | agtab | zscr(3Z) | zmode(Z ints)
+  int off = ((d.NL + 1) & ~1) + 2 * kGuard;
+  d.off_agtab = off; off += (d.ncls + 1) * 2;
   d.off_zscr = off; off += (3 * d.Z + 1) & ~1;
   d.off_zmode = off; off += ((d.Z + 1) / 2 + 1) & ~1;
   d.lds_wave_doubles = off;
-  const size_t shared_bytes = (size_t)((d.ncls * kCoef + 1) & ~1) * 8;
+  const size_t shared_bytes = (size_t)(d.ncls + 1) * 4 * 8 + (size_t)((d.Z + 2) >> 1) * 8;
   const size_t wave_bytes = (size_t)off * 8;
   const size_t lds_cap = 160 * 1024;
   if (shared_bytes + wave_bytes > lds_cap) {
@@ -626,7 +892,11 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     if (plan->class_zone[c] >= d.Z) { delete h; return fail(SB_ERR_INVALID, "sb_create: class zone out of range"); }
   if (obs->n_obs < 1) { delete h; return fail(SB_ERR_INVALID, "sb_create: empty observation layout"); }
 #define SB_TRY(x) do { rc = (x); if (rc != SB_OK) { delete h; return rc; } } while (0)
-  SB_TRY(upload(h->cls, plan->cell_class, (size_t)d.N));
+  {
+    std::vector<uint8_t> padded((size_t)d.N + 2 * kPad + 8, 0);
+    std::memcpy(padded.data() + kPad, plan->cell_class, (size_t)d.N);
+    SB_TRY(upload(h->cls, padded.data(), padded.size()));
+  }
   SB_TRY(upload(h->ctab, plan->class_coef, (size_t)d.ncls * 8));
   SB_TRY(upload(h->czone, plan->class_zone, (size_t)d.ncls));
   SB_TRY(upload(h->zone_off, plan->zone_off, (size_t)d.Z + 1));
@@ -648,6 +918,10 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   d.scal = h->scal.p;
   d.O = obs->n_obs; d.col_ahu = obs->col_ahu; d.col_blr = obs->col_boiler; d.col_aux = obs->col_aux;
   d.col_zone = h->col_zone.p; d.obs_mean = h->obs_mean.p; d.obs_sigma = h->obs_sigma.p;
+  d.dbg = nullptr;
+  if (getenv("SBSIM_PHASE_TIMING")) { // developer aid: cycle stamps of wave 0's first building
+    if (alloc_zero(h->dbg, 16) == SB_OK) d.dbg = h->dbg.p;
+  }
 
   hipError_t e = hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->lds_bytes);
@@ -735,5 +1009,15 @@ SB_COPY_OUT(sb_get_zone_temps, h->d.zmean, (size_t)h->d.B *h->d.Z, double)
 SB_COPY_OUT(sb_get_scalars, h->d.scal, (size_t)h->d.B *kNScal, double)
 SB_COPY_OUT(sb_get_modes, h->d.mode, (size_t)h->d.B *h->d.Z, int32_t)
 SB_COPY_OUT(sb_get_zone_power, h->d.qz, (size_t)h->d.B *h->d.Z, double)
+
+/* Developer aid (not part of the parity/bench path): 16 int64 cycle stamps, host pointer. */
+int sb_debug_phase_cycles(sb_handle *h, long long *out_host) {
+  if (!h || !out_host) return fail(SB_ERR_INVALID, "sb_debug_phase_cycles: null argument");
+  if (!h->d.dbg) return fail(SB_ERR_INVALID, "sb_debug_phase_cycles: set SBSIM_PHASE_TIMING=1 before sb_create");
+  SB_HIP(hipSetDevice(h->device));
+  SB_HIP(hipDeviceSynchronize());
+  SB_HIP(hipMemcpy(out_host, h->d.dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  return SB_OK;
+}
 
 } // extern "C"

@@ -5,7 +5,7 @@ import pytest
 from oracle import oracle as orc
 from sbsim_amd.floorplan import FloorPlan
 from tests.golden_util import load, oracle_plan
-from tests.kernel_model import model_fd_timestep
+from tests.kernel_model import FastSweepModel, model_fd_timestep
 
 
 def _plan_from_golden(p):
@@ -39,3 +39,8 @@ def test_skewed_class_table_sweep_matches_oracle(name):
   got, n_got = model_fd_timestep(cp, g["prev"], float(g["t_amb"]), qz, 0.01, 60)
   assert n_got == n_ref
   assert np.abs(got - ref).max() < 1e-10
+  fm = FastSweepModel(cp)
+  assert fm.fast
+  got2, n2 = fm.fd_timestep(g["prev"], float(g["t_amb"]), qz, 0.01, 60)
+  assert n2 == n_ref
+  assert np.abs(got2 - ref).max() < 1e-10
