@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsbsim_amd.so")
+LIB_PATH = os.environ.get("SBSIM_LIB") or os.path.join(_HERE, "libsbsim_amd.so")
 
 SB_NUM_ACTIONS = 2
 SB_NUM_AUX = 7

@@ -64,6 +64,14 @@ struct Dev {
   const int *czone;        // [ncls]
   const int *zone_off;     // [Z+1]
   const int *zone_cells_l; // LDS index of every zone cell
+  // zone sums: per zone, u16 LDS indices padded to a multiple of 512 with `NL` (a zero guard
+  // cell); block = 512 indices = one 16-byte load per lane
+  const uint4 *zl16;       // [n_zblocks][64]
+  const int *zblk_zone;    // [n_zblocks]
+  int n_zblocks;
+  // fast-sweep schedule: per (chunk, lane) {li0, g0, liD0, liU0}; per (chunk, slot) lane mask
+  const int4 *sched;
+  const unsigned long long *smask;
   // state
   double *temp;            // [B][Np], grid at +kPad (zero padding both sides)
   double *zmean;           // [B][Z] zone means of the current grid
@@ -230,7 +238,7 @@ struct StageG {
   unsigned long long cw; // 8 class bytes
   int li0;               // LDS index of position 0 of the chunk (may point before the row)
   int liD0, liU0;        // same position one row down / one row up (row clamped to the grid)
-  bool act[kChunk];      // position k is a real cell
+  int mlo, mhi;          // lane k holds the 64-bit lane mask of slot k ("is a real cell")
 };
 struct StageL {
   double A[kChunk], bU[kChunk], bD[kChunk], bL[kChunk], bR[kChunk], Rn[kChunk], Dn[kChunk], Ee[kChunk];
@@ -238,25 +246,27 @@ struct StageL {
 
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
 
+// Stage S: where the lane is during chunk `ch` -- tables built once per floor plan
+// (sb_create), so the loop spends no instructions on index arithmetic.  Loaded one chunk
+// before stage G needs it (its addresses feed G's loads).
+struct StageS {
+  int4 sc;               // {li0, g0, liD0, liU0}
+  unsigned long long mk; // slot k's lane mask, held by lane k
+};
+__device__ __forceinline__ void stage_s(const Dev &a, int ch, int lane, StageS &st) {
+  st.sc = a.sched[ch * 64 + lane];
+  st.mk = a.smask[ch * kChunk + (lane & (kChunk - 1))];
+}
+
 template <bool FIRST>
 __device__ __forceinline__ void stage_g(const Dev &a, const double *E, const double *__restrict__ Pg,
-                                        int ch, int lane, StageG &g) {
-  const int v0 = ch * kChunk - lane;
-  const int vl = v0 + kChunk - 1;
-  const int band = (int)__umulhi((unsigned)max(vl, 0), a.S_magic);
-  const int y0 = v0 - band * a.S;
-  const int r = band * 64 + lane;
-  const bool row_ok = (vl >= 0) && (r < a.H);
-#pragma unroll
-  for (int k = 0; k < kChunk; ++k) g.act[k] = row_ok && (y0 + k >= 0) && (y0 + k < a.W);
-  const int ra = min(r, a.H - 1);
-  // position 0 of the chunk relative to the row (negative while the row has not started);
-  // clamped only so that addresses stay inside the guards / padding
-  const int y0a = clampi(vl >= 0 ? y0 : v0, -kChunk, a.W);
-  g.li0 = ra * a.pitch + y0a;
-  g.liD0 = min(ra + 1, a.H - 1) * a.pitch + y0a;
-  g.liU0 = max(ra - 1, 0) * a.pitch + y0a;
-  const int g0 = ra * a.W + y0a; // in [-8, N]: the grid is padded by kPad on both sides
+                                        const StageS &st, StageG &g) {
+  g.li0 = st.sc.x;
+  g.liD0 = st.sc.z;
+  g.liU0 = st.sc.w;
+  g.mlo = (int)(unsigned)st.mk;
+  g.mhi = (int)(unsigned)(st.mk >> 32);
+  const int g0 = st.sc.y; // in [-8, N]: the grid is padded by kPad on both sides
   __builtin_memcpy(&g.cw, a.cls + kPad + g0, 8);
   if (FIRST) { // first sweep: the estimate still equals the previous temperatures
 #pragma unroll
@@ -272,21 +282,61 @@ __device__ __forceinline__ void stage_g(const Dev &a, const double *E, const dou
   }
 }
 
+// slot k's 64-bit lane mask (held by lane k) -> a lane predicate without any VALU compare
+template <int K>
+__device__ __forceinline__ bool slot_active(int mlo, int mhi) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane(mlo, K);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane(mhi, K);
+  return __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
+}
+
 // Gathers slot K of the NEXT chunk (described by g) into l.  R of a position is the old
 // value of the lane's NEXT position; for the chunk's last slot that position belongs to the
 // chunk after (base index li0_after), which may sit in another band row.
 template <bool MULTI, int K>
 __device__ __forceinline__ void load_slot(const double *E, const double *agtab, const double *btab,
                                           const StageG &g, int li0_after, StageL &l) {
+#if defined(SB_EXP) && (SB_EXP & 32) /* experiment: every lane reads table row 3 */
+  const int c = 3 + 0 * (int)((g.cw >> (8 * K)) & 0xffull);
+#elif defined(SB_EXP) && (SB_EXP & 64) /* experiment: rows spread over lanes (no two lanes share a row) */
+  const int c = (int)((g.cw >> (8 * K)) & 0x0full) + (threadIdx.x & 3) * 5;
+#else
   const int c = (int)((g.cw >> (8 * K)) & 0xffull);
+#endif
+#if defined(SB_EXP) && (SB_EXP & 1) /* experiment: no coefficient-table reads */
+  const double cc = 0.2499 + 1e-9 * c;
+  l.bU[K] = cc; l.bD[K] = cc; l.bL[K] = cc; l.bR[K] = cc;
+  l.A[K] = fma(1e-4, g.P[K], 0.0);
+#elif defined(SB_EXP) && (SB_EXP & 8) /* experiment: six ds_read_b64 instead of three b128 */
+  {
+    const volatile double *bt = btab + c * 4;
+    const volatile double *at = agtab + c * 2;
+    l.bU[K] = bt[0]; l.bD[K] = bt[1]; l.bL[K] = bt[2]; l.bR[K] = bt[3];
+    l.A[K] = fma(at[0], g.P[K], at[1]);
+  }
+#elif defined(SB_EXP) && (SB_EXP & 16) /* experiment: b128 reads at lane-distinct addresses */
+  {
+    const double *fake = E + (threadIdx.x & 63) * 98 + (c & 7) * 2;
+    const double2 b01 = *(const double2 *)(fake);
+    const double2 b23 = *(const double2 *)(fake + 16);
+    const double2 ag = *(const double2 *)(fake + 32);
+    l.bU[K] = b01.x * 1e-3; l.bD[K] = b01.y * 1e-3; l.bL[K] = b23.x * 1e-3; l.bR[K] = b23.y * 1e-3;
+    l.A[K] = fma(ag.x * 1e-6, g.P[K], ag.y * 1e-6);
+  }
+#else
   const double2 b01 = *(const double2 *)(btab + c * 4);
   const double2 b23 = *(const double2 *)(btab + c * 4 + 2);
   const double2 ag = *(const double2 *)(agtab + c * 2);
   l.bU[K] = b01.x; l.bD[K] = b01.y; l.bL[K] = b23.x; l.bR[K] = b23.y;
   l.A[K] = fma(ag.x, g.P[K], ag.y);
+#endif
+#if defined(SB_EXP) && (SB_EXP & 2) /* experiment: no E reads in the loop */
+  l.Rn[K] = g.P[K]; l.Dn[K] = g.P[K]; if (MULTI) l.Ee[K] = g.P[K];
+#else
   l.Rn[K] = K == kChunk - 1 ? E[li0_after] : E[g.li0 + K + 1];
   l.Dn[K] = E[g.liD0 + K];
   if (MULTI) l.Ee[K] = E[g.liU0 + K];
+#endif
 }
 
 // lane l <- lane l-1's x; lane 0 (no source lane) keeps `seam`.
@@ -306,21 +356,22 @@ __device__ __forceinline__ void update_slot(double *E, const StageL &l, int li0,
   t = fma(l.bL[K], nv, t);
   const double nvn = fma(l.bU[K], U, t);
   if (act) {
+#if !(defined(SB_EXP) && (SB_EXP & 4)) /* experiment 4: no LDS store */
     E[li0 + K] = nvn;
+#endif
     dmax = fmax(dmax, fabs(nvn - oldv));
   }
   oldv = l.Rn[K];
   nv = nvn;
 }
 
-// Computes the chunk held in l (li0/act) while refilling each freed slot with chunk `nx`.
+// Computes the chunk held in l (li0, masks) while refilling each freed slot with chunk `nx`.
 template <bool MULTI>
 __device__ __forceinline__ void run_chunk(double *E, const double *agtab, const double *btab,
-                                          StageL &l, int li0, const bool (&act)[kChunk],
-                                          const StageG &nx, int li0_after, double &nv, double &oldv,
-                                          double &dmax) {
-#define SB_SLOT(K)                                              \
-  update_slot<MULTI, K>(E, l, li0, act[K], nv, oldv, dmax);      \
+                                          StageL &l, int li0, int mlo, int mhi, const StageG &nx,
+                                          int li0_after, double &nv, double &oldv, double &dmax) {
+#define SB_SLOT(K)                                                                        \
+  update_slot<MULTI, K>(E, l, li0, slot_active<K>(mlo, mhi), nv, oldv, dmax);              \
   load_slot<MULTI, K>(E, agtab, btab, nx, li0_after, l);
   SB_SLOT(0) SB_SLOT(1) SB_SLOT(2) SB_SLOT(3) SB_SLOT(4) SB_SLOT(5) SB_SLOT(6) SB_SLOT(7)
 #undef SB_SLOT
@@ -331,29 +382,29 @@ __device__ double sweep_fast(const Dev &a, double *E, const double *agtab, const
                              const double *__restrict__ Pg, int lane) {
   double dmax = 0.0, nv = 0.0;
   const int nch = (a.nsteps + kChunk - 1) / kChunk;
+  StageS s0, s1;
   StageG g0, g1;
   StageL l;
-  stage_g<FIRST>(a, E, Pg, 0, lane, g0);
-  stage_g<FIRST>(a, E, Pg, 1, lane, g1);
+  stage_s(a, 0, lane, s0);
+  stage_s(a, 1, lane, s1);
+  stage_g<FIRST>(a, E, Pg, s0, g0);
+  stage_g<FIRST>(a, E, Pg, s1, g1);
+  stage_s(a, 2, lane, s0);
+  stage_s(a, 3, lane, s1);
 #define SB_LOAD0(K) load_slot<MULTI, K>(E, agtab, btab, g0, g1.li0, l);
   SB_LOAD0(0) SB_LOAD0(1) SB_LOAD0(2) SB_LOAD0(3) SB_LOAD0(4) SB_LOAD0(5) SB_LOAD0(6) SB_LOAD0(7)
 #undef SB_LOAD0
   double oldv = E[g0.li0];
-  int li0 = g0.li0;
-  bool act[kChunk];
-#pragma unroll
-  for (int k = 0; k < kChunk; ++k) act[k] = g0.act[k];
+  int li0 = g0.li0, mlo = g0.mlo, mhi = g0.mhi;
   for (int ch = 0; ch < nch; ch += 2) {
-    stage_g<FIRST>(a, E, Pg, ch + 2, lane, g0);
-    run_chunk<MULTI>(E, agtab, btab, l, li0, act, g1, g0.li0, nv, oldv, dmax);
-    li0 = g1.li0;
-#pragma unroll
-    for (int k = 0; k < kChunk; ++k) act[k] = g1.act[k];
-    stage_g<FIRST>(a, E, Pg, ch + 3, lane, g1);
-    run_chunk<MULTI>(E, agtab, btab, l, li0, act, g0, g1.li0, nv, oldv, dmax);
-    li0 = g0.li0;
-#pragma unroll
-    for (int k = 0; k < kChunk; ++k) act[k] = g0.act[k];
+    stage_g<FIRST>(a, E, Pg, s0, g0);   // chunk ch+2
+    stage_s(a, ch + 4, lane, s0);
+    run_chunk<MULTI>(E, agtab, btab, l, li0, mlo, mhi, g1, g0.li0, nv, oldv, dmax);
+    li0 = g1.li0; mlo = g1.mlo; mhi = g1.mhi;
+    stage_g<FIRST>(a, E, Pg, s1, g1);   // chunk ch+3
+    stage_s(a, ch + 5, lane, s1);
+    run_chunk<MULTI>(E, agtab, btab, l, li0, mlo, mhi, g0, g1.li0, nv, oldv, dmax);
+    li0 = g0.li0; mlo = g0.mlo; mhi = g0.mhi;
   }
   return wave_max(dmax);
 }
@@ -654,44 +705,35 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
     const double hsp2 = (double)(float)(in.comfort_next ? p.comfort_lo : p.eco_lo);
     const double csp2 = (double)(float)(in.comfort_next ? p.comfort_hi : p.eco_hi);
     double prod_part = 0.0, occ_part = 0.0;
+    // zone sums: u16 index blocks (512 cells each), 8 blocks' indices loaded before any gather
+    for (int z = lane; z < a.Z; z += 64) zscr[a.Z + z] = 0.0;
+    for (int b0 = 0; b0 < a.n_zblocks; b0 += 8) {
+      uint4 w[8];
+      double part[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = a.zl16[(size_t)min(b0 + j, a.n_zblocks - 1) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned q[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc += E[q[t] & 0xffffu] + E[q[t] >> 16];
+        part[j] = acc;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part[j] = wave_sum(part[j]);
+      if (lane == 0) { // block order == zone order: deterministic accumulation
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (b0 + j < a.n_zblocks) zscr[a.Z + a.zblk_zone[b0 + j]] += part[j];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
     for (int z0 = 0; z0 < a.Z; z0 += 64) {
       const int z = z0 + lane;
-      const int zend = min(z0 + 64, a.Z);
-      for (int zb0 = z0; zb0 < zend; zb0 += 8) { // zone means, 8 zones per batch
-        // index loads of a whole batch are issued together and one iteration ahead, so the
-        // loop runs at LDS-gather speed instead of one global-load latency per iteration
-        double part[8];
-        int c0[8], n[8], idx[8], nidx[8];
-        int maxn = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int zz = min(zb0 + j, zend - 1);
-          c0[j] = zoffL[zz];
-          n[j] = zb0 + j < zend ? zoffL[zz + 1] - c0[j] : 0;
-          maxn = max(maxn, n[j]);
-          part[j] = 0.0;
-          nidx[j] = lane < n[j] ? a.zone_cells_l[c0[j] + lane] : -1;
-        }
-        for (int it = 0; it < maxn; it += 64) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            idx[j] = nidx[j];
-            const int i = it + 64 + lane;
-            nidx[j] = i < n[j] ? a.zone_cells_l[c0[j] + i] : -1;
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) part[j] += idx[j] >= 0 ? E[idx[j]] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) part[j] = wave_sum(part[j]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (zb0 + j < zend && lane == j) zscr[a.Z + zb0 + j] = part[j] / (double)n[j];
-        }
-      }
       __builtin_amdgcn_wave_barrier();
       if (z < a.Z) {
-        const double tzp = zscr[a.Z + z];
+        const double tzp = zscr[a.Z + z] / (double)(zoffL[z + 1] - zoffL[z]);
         a.zmean[zb + z] = tzp;
         const double t = (double)(float)tzp;
         const double occ = (double)(float)(in.occupancy_dev ? in.occupancy_dev[z] : in.occupancy);
@@ -791,7 +833,10 @@ struct sb_handle {
   size_t lds_bytes = 0;
   DevBuf<uint8_t> cls;
   DevBuf<double> ctab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma;
-  DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone;
+  DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone;
+  DevBuf<uint4> zl16;
+  DevBuf<int4> sched;
+  DevBuf<unsigned long long> smask;
   DevBuf<long long> dbg;
 };
 
@@ -901,6 +946,55 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   SB_TRY(upload(h->czone, plan->class_zone, (size_t)d.ncls));
   SB_TRY(upload(h->zone_off, plan->zone_off, (size_t)d.Z + 1));
   SB_TRY(upload(h->zone_cells_l, zl.data(), zl.size()));
+  { // zone-sum blocks: u16 LDS indices, zones padded to 512 with NL (zero guard cell)
+    if (d.NL >= 65535) { delete h; return fail(SB_ERR_TOO_LARGE, "sb_create: grid too large for u16 LDS indices"); }
+    std::vector<uint16_t> idx;
+    std::vector<int> bz;
+    for (int z = 0; z < d.Z; ++z) {
+      const int c0 = plan->zone_off[z], c1 = plan->zone_off[z + 1];
+      std::vector<uint16_t> cells;
+      for (int i = c0; i < c1; ++i) cells.push_back((uint16_t)zl[i]);
+      while (cells.size() % 512) cells.push_back((uint16_t)d.NL);
+      // within a block, element t of lane l is cell t*64+l: one gather instruction touches
+      // 64 consecutive cells of the (sorted) zone list -> consecutive LDS addresses, no
+      // bank conflicts
+      for (size_t b0 = 0; b0 < cells.size(); b0 += 512) {
+        for (int l = 0; l < 64; ++l)
+          for (int t = 0; t < 8; ++t) idx.push_back(cells[b0 + (size_t)t * 64 + l]);
+        bz.push_back(z);
+      }
+    }
+    if (idx.empty()) { idx.assign(512, (uint16_t)d.NL); bz.push_back(0); }
+    d.n_zblocks = (int)bz.size();
+    SB_TRY(upload(h->zl16, (const uint4 *)idx.data(), idx.size() / 8));
+    SB_TRY(upload(h->zblk_zone, bz.data(), bz.size()));
+  }
+  { // fast-sweep schedule (see stage_g): where every lane is during every 8-step chunk
+    const int nch = (d.nsteps + kChunk - 1) / kChunk;
+    const int nct = ((nch + 1) & ~1) + 6; // the pipeline prefetches up to 5 chunks past the end
+    std::vector<int4> sc((size_t)nct * 64);
+    std::vector<unsigned long long> mk((size_t)nct * kChunk, 0ull);
+    for (int ch = 0; ch < nct; ++ch)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int v0 = ch * kChunk - lane, vl = v0 + kChunk - 1;
+        const int band = vl >= 0 ? vl / d.S : 0;
+        const int y0 = v0 - band * d.S;
+        const int r = band * 64 + lane;
+        const bool row_ok = vl >= 0 && r < d.H;
+        const int ra = std::min(r, d.H - 1);
+        const int y0a = std::min(std::max(vl >= 0 ? y0 : v0, -kChunk), d.W);
+        int4 e;
+        e.x = ra * d.pitch + y0a;
+        e.y = ra * d.W + y0a;
+        e.z = std::min(ra + 1, d.H - 1) * d.pitch + y0a;
+        e.w = std::max(ra - 1, 0) * d.pitch + y0a;
+        sc[(size_t)ch * 64 + lane] = e;
+        for (int k = 0; k < kChunk; ++k)
+          if (row_ok && y0 + k >= 0 && y0 + k < d.W) mk[(size_t)ch * kChunk + k] |= 1ull << lane;
+      }
+    SB_TRY(upload(h->sched, sc.data(), sc.size()));
+    SB_TRY(upload(h->smask, mk.data(), mk.size()));
+  }
   SB_TRY(upload(h->col_zone, obs->col_zone, (size_t)d.Z));
   SB_TRY(upload(h->obs_mean, obs->mean, (size_t)obs->n_obs));
   SB_TRY(upload(h->obs_sigma, obs->sigma, (size_t)obs->n_obs));
@@ -914,6 +1008,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
 #undef SB_TRY
   d.cls = h->cls.p; d.ctab = h->ctab.p; d.czone = h->czone.p; d.zone_off = h->zone_off.p;
   d.zone_cells_l = h->zone_cells_l.p; d.temp = h->temp.p; d.zmean = h->zmean.p;
+  d.zl16 = h->zl16.p; d.zblk_zone = h->zblk_zone.p; d.sched = h->sched.p; d.smask = h->smask.p;
   d.zair = h->zair.p; d.damper = h->damper.p; d.qz = h->qz.p; d.mode = h->mode.p;
   d.scal = h->scal.p;
   d.O = obs->n_obs; d.col_ahu = obs->col_ahu; d.col_blr = obs->col_boiler; d.col_aux = obs->col_aux;
