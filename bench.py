@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-from sbsim_amd import _ffi  # noqa: E402
+from sbsim_amd import _ffi, distributed as sd  # noqa: E402
 from sbsim_amd.environment import BatchedEnvironment, SimConfig  # noqa: E402
 from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan  # noqa: E402
 
@@ -108,32 +108,31 @@ def main() -> None:
   ap.add_argument("--warmup", type=int, default=12)
   ap.add_argument("--buildings", type=int, default=65536, help="buildings PER GPU")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--iteration-limit", type=int, default=100,
+                  help="Simulator.iteration_limit (100 = the reference's SB1 value; 1 is used only to "
+                       "calibrate the PMC byte counters on a known traffic pattern)")
   args = ap.parse_args()
 
-  rank = int(os.environ.get("RANK", "0"))
-  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  distributed = world > 1
+  rank, local_rank, world = sd.env_rank_world()
+  torch.cuda.set_device(local_rank)
+  distributed = sd.init_process_group("nccl")   # "nccl" is RCCL on ROCm
   if distributed:
     import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
-  torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
 
   B, K, W = args.buildings, args.steps, args.warmup
   plan = r9_plan()
   env = BatchedEnvironment(plan, B, device=local_rank, holiday_calendar="us", collect_info=True,
-                           num_days_in_episode=3)
+                           num_days_in_episode=3, config=SimConfig(iteration_limit=args.iteration_limit))
   H, Wd = plan.shape
   Z = env.sim.Z
-  rs = np.random.RandomState(7 + rank)
+  rs = np.random.RandomState(sd.shard_seed(7, rank))
   t_init = np.clip(294.0 + rs.randn(B), 285.0, 305.0)
   init = torch.tensor(t_init, dtype=torch.float64, device=dev)[:, None].expand(B, H * Wd).contiguous()
   env.reset()
   env.sim.reset(temps=init)
   gen = torch.Generator(device=dev)
-  gen.manual_seed(1234 + rank)
+  gen.manual_seed(sd.shard_seed(1234, rank))
   total = W + K
   actions = torch.rand((total, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
   returns = torch.zeros((B,), dtype=torch.float32, device=dev)
@@ -143,9 +142,15 @@ def main() -> None:
       dist.barrier()
     torch.cuda.synchronize(dev)
 
+  wev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(W)]
   for t in range(W):
-    ts = env.step(actions[t])
-    returns += ts.reward
+    si = env.make_step_in(env.current_simulation_timestamp)
+    wev[t][0].record()
+    env.sim.step(actions[t], si, env._obs, env._reward, env._info)
+    wev[t][1].record()
+    env._prev_thermostat_ts = env._now
+    env._now = env._now + env._step_interval
+    returns += env._reward
   ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
   sweeps = torch.zeros((), dtype=torch.float64, device=dev)
   barrier()
@@ -162,18 +167,17 @@ def main() -> None:
   barrier()
   elapsed = time.perf_counter() - t0
   kernel_ms = [a.elapsed_time(b) for a, b in ev]
+  warm_ms = [a.elapsed_time(b) for a, b in wev]
 
-  t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+  elapsed = sd.max_over_ranks(elapsed, dev)
   gather_ms = 0.0
   if distributed:
-    dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     torch.cuda.synchronize(dev)
     g0 = time.perf_counter()
-    out = [torch.empty_like(returns) for _ in range(world)]
-    dist.all_gather(out, returns)           # end-of-rollout return gather over xGMI
+    all_returns = sd.gather_returns(returns, world * B)   # end-of-rollout gather (RCCL / xGMI)
     torch.cuda.synchronize(dev)
     gather_ms = (time.perf_counter() - g0) * 1e3
-  elapsed = float(t_all.item())
+    assert all_returns.numel() == world * B
 
   if rank == 0:
     li = env.sim.launch_info
@@ -196,9 +200,19 @@ def main() -> None:
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": "k_step", "avg_kernel_ms": avg_kernel_s * 1e3,
+                     # rocprofv3 --stats averages over EVERY k_step launch of the command (warm-up
+                     # steps run more sweeps: the start state is not an equilibrium); same quantity:
+                     "avg_kernel_ms_all_launches_incl_warmup": float(np.mean(warm_ms + kernel_ms)),
+                     "kernel_ms_timed": [round(x, 4) for x in kernel_ms],
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "state_bytes_per_launch_fp64": li["state_bytes_per_env_step"] * B},
     }
+    tr = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tr):   # PMC passes of this same command (tools/collect_profiles.sh)
+      with open(tr) as fh:
+        t = json.load(fh)
+      result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+      result["roofline"]["traffic_source"] = t.get("source")
     if world == 1 and not args.no_cpu_baseline:
       nb_s = 256
       acts_cpu = actions[:, :nb_s].cpu().numpy()
