@@ -95,10 +95,27 @@ struct StepArgs {
 };
 
 // ---------------------------------------------------------------- wave helpers
+// DPP move of a double; lanes without a source (or outside row_mask) receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// Wave-wide sum in VALU/DPP only (no LDS-pipe bpermutes): row_shr 1,2,3,4,8 leave each row's
+// total in its lane 15, row_bcast:15 / row_bcast:31 carry it to lane 63; fixed order =>
+// deterministic.  Returns the total in every lane.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  double t = v + dpp_or_zero<0x111, 0xf>(v);
+  t += dpp_or_zero<0x112, 0xf>(v);
+  t += dpp_or_zero<0x113, 0xf>(v);
+  t += dpp_or_zero<0x114, 0xf>(t);
+  t += dpp_or_zero<0x118, 0xf>(t);
+  t += dpp_or_zero<0x142, 0xa>(t);
+  t += dpp_or_zero<0x143, 0xc>(t);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(t), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(t), 63);
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -705,27 +722,50 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
     const double hsp2 = (double)(float)(in.comfort_next ? p.comfort_lo : p.eco_lo);
     const double csp2 = (double)(float)(in.comfort_next ? p.comfort_hi : p.eco_hi);
     double prod_part = 0.0, occ_part = 0.0;
-    // zone sums: u16 index blocks (512 cells each), 8 blocks' indices loaded before any gather
+    // zone sums: u16 index blocks (512 cells each).  Index loads run one batch ahead of the
+    // gathers; blocks are walked in zone order (block -> zone from the zone sizes, no lookups)
     for (int z = lane; z < a.Z; z += 64) zscr[a.Z + z] = 0.0;
-    for (int b0 = 0; b0 < a.n_zblocks; b0 += 8) {
-      uint4 w[8];
-      double part[8];
+    __builtin_amdgcn_wave_barrier();
+    {
+      constexpr int kZB = 6;
+      uint4 w[kZB], wn[kZB];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = a.zl16[(size_t)min(b0 + j, a.n_zblocks - 1) * 64 + lane];
+      for (int j = 0; j < kZB; ++j) wn[j] = a.zl16[(size_t)min(j, a.n_zblocks - 1) * 64 + lane];
+      int zcur = 0, left = a.Z > 0 ? (zoffL[1] - zoffL[0] + 511) >> 9 : 0;
+      double zacc = 0.0;
+      for (int b0 = 0; b0 < a.n_zblocks; b0 += kZB) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned q[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
-        double acc = 0.0;
+        for (int j = 0; j < kZB; ++j) {
+          w[j] = wn[j];
+          wn[j] = a.zl16[(size_t)min(b0 + kZB + j, a.n_zblocks - 1) * 64 + lane];
+        }
+        double part[kZB];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc += E[q[t] & 0xffffu] + E[q[t] >> 16];
-        part[j] = acc;
-      }
+        for (int j = 0; j < kZB; ++j) {
+          const unsigned q[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+          double acc = 0.0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) part[j] = wave_sum(part[j]);
-      if (lane == 0) { // block order == zone order: deterministic accumulation
+          for (int t = 0; t < 4; ++t) acc += E[q[t] & 0xffffu] + E[q[t] >> 16];
+          part[j] = acc;
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (b0 + j < a.n_zblocks) zscr[a.Z + a.zblk_zone[b0 + j]] += part[j];
+        for (int j = 0; j < kZB; ++j) part[j] = wave_sum(part[j]);
+#pragma unroll
+        for (int j = 0; j < kZB; ++j) {
+          if (b0 + j < a.n_zblocks) { // uniform control flow; block order == zone order
+            while (left == 0) {       // zones without cells
+              if (lane == 0) zscr[a.Z + zcur] = zacc;
+              zacc = 0.0; ++zcur;
+              left = (zoffL[zcur + 1] - zoffL[zcur] + 511) >> 9;
+            }
+            zacc += part[j];
+            if (--left == 0) {
+              if (lane == 0) zscr[a.Z + zcur] = zacc;
+              zacc = 0.0; ++zcur;
+              left = zcur < a.Z ? (zoffL[zcur + 1] - zoffL[zcur] + 511) >> 9 : 1 << 30;
+            }
+          }
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
