@@ -56,6 +56,7 @@ struct Dev {
   int S, nsteps;           // band stride (max(W+8,64)) and sweep steps per sweep
   unsigned S_magic;        // floor(2^32 / S) + 1
   int nbands, fast;        // fast: register/DPP sweep is legal for this shape
+  int ts;                  // coefficient-table stride in entries (32 or 128; >= ncls)
   int lds_wave_doubles;    // per-wave LDS region, in doubles
   int off_agtab, off_zscr, off_zmode; // offsets inside the per-wave region (doubles)
   // static tables
@@ -155,9 +156,10 @@ __device__ __forceinline__ int default_control(int mode, double tz, double hsp, 
 // (sbsim_amd/floorplan.py folds the corner / edge / interior / exterior formulas into
 // per-class coefficients; missing neighbours have b = 0, so any finite value may stand in).
 //
-// LDS tables: btab[c] = {bU,bD,bL,bR} (shared by the workgroup), agtab[c] = {ap, g} (per
-// wave: g depends on the building's ambient temperature and VAV power); row `ncls` of both
-// is all zeros and is what idle lanes look up, so they compute exactly 0.
+// LDS tables, structure-of-arrays so that every lookup is a ds_read_b64: tab[j*ts + c] for
+// j = bU,bD,bL,bR,ap (shared by the workgroup) and gtab[c] (per wave: g depends on the
+// building's ambient temperature and VAV power).  Measured on gfx950: gathering table rows
+// with ds_read_b128 costs ~45 cycles per instruction here, ds_read_b64 ~6.
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
 
@@ -198,7 +200,7 @@ __device__ __forceinline__ void load_chunk(const Dev &a, const double *__restric
   }
 }
 
-__device__ double sweep_generic(const Dev &a, double *E, const double *agtab, const double *btab,
+__device__ double sweep_generic(const Dev &a, double *E, const double *gtab, const double *tab,
                                 const double *__restrict__ Pg, int lane) {
   double dmax = 0.0;
   const int pitch = a.pitch, last = a.NL - 1;
@@ -211,15 +213,15 @@ __device__ double sweep_generic(const Dev &a, double *E, const double *agtab, co
     for (int k = 0; k < kChunk; ++k) {
       const int li = cur.li[k];
       if (li >= 0) {
-        const double *bt = btab + cur.c[k] * 4;
-        const double *ag = agtab + cur.c[k] * 2;
+        const double *bt = tab + cur.c[k];
+        const int ts = a.ts;
         const double U = E[max(li - pitch, 0)], D = E[min(li + pitch, last)];
         const double L = E[max(li - 1, 0)], R = E[min(li + 1, last)];
         const double old = E[li];
-        double nv = fma(ag[0], cur.P[k], ag[1]);
-        nv = fma(bt[1], D, nv);
-        nv = fma(bt[3], R, nv);
-        nv = fma(bt[2], L, nv);
+        double nv = fma(bt[4 * ts], cur.P[k], gtab[cur.c[k]]);
+        nv = fma(bt[ts], D, nv);
+        nv = fma(bt[3 * ts], R, nv);
+        nv = fma(bt[2 * ts], L, nv);
         nv = fma(bt[0], U, nv);
         dmax = fmax(dmax, fabs(nv - old));
         E[li] = nv;
@@ -310,8 +312,8 @@ __device__ __forceinline__ bool slot_active(int mlo, int mhi) {
 // Gathers slot K of the NEXT chunk (described by g) into l.  R of a position is the old
 // value of the lane's NEXT position; for the chunk's last slot that position belongs to the
 // chunk after (base index li0_after), which may sit in another band row.
-template <bool MULTI, int K>
-__device__ __forceinline__ void load_slot(const double *E, const double *agtab, const double *btab,
+template <bool MULTI, int TS, int K>
+__device__ __forceinline__ void load_slot(const double *E, const double *gtab, const double *tab,
                                           const StageG &g, int li0_after, StageL &l) {
 #if defined(SB_EXP) && (SB_EXP & 32) /* experiment: every lane reads table row 3 */
   const int c = 3 + 0 * (int)((g.cw >> (8 * K)) & 0xffull);
@@ -324,28 +326,10 @@ __device__ __forceinline__ void load_slot(const double *E, const double *agtab, 
   const double cc = 0.2499 + 1e-9 * c;
   l.bU[K] = cc; l.bD[K] = cc; l.bL[K] = cc; l.bR[K] = cc;
   l.A[K] = fma(1e-4, g.P[K], 0.0);
-#elif defined(SB_EXP) && (SB_EXP & 8) /* experiment: six ds_read_b64 instead of three b128 */
-  {
-    const volatile double *bt = btab + c * 4;
-    const volatile double *at = agtab + c * 2;
-    l.bU[K] = bt[0]; l.bD[K] = bt[1]; l.bL[K] = bt[2]; l.bR[K] = bt[3];
-    l.A[K] = fma(at[0], g.P[K], at[1]);
-  }
-#elif defined(SB_EXP) && (SB_EXP & 16) /* experiment: b128 reads at lane-distinct addresses */
-  {
-    const double *fake = E + (threadIdx.x & 63) * 98 + (c & 7) * 2;
-    const double2 b01 = *(const double2 *)(fake);
-    const double2 b23 = *(const double2 *)(fake + 16);
-    const double2 ag = *(const double2 *)(fake + 32);
-    l.bU[K] = b01.x * 1e-3; l.bD[K] = b01.y * 1e-3; l.bL[K] = b23.x * 1e-3; l.bR[K] = b23.y * 1e-3;
-    l.A[K] = fma(ag.x * 1e-6, g.P[K], ag.y * 1e-6);
-  }
 #else
-  const double2 b01 = *(const double2 *)(btab + c * 4);
-  const double2 b23 = *(const double2 *)(btab + c * 4 + 2);
-  const double2 ag = *(const double2 *)(agtab + c * 2);
-  l.bU[K] = b01.x; l.bD[K] = b01.y; l.bL[K] = b23.x; l.bR[K] = b23.y;
-  l.A[K] = fma(ag.x, g.P[K], ag.y);
+  const double *bt = tab + c;
+  l.bU[K] = bt[0]; l.bD[K] = bt[TS]; l.bL[K] = bt[2 * TS]; l.bR[K] = bt[3 * TS];
+  l.A[K] = fma(bt[4 * TS], g.P[K], gtab[c]);
 #endif
 #if defined(SB_EXP) && (SB_EXP & 2) /* experiment: no E reads in the loop */
   l.Rn[K] = g.P[K]; l.Dn[K] = g.P[K]; if (MULTI) l.Ee[K] = g.P[K];
@@ -383,19 +367,19 @@ __device__ __forceinline__ void update_slot(double *E, const StageL &l, int li0,
 }
 
 // Computes the chunk held in l (li0, masks) while refilling each freed slot with chunk `nx`.
-template <bool MULTI>
-__device__ __forceinline__ void run_chunk(double *E, const double *agtab, const double *btab,
+template <bool MULTI, int TS>
+__device__ __forceinline__ void run_chunk(double *E, const double *gtab, const double *tab,
                                           StageL &l, int li0, int mlo, int mhi, const StageG &nx,
                                           int li0_after, double &nv, double &oldv, double &dmax) {
 #define SB_SLOT(K)                                                                        \
   update_slot<MULTI, K>(E, l, li0, slot_active<K>(mlo, mhi), nv, oldv, dmax);              \
-  load_slot<MULTI, K>(E, agtab, btab, nx, li0_after, l);
+  load_slot<MULTI, TS, K>(E, gtab, tab, nx, li0_after, l);
   SB_SLOT(0) SB_SLOT(1) SB_SLOT(2) SB_SLOT(3) SB_SLOT(4) SB_SLOT(5) SB_SLOT(6) SB_SLOT(7)
 #undef SB_SLOT
 }
 
-template <bool FIRST, bool MULTI>
-__device__ double sweep_fast(const Dev &a, double *E, const double *agtab, const double *btab,
+template <bool FIRST, bool MULTI, int TS>
+__device__ double sweep_fast(const Dev &a, double *E, const double *gtab, const double *tab,
                              const double *__restrict__ Pg, int lane) {
   double dmax = 0.0, nv = 0.0;
   const int nch = (a.nsteps + kChunk - 1) / kChunk;
@@ -408,7 +392,7 @@ __device__ double sweep_fast(const Dev &a, double *E, const double *agtab, const
   stage_g<FIRST>(a, E, Pg, s1, g1);
   stage_s(a, 2, lane, s0);
   stage_s(a, 3, lane, s1);
-#define SB_LOAD0(K) load_slot<MULTI, K>(E, agtab, btab, g0, g1.li0, l);
+#define SB_LOAD0(K) load_slot<MULTI, TS, K>(E, gtab, tab, g0, g1.li0, l);
   SB_LOAD0(0) SB_LOAD0(1) SB_LOAD0(2) SB_LOAD0(3) SB_LOAD0(4) SB_LOAD0(5) SB_LOAD0(6) SB_LOAD0(7)
 #undef SB_LOAD0
   double oldv = E[g0.li0];
@@ -416,25 +400,33 @@ __device__ double sweep_fast(const Dev &a, double *E, const double *agtab, const
   for (int ch = 0; ch < nch; ch += 2) {
     stage_g<FIRST>(a, E, Pg, s0, g0);   // chunk ch+2
     stage_s(a, ch + 4, lane, s0);
-    run_chunk<MULTI>(E, agtab, btab, l, li0, mlo, mhi, g1, g0.li0, nv, oldv, dmax);
+    run_chunk<MULTI, TS>(E, gtab, tab, l, li0, mlo, mhi, g1, g0.li0, nv, oldv, dmax);
     li0 = g1.li0; mlo = g1.mlo; mhi = g1.mhi;
     stage_g<FIRST>(a, E, Pg, s1, g1);   // chunk ch+3
     stage_s(a, ch + 5, lane, s1);
-    run_chunk<MULTI>(E, agtab, btab, l, li0, mlo, mhi, g0, g1.li0, nv, oldv, dmax);
+    run_chunk<MULTI, TS>(E, gtab, tab, l, li0, mlo, mhi, g0, g1.li0, nv, oldv, dmax);
     li0 = g0.li0; mlo = g0.mlo; mhi = g0.mhi;
   }
   return wave_max(dmax);
 }
 
-__device__ __forceinline__ double sweep(const Dev &a, double *E, const double *agtab,
-                                        const double *btab, const double *__restrict__ Pg,
-                                        int lane, bool first) {
-  if (!a.fast) return sweep_generic(a, E, agtab, btab, Pg, lane);
+template <int TS>
+__device__ __forceinline__ double sweep_ts(const Dev &a, double *E, const double *gtab,
+                                           const double *tab, const double *__restrict__ Pg,
+                                           int lane, bool first) {
   if (a.nbands > 1)
-    return first ? sweep_fast<true, true>(a, E, agtab, btab, Pg, lane)
-                 : sweep_fast<false, true>(a, E, agtab, btab, Pg, lane);
-  return first ? sweep_fast<true, false>(a, E, agtab, btab, Pg, lane)
-               : sweep_fast<false, false>(a, E, agtab, btab, Pg, lane);
+    return first ? sweep_fast<true, true, TS>(a, E, gtab, tab, Pg, lane)
+                 : sweep_fast<false, true, TS>(a, E, gtab, tab, Pg, lane);
+  return first ? sweep_fast<true, false, TS>(a, E, gtab, tab, Pg, lane)
+               : sweep_fast<false, false, TS>(a, E, gtab, tab, Pg, lane);
+}
+
+__device__ __forceinline__ double sweep(const Dev &a, double *E, const double *gtab,
+                                        const double *tab, const double *__restrict__ Pg,
+                                        int lane, bool first) {
+  if (!a.fast) return sweep_generic(a, E, gtab, tab, Pg, lane);
+  if (a.ts == 32) return sweep_ts<32>(a, E, gtab, tab, Pg, lane, first);
+  return sweep_ts<128>(a, E, gtab, tab, Pg, lane, first);
 }
 
 // ---------------------------------------------------------------- observation row
@@ -549,21 +541,21 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
   const int wpb = blockDim.x >> 6;
   const int wave = blockIdx.x * wpb + wib;
   const int nwaves = gridDim.x * wpb;
-  // LDS: [btab: (ncls+1)*4] then per wave [E: NL | agtab: (ncls+1)*2 | zscr: 3*Z | zmode: Z ints]
-  double *btab = lds;
-  int *zoffL = (int *)(lds + (a.ncls + 1) * 4); // [Z+1] zone_off, shared
-  double *mine = lds + (a.ncls + 1) * 4 + ((a.Z + 2) >> 1) + (size_t)wib * a.lds_wave_doubles;
+  // LDS: [tab: 5*ts | zone_off] then per wave [guard | E: NL | guard | gtab: ts | zscr: 3*Z | zmode]
+  double *tab = lds;
+  int *zoffL = (int *)(lds + 5 * a.ts); // [Z+1] zone_off, shared
+  double *mine = lds + 5 * a.ts + ((a.Z + 2) >> 1) + (size_t)wib * a.lds_wave_doubles;
   double *E = mine + kGuard; // [guard | E: NL | guard]: the guards stay zero (finite) forever
   for (int i = lane; i < kGuard; i += 64) {
     mine[i] = 0.0;
     mine[kGuard + a.NL + i] = 0.0;
   }
-  double *agtab = mine + a.off_agtab;
+  double *gtab = mine + a.off_agtab;
   double *zscr = mine + a.off_zscr; // [0..Z) tz_pre, [Z..2Z) q / post means, [2Z..3Z) tzs
   int *zmode = (int *)(mine + a.off_zmode);
-  for (int i = threadIdx.x; i < (a.ncls + 1) * 4; i += blockDim.x) {
-    const int c = i >> 2, j = i & 3;
-    btab[i] = c < a.ncls ? a.ctab[c * 8 + j] : 0.0;
+  for (int i = threadIdx.x; i < 5 * a.ts; i += blockDim.x) {
+    const int j = i / a.ts, c = i - j * a.ts;
+    tab[i] = c < a.ncls ? a.ctab[c * 8 + j] : 0.0; // columns 0..4 of class_coef: bU bD bL bR ap
   }
   for (int i = threadIdx.x; i <= a.Z; i += blockDim.x) zoffL[i] = a.zone_off[i];
   __syncthreads();
@@ -606,16 +598,14 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
     const double mixed = p.ahu_recirc * recirc + (1 - p.ahu_recirc) * t_now;
     const double t_sa = ahu_supply(mixed, heat_sp, cool_sp);
 
-    for (int c = lane; c <= a.ncls; c += 64) {
-      double ap = 0.0, gg = 0.0;
+    for (int c = lane; c < a.ts; c += 64) {
+      double gg = 0.0;
       if (c < a.ncls) {
         const int zc = a.czone[c];
         const double q = zc >= 0 ? zscr[a.Z + zc] : 0.0;
-        ap = a.ctab[c * 8 + 4];
         gg = fma(a.ctab[c * 8 + 6], q, a.ctab[c * 8 + 5] * t_now);
       }
-      agtab[2 * c] = ap;
-      agtab[2 * c + 1] = gg;
+      gtab[c] = gg;
     }
     SB_STAMP(1);
     // grid -> LDS.  Even W: one flat copy by LDS-DMA (global_load_lds_dwordx4: 1 KiB per
@@ -638,7 +628,7 @@ __global__ void __launch_bounds__(256) k_step(Dev a, StepArgs s) {
     SB_STAMP(2);
     int n_sweeps = 0, converged = 0;
     for (int it = 0; it < p.iter_limit; ++it) { // simulator.py:348-368
-      const double md = sweep(a, E, agtab, btab, T, lane, it == 0);
+      const double md = sweep(a, E, gtab, tab, T, lane, it == 0);
       ++n_sweeps;
       if (md <= p.conv_threshold) { converged = 1; break; }
     }
@@ -942,11 +932,13 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
 
   // per-wave LDS region (doubles): E | agtab | zscr(3Z) | zmode(Z ints)
   int off = ((d.NL + 1) & ~1) + 2 * kGuard;
-  d.off_agtab = off; off += (d.ncls + 1) * 2;
+  d.ts = d.ncls <= 32 ? 32 : 128;
+  if (d.ncls > 128) { d.ts = (d.ncls + 1) & ~1; d.fast = 0; } // generic sweep handles any table size
+  d.off_agtab = off; off += d.ts;
   d.off_zscr = off; off += (3 * d.Z + 1) & ~1;
   d.off_zmode = off; off += ((d.Z + 1) / 2 + 1) & ~1;
   d.lds_wave_doubles = off;
-  const size_t shared_bytes = (size_t)(d.ncls + 1) * 4 * 8 + (size_t)((d.Z + 2) >> 1) * 8;
+  const size_t shared_bytes = (size_t)5 * d.ts * 8 + (size_t)((d.Z + 2) >> 1) * 8;
   const size_t wave_bytes = (size_t)off * 8;
   const size_t lds_cap = 160 * 1024;
   if (shared_bytes + wave_bytes > lds_cap) {
