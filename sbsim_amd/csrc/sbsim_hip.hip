@@ -919,9 +919,11 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   d.ncls = plan->n_classes;
   d.pitch = (plan->W + 1) & ~1; // even pitch: skewed ds_read_b64 is bank-conflict free
   d.NL = d.H * d.pitch;
-  d.S = std::max(plan->W + kChunk, 64); // >= kChunk idle positions between a lane's rows
-  d.S_magic = (unsigned)((1ull << 32) / (unsigned)d.S) + 1u;
   const int nbands = (d.H + 63) / 64;
+  // band stride: >= kChunk idle positions between a lane's rows, and with several bands the
+  // seam row must be written >= 17 steps before lane 0 prefetches it (S - 63 > 2*kChunk)
+  d.S = std::max(plan->W + kChunk, nbands > 1 ? 64 + 2 * kChunk : 64);
+  d.S_magic = (unsigned)((1ull << 32) / (unsigned)d.S) + 1u;
   const int rows_last = d.H - (nbands - 1) * 64;
   d.nsteps = (nbands - 1) * d.S + rows_last + d.W - 1;
   d.nbands = nbands;

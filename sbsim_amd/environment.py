@@ -200,14 +200,22 @@ class BatchedSimulator:
   def __init__(self, plan: FloorPlan, config: SimConfig, n_buildings: int, h_conv: float,
                device: int = 0,
                observation_normalization: Optional[Mapping[str, Tuple[float, float]]] = None,
-               zone_names: Optional[Sequence[str]] = None):
+               zone_names: Optional[Sequence[str]] = None, orientation: str = "auto"):
     self._lib = _ffi.load()
     if not torch.cuda.is_available():
       raise _ffi.SbsimError("sbsim_amd needs a HIP device (MI355X); there is no CPU path")
     self.plan, self.config, self.B, self.device = plan, config, int(n_buildings), int(device)
-    self.compiled: CompiledPlan = plan.compile(config.time_step_sec, h_conv)
+    H0, W0 = plan.shape
+    # device-side orientation: whichever needs fewer wavefront steps per sweep (internal to the
+    # library; reset()/temps() convert, so callers always see the reference's [H, W] layout)
+    if orientation not in ("auto", "rows", "columns"):
+      raise ValueError("orientation must be 'auto', 'rows' or 'columns'")
+    self.transposed = (orientation == "columns" or
+                       (orientation == "auto" and FloorPlan.sweep_steps(W0, H0) < FloorPlan.sweep_steps(H0, W0)))
+    dev_plan = plan.transposed() if self.transposed else plan
+    self.compiled: CompiledPlan = dev_plan.compile(config.time_step_sec, h_conv)
     cp = self.compiled
-    self.Z, self.H, self.W = cp.Z, cp.H, cp.W
+    self.Z, self.H, self.W = cp.Z, H0, W0
     zone_names = list(zone_names or plan.zone_names or [f"room_{i + 1}" for i in range(cp.Z)])
     (self.field_names, col_ahu, col_blr, col_zone, col_aux) = observation_field_names(
         zone_names, config.ahu_has_weather_sensor)
@@ -264,6 +272,8 @@ class BatchedSimulator:
     if temps is not None:
       if temps.dtype != torch.float64 or tuple(temps.shape) != (self.B, self.H * self.W) or not temps.is_contiguous():
         raise ValueError("temps must be a contiguous float64 [B, H*W] tensor")
+      if self.transposed:
+        temps = temps.view(self.B, self.H, self.W).transpose(1, 2).contiguous()
       ptr = C.c_void_p(temps.data_ptr())
     t0 = self.config.initial_temp if initial_temp is None else float(initial_temp)
     _ffi.check(self._lib.sb_reset(self._h, t0, ptr, self._stream()), "sb_reset")
@@ -294,6 +304,9 @@ class BatchedSimulator:
     return out
 
   def temps(self) -> torch.Tensor:
+    if self.transposed:
+      t = self._get(self._lib.sb_get_temps, (self.B, self.W, self.H), torch.float64)
+      return t.transpose(1, 2).contiguous()
     return self._get(self._lib.sb_get_temps, (self.B, self.H, self.W), torch.float64)
 
   def zone_temps(self) -> torch.Tensor:

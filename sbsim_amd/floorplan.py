@@ -220,6 +220,30 @@ class FloorPlan:
     present &= solid[:, :, None]
     return present, present.sum(axis=2).astype(np.int32)
 
+  def transposed(self) -> "FloorPlan":
+    """The same building with rows and columns exchanged.  The reference's row-major
+    in-place sweep only requires that a cell is updated after its upper and left neighbours
+    (simulator.py:302-314); that dependency set is symmetric under transposition, so
+    sweeping the transposed grid row-major visits cells in another topological order of the
+    same dependency graph and produces the same iterates (up to the association order of the
+    four-neighbour sum).  The device library uses whichever orientation needs fewer
+    wavefront steps (`sweep_steps`)."""
+    return dataclasses.replace(
+        self, conductivity=np.ascontiguousarray(self.conductivity.T),
+        heat_capacity=np.ascontiguousarray(self.heat_capacity.T),
+        density=np.ascontiguousarray(self.density.T),
+        exterior_space=np.ascontiguousarray(self.exterior_space.T),
+        zone_label=np.ascontiguousarray(self.zone_label.T),
+        diffusers=np.ascontiguousarray(self.diffusers.T))
+
+  @staticmethod
+  def sweep_steps(n_rows: int, n_cols: int) -> int:
+    """Wavefront steps of one Gauss-Seidel sweep in the HIP kernel (sbsim_hip.hip): lanes own
+    rows in bands of 64, a lane's consecutive rows are spaced max(W+8, 64 or 80) positions apart."""
+    bands = (n_rows + 63) // 64
+    stride = max(n_cols + 8, 80 if bands > 1 else 64)
+    return (bands - 1) * stride + (n_rows - (bands - 1) * 64) + n_cols - 1
+
   # ------------------------------------------------------------------ compile
   def compile(self, dt: float, h_conv: float) -> CompiledPlan:
     """Folds simulator.py:98-276 into per-cell classes (see module docstring)."""

@@ -101,9 +101,9 @@ class FastSweepModel:
     self.H, self.W = H, W
     self.pitch = (W + 1) & ~1
     self.NL = H * self.pitch
-    self.S = max(W + KCH, 64)
-    self.magic = (1 << 32) // self.S + 1
     self.nbands = (H + 63) // 64
+    self.S = max(W + KCH, 64 + 2 * KCH if self.nbands > 1 else 64)
+    self.magic = (1 << 32) // self.S + 1
     rows_last = H - (self.nbands - 1) * 64
     self.nsteps = (self.nbands - 1) * self.S + rows_last + W - 1
     self.fast = self.nbands == 1 or (self.S - 63 > 2 * KCH)

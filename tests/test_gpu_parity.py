@@ -59,7 +59,11 @@ def test_one_day_rollout_against_reference_golden(tag):
   _need_gpu()
   g = load(f"h2_sb1_r9_{tag}.npz")
   B = 5
-  sim = BatchedSimulator(_plan(load("plan_r9_sb1.npz")), SimConfig.sb1(), B, float(g["h_conv"]))
+  # "random" runs in the library's preferred orientation (columns as lanes for R9), "const" forces
+  # rows as lanes (two bands + seam): both wavefront schedules are checked against the reference
+  sim = BatchedSimulator(_plan(load("plan_r9_sb1.npz")), SimConfig.sb1(), B, float(g["h_conv"]),
+                         orientation="auto" if tag == "random" else "rows")
+  assert sim.transposed == (tag == "random")
   sim.reset()
   obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
   rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
