@@ -340,10 +340,17 @@ __device__ __forceinline__ void load_slot(const double *E, const double *gtab, c
 #endif
 }
 
-// lane l <- lane l-1's x; lane 0 (no source lane) keeps `seam`.
+// lane l <- lane l-1's x; lane 0 (no source lane) keeps `seam` (MULTI) or reads 0.
+template <bool MULTI>
 __device__ __forceinline__ double shr1_seam(double x, double seam) {
-  int lo = __builtin_amdgcn_update_dpp(__double2loint(seam), __double2loint(x), 0x138, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(__double2hiint(seam), __double2hiint(x), 0x138, 0xf, 0xf, false);
+  int lo, hi;
+  if (MULTI) { // the DPP `old` operand is the seam value: no extra instruction
+    lo = __builtin_amdgcn_update_dpp(__double2loint(seam), __double2loint(x), 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(seam), __double2hiint(x), 0x138, 0xf, 0xf, false);
+  } else {     // bound_ctrl: out-of-range source reads 0, `old` is a don't-care (no v_mov to set it up)
+    lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x138, 0xf, 0xf, true);
+  }
   return __hiloint2double(hi, lo);
 }
 
@@ -351,7 +358,7 @@ __device__ __forceinline__ double shr1_seam(double x, double seam) {
 template <bool MULTI, int K>
 __device__ __forceinline__ void update_slot(double *E, const StageL &l, int li0, bool act,
                                             double &nv, double &oldv, double &dmax) {
-  const double U = shr1_seam(nv, MULTI ? l.Ee[K] : 0.0);
+  const double U = shr1_seam<MULTI>(nv, MULTI ? l.Ee[K] : 0.0);
   double t = fma(l.bD[K], l.Dn[K], l.A[K]);
   t = fma(l.bR[K], l.Rn[K], t);
   t = fma(l.bL[K], nv, t);
