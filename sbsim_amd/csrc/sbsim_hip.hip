@@ -56,7 +56,7 @@ struct Dev {
   int S, nsteps;           // band stride (max(W+8,64)) and sweep steps per sweep
   unsigned S_magic;        // floor(2^32 / S) + 1
   int nbands, fast;        // fast: register/DPP sweep is legal for this shape
-  int ts;                  // coefficient-table stride in entries (32 or 128; >= ncls)
+  int ts;                  // coefficient-table stride in entries (32, 128 or 256; >= ncls)
   int lds_wave_doubles;    // per-wave LDS region, in doubles
   int off_agtab, off_zscr, off_zmode; // offsets inside the per-wave region (doubles)
   // static tables
@@ -433,7 +433,8 @@ __device__ __forceinline__ double sweep(const Dev &a, double *E, const double *g
                                         int lane, bool first) {
   if (!a.fast) return sweep_generic(a, E, gtab, tab, Pg, lane);
   if (a.ts == 32) return sweep_ts<32>(a, E, gtab, tab, Pg, lane, first);
-  return sweep_ts<128>(a, E, gtab, tab, Pg, lane, first);
+  if (a.ts == 128) return sweep_ts<128>(a, E, gtab, tab, Pg, lane, first);
+  return sweep_ts<256>(a, E, gtab, tab, Pg, lane, first);
 }
 
 // ---------------------------------------------------------------- observation row
@@ -941,8 +942,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
 
   // per-wave LDS region (doubles): E | agtab | zscr(3Z) | zmode(Z ints)
   int off = ((d.NL + 1) & ~1) + 2 * kGuard;
-  d.ts = d.ncls <= 32 ? 32 : 128;
-  if (d.ncls > 128) { d.ts = (d.ncls + 1) & ~1; d.fast = 0; } // generic sweep handles any table size
+  d.ts = d.ncls <= 32 ? 32 : (d.ncls <= 128 ? 128 : 256); // n_classes <= 255 (checked above)
   d.off_agtab = off; off += d.ts;
   d.off_zscr = off; off += (3 * d.Z + 1) & ~1;
   d.off_zmode = off; off += ((d.Z + 1) / 2 + 1) & ~1;

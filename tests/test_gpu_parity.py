@@ -237,3 +237,77 @@ def test_abi_error_paths():
   sim = BatchedSimulator(_plan(p), SimConfig(), 2, 12.0)
   with pytest.raises(ValueError):
     sim.step(torch.zeros((3, 2), device="cuda"), _ffi.StepIn(), None, torch.zeros(2, device="cuda"))
+
+
+def _oracle_twin(plan, cfg, init_flat):
+  oplan = orc.OraclePlan(plan.conductivity, plan.density, plan.heat_capacity, plan.exterior_space,
+                         plan.zone_cell_lists(), plan.diffusers, plan.cv_size_cm, plan.floor_height_cm)
+  c = cfg
+  oprm = orc.OracleParams(
+      dt=c.time_step_sec, conv_threshold=c.convergence_threshold, iter_limit=c.iteration_limit,
+      vav_max_air_flow=c.vav_max_air_flow_rate, vav_max_water_flow=c.vav_reheat_max_water_flow_rate,
+      ahu_recirc=c.ahu_recirculation, ahu_heat_sp=c.ahu_heating_air_temp_setpoint,
+      ahu_cool_sp=c.ahu_cooling_air_temp_setpoint, ahu_dp=c.ahu_fan_differential_pressure,
+      ahu_eff=c.ahu_fan_efficiency, blr_setpoint=c.boiler_reheat_water_setpoint,
+      blr_head=c.boiler_water_pump_differential_head, blr_pump_eff=c.boiler_water_pump_efficiency,
+      comfort_lo=c.comfort_temp_window[0], comfort_hi=c.comfort_temp_window[1],
+      eco_lo=c.eco_temp_window[0], eco_hi=c.eco_temp_window[1],
+      blr_heating_rate=c.boiler_heating_rate, blr_cooling_rate=c.boiler_cooling_rate, ahu_has_weather=1)
+  return orc.OracleBuilding(oplan, oprm, 0.0, reset_temps=init_flat)
+
+
+@pytest.mark.parametrize("rooms,room_shape,orientation", [
+    ((8, 5), (12, 14), "auto"),     # "SB2-synth": 40 zones, 109x81 grid, 2 bands either way
+    ((14, 9), (8, 7), "auto"),      # "SB1-synth": 126 zones (the real SB1's VAV count), 131x78 grid, 3 bands
+    ((2, 3), (9, 10), "rows"),      # small: single band, W < 64
+    ((5, 1), (12, 10), "generic"),  # H > 64, narrow grid, forced onto the generic (all-LDS) sweep
+])
+def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, monkeypatch):
+  """BASELINE.json configs[2] semantics: other floor-plan classes (different H x W and zone
+  counts) through the same C ABI, each checked against its CPU-oracle twin."""
+  _need_gpu()
+  from sbsim_amd.floorplan import rectangular_floor_plan
+  g = load("h2_sb1_r9_random.npz")
+  plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, room_shape), Materials.sb1(), 10.0, 300.0)
+  H, W = plan.shape
+  B, T = 6, 14
+  rs = np.random.RandomState(11)
+  init = np.clip(294.0 + 2.0 * rs.randn(B, 1) + 0.2 * rs.randn(B, H * W), 285.0, 305.0)
+  acts = rs.uniform(-1, 1, size=(T, B, 2)).astype(np.float32)
+  cfg = SimConfig.sb1()
+  if orientation == "generic":
+    monkeypatch.setenv("SBSIM_FORCE_GENERIC_SWEEP", "1")
+    orientation = "rows"
+  sim = BatchedSimulator(plan, cfg, B, float(g["h_conv"]), orientation=orientation)
+  assert sim.Z == rooms[0] * rooms[1]
+  sim.reset(temps=torch.tensor(init, dtype=torch.float64, device="cuda"))
+  twins = [_oracle_twin(plan, cfg, init[b]) for b in range(B)]
+  obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  lo, hi = cfg.action_ranges
+  for t in range(T):
+    tt = 96 + t   # mid-morning: occupied, comfort mode
+    sim.step(torch.tensor(acts[t], device="cuda"), _step_in(g, tt), obs, rew, info)
+    i = info.cpu().numpy().astype(np.float64)
+    zt = sim.zone_temps().cpu().numpy()
+    r = rew.cpu().numpy()
+    for b in range(B):
+      a = acts[t, b]
+      native = [np.float32((float(a[0]) + 1.0) / 2.0 * (lo[1] - lo[0]) + lo[0]),
+                np.float32((float(a[1]) + 1.0) / 2.0 * (hi[1] - hi[0]) + hi[0])]
+      o = twins[b].step(
+          now_ts=300.0 * t, t_amb_now=float(g["t_amb_now"][tt]), h_conv=float(g["h_conv"]),
+          t_amb_next=float(g["t_amb_next"][tt]), comfort_now=bool(g["comfort_now"][tt]),
+          comfort_prev=g["comfort_prev"][tt] == 1, comfort_next=bool(g["comfort_next"][tt]),
+          occupancy=float(g["occupancy"][tt]), e_price=float(g["e_price"][tt]),
+          e_carbon=float(g["e_carbon"][tt]), g_price=float(g["g_price"][tt]),
+          g_carbon=float(g["g_carbon"][tt]), action=native, observe=True)
+      assert i[b, 4] == o["n_sweeps"], (t, b, i[b, 4], o["n_sweeps"])
+      assert np.abs(zt[b] - o["zone_temp_post"]).max() < T_TOL, (t, b)
+      ref = np.array([o["blower_rate"], o["ac_rate"], o["gas_rate"], o["pump_rate"]], np.float64)
+      assert np.allclose(i[b, :4], ref, rtol=2e-6, atol=1e-6), (t, b)
+      assert abs(float(r[b]) - o["reward"]) < 2e-6, (t, b)
+  grid = sim.temps().cpu().numpy()
+  for b in range(B):
+    assert np.abs(grid[b] - twins[b].grid()).max() < T_TOL, b
