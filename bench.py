@@ -40,11 +40,13 @@ def r9_plan() -> FloorPlan:
 
 
 def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, acts: np.ndarray,
-                 target_cpu_seconds: float = 20.0):
+                 warmup: int, target_cpu_seconds: float = 30.0):
   """Times the CPU oracle ("port": oracle/sb_oracle.c, float64, reference operation order,
   OpenMP over buildings) on a bounded sample of the same workload, and uses the same sample
   as an in-run parity check of the GPU path.  The oracle is the checker and the baseline,
-  never the product."""
+  never the product.  Like the GPU leg it first runs the `warmup` steps untimed (the start
+  state is not an equilibrium: the first steps need 10-100 sweeps), so both legs are timed on
+  the same steps of the same rollout."""
   from oracle import oracle as orc
   c = env.config
   oplan = orc.OraclePlan(plan.conductivity, plan.density, plan.heat_capacity, plan.exterior_space,
@@ -84,21 +86,24 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
           action=native))
     t0 = time.perf_counter()
     outs = batch.step(ins, n_threads=threads)
-    t_cpu += time.perf_counter() - t0
-    sweeps += sum(outs[b].n_sweeps for b in range(nb))
     n_steps += 1
     prev, ts = ts, ts + step
+    if n_steps <= warmup:
+      continue
+    t_cpu += time.perf_counter() - t0
+    sweeps += sum(outs[b].n_sweeps for b in range(nb))
     if t_cpu * threads >= target_cpu_seconds or t_cpu > 60.0:
       break
   env._prev_thermostat_ts = None
   zones = oplan.Z
-  value = nb * n_steps * zones / t_cpu
+  n_timed = n_steps - warmup
+  value = nb * n_timed * zones / t_cpu
   grids = np.stack([b.grid() for b in batch.buildings])
   return dict(value=value, unit="zone-updates/s", cores=threads, kind="port",
-              sample=f"{nb} buildings x {n_steps} steps of the bench workload "
-                     f"({sweeps / (nb * n_steps):.2f} sweeps/step), oracle/sb_oracle.c with OpenMP "
-                     f"over buildings, {t_cpu:.2f} s wall",
-              env_steps_per_s=nb * n_steps / t_cpu), grids, n_steps, nb
+              sample=f"{nb} buildings x {n_timed} steps of the bench workload after {warmup} untimed "
+                     f"warm-up steps ({sweeps / (nb * n_timed):.2f} sweeps/step), oracle/sb_oracle.c "
+                     f"with OpenMP over buildings, {t_cpu:.2f} s wall x {threads} threads",
+              env_steps_per_s=nb * n_timed / t_cpu), grids, n_steps, nb
 
 
 def main() -> None:
@@ -142,32 +147,41 @@ def main() -> None:
       dist.barrier()
     torch.cuda.synchronize(dev)
 
-  wev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(W)]
-  for t in range(W):
+  def new_events(n):
+    return [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n)]
+
+  def one_step(t, e):
+    """sb_step == its three launches (sb_step_phases 1|2|4), bracketed by HIP events on the
+    stream they are launched on: e[1]..e[2] is the sweep kernel, the dominant one."""
     si = env.make_step_in(env.current_simulation_timestamp)
-    wev[t][0].record()
-    env.sim.step(actions[t], si, env._obs, env._reward, env._info)
-    wev[t][1].record()
+    args = (actions[t], si, env._obs, env._reward, env._info)
+    e[0].record()
+    env.sim.step(*args, phases=1)     # k_pre: thermostats, VAV, demand
+    e[1].record()
+    env.sim.step(*args, phases=2)     # sweep kernel
+    e[2].record()
+    env.sim.step(*args, phases=4)     # k_post: reward, observation
+    e[3].record()
     env._prev_thermostat_ts = env._now
     env._now = env._now + env._step_interval
+
+  wev, ev = new_events(W), new_events(K)
+  for t in range(W):
+    one_step(t, wev[t])
     returns += env._reward
-  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
   sweeps = torch.zeros((), dtype=torch.float64, device=dev)
   barrier()
   t0 = time.perf_counter()
   for t in range(K):
-    si = env.make_step_in(env.current_simulation_timestamp)
-    ev[t][0].record()           # HIP events on the stream the kernel is launched on
-    env.sim.step(actions[W + t], si, env._obs, env._reward, env._info)
-    ev[t][1].record()
-    env._prev_thermostat_ts = env._now
-    env._now = env._now + env._step_interval
+    one_step(W + t, ev[t])
     returns += env._reward
     sweeps += env._info[:, 4].double().sum()
   barrier()
   elapsed = time.perf_counter() - t0
-  kernel_ms = [a.elapsed_time(b) for a, b in ev]
-  warm_ms = [a.elapsed_time(b) for a, b in wev]
+  kernel_ms = [e[1].elapsed_time(e[2]) for e in ev]
+  warm_ms = [e[1].elapsed_time(e[2]) for e in wev]
+  pre_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+  post_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
 
   elapsed = sd.max_over_ranks(elapsed, dev)
   gather_ms = 0.0
@@ -199,8 +213,11 @@ def main() -> None:
                    "return_gather_ms": gather_ms, "launch": li},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "k_step", "avg_kernel_ms": avg_kernel_s * 1e3,
-                     # rocprofv3 --stats averages over EVERY k_step launch of the command (warm-up
+                     "kernel": "k_sweep_reg" if li.get("path") == 1 else "k_sweep_lds",
+                     "avg_kernel_ms": avg_kernel_s * 1e3,
+                     # the step's two small launches around it (device algebra, reward/observation)
+                     "avg_pre_kernel_ms": pre_ms, "avg_post_kernel_ms": post_ms,
+                     # rocprofv3 --stats averages over EVERY sweep launch of the command (warm-up
                      # steps run more sweeps: the start state is not an equilibrium); same quantity:
                      "avg_kernel_ms_all_launches_incl_warmup": float(np.mean(warm_ms + kernel_ms)),
                      "kernel_ms_timed": [round(x, 4) for x in kernel_ms],
@@ -214,10 +231,10 @@ def main() -> None:
       result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
       result["roofline"]["traffic_source"] = t.get("source")
     if world == 1 and not args.no_cpu_baseline:
-      nb_s = 256
+      nb_s = 512
       acts_cpu = actions[:, :nb_s].cpu().numpy()
       base, grids, n_s, nb = cpu_baseline(env, plan, np.broadcast_to(t_init[:nb_s, None], (nb_s, H * Wd)).copy(),
-                                          acts_cpu)
+                                          acts_cpu, W)
       # in-run parity: replay the same sample on the GPU and compare grids
       env2 = BatchedEnvironment(plan, nb, device=local_rank, holiday_calendar="us")
       env2.reset()

@@ -20,6 +20,7 @@
  *                  simulator.py:548-576 reward_info and
  *                  reward/setpoint_energy_carbon_regret.py:142-291 compute_reward,
  *                  in the order of environment/environment.py:1228-1309 _step
+ *   sb_plan_info <- no reference counterpart (launch planning of this library)
  *   sb_get_*    <- parity taps (building.temp, get_zone_average_temps, device attributes)
  *
  * Conventions: plain C types only.  All `*_dev` pointers are DEVICE pointers (HBM) owned
@@ -43,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 1
+#define SB_ABI_VERSION 2
 #define SB_NUM_ACTIONS 2   /* boiler supply_water_setpoint, AHU supply_air_heating_temperature_setpoint */
 #define SB_NUM_AUX 7       /* hod cos/sin, dow cos/sin, comfort_now, comfort_soon, num_occupants */
 #define SB_INFO_STRIDE 8   /* floats per building in the optional info output */
@@ -117,10 +118,17 @@ typedef struct sb_launch_info {
   int32_t waves_per_workgroup, workgroups, lds_bytes_per_workgroup, sweep_steps;
   int64_t algorithmic_bytes_per_env_step; /* 8HW+24Z+4A+4O+44 (fp32 state) */
   int64_t state_bytes_per_env_step;       /* what this build really moves: fp64 grid r+w */
+  int32_t path;               /* 1: grid in registers (step_reg.hip), 0: grid in LDS (step_lds.hip) */
+  int32_t waves_per_building; /* wavefronts that share one building (1 or 2) */
 } sb_launch_info;
 
 int sb_abi_version(void);
 const char *sb_last_error(void);
+
+/* What sb_create would choose for this floor plan (no device needed): the host uses it to
+ * pick the cheaper of the two grid orientations (FloorPlan.transposed()).  n_obs as in
+ * sb_obs_layout. */
+int sb_plan_info(const sb_plan_desc *plan, int32_t n_obs, int32_t n_buildings, sb_launch_info *out);
 
 int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_layout *obs,
               int32_t n_buildings, int32_t device, sb_handle **out);
@@ -141,6 +149,17 @@ int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, float *o
  * converged, supply air K, reward before the fp32 store}. */
 int sb_step(sb_handle *h, const float *actions_dev, const sb_step_in *in, float *obs_dev,
             float *reward_dev, float *info_dev, void *stream);
+
+/* sb_step is three launches on `stream`: the per-building device algebra before the sweep
+ * (thermostats, VAV, demand), the Gauss-Seidel sweep kernel, reward / observation after it.
+ * Measurement entry: the same step with an explicit subset of the launches, so that a
+ * benchmark can bracket the sweep kernel alone with events.  A step is complete only after
+ * all three phases ran once, in this order, with the same arguments. */
+#define SB_PHASE_PRE 1
+#define SB_PHASE_SWEEP 2
+#define SB_PHASE_POST 4
+int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in, float *obs_dev,
+                   float *reward_dev, float *info_dev, void *stream, int32_t phases);
 
 /* Parity taps (all DEVICE outputs, float64). */
 int sb_get_temps(sb_handle *h, double *out_dev /* [B][H*W] */, void *stream);

@@ -68,11 +68,12 @@ class LaunchInfo(C.Structure):
   _fields_ = [("waves_per_workgroup", C.c_int32), ("workgroups", C.c_int32),
               ("lds_bytes_per_workgroup", C.c_int32), ("sweep_steps", C.c_int32),
               ("algorithmic_bytes_per_env_step", C.c_int64),
-              ("state_bytes_per_env_step", C.c_int64)]
+              ("state_bytes_per_env_step", C.c_int64),
+              ("path", C.c_int32), ("waves_per_building", C.c_int32)]
 
 
-EXPORTS = ("sb_abi_version", "sb_last_error", "sb_create", "sb_destroy", "sb_get_launch_info",
-           "sb_reset", "sb_observe", "sb_step", "sb_get_temps", "sb_get_zone_temps",
+EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",
+           "sb_reset", "sb_observe", "sb_step", "sb_step_phases", "sb_get_temps", "sb_get_zone_temps",
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles")
 
 _lib = None
@@ -97,12 +98,14 @@ def load():
   L.sb_last_error.restype = C.c_char_p
   L.sb_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(Params), C.POINTER(ObsLayout),
                           C.c_int32, C.c_int32, C.POINTER(vp)]
+  L.sb_plan_info.argtypes = [C.POINTER(PlanDesc), C.c_int32, C.c_int32, C.POINTER(LaunchInfo)]
   L.sb_destroy.argtypes = [vp]
   L.sb_destroy.restype = None
   L.sb_get_launch_info.argtypes = [vp, C.POINTER(LaunchInfo)]
   L.sb_reset.argtypes = [vp, C.c_double, vp, vp]
   L.sb_observe.argtypes = [vp, C.POINTER(C.c_float), C.c_double, vp, vp]
   L.sb_step.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp]
+  L.sb_step_phases.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp, C.c_int32]
   for name in ("sb_get_temps", "sb_get_zone_temps", "sb_get_scalars", "sb_get_modes",
                "sb_get_zone_power"):
     getattr(L, name).argtypes = [vp, vp, vp]

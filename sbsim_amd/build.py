@@ -11,9 +11,12 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-SRC = os.path.join(_HERE, "csrc", "sbsim_hip.hip")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["sbsim_hip.hip", "step_reg.hip", "step_lds.hip"]   # one translation unit per step kernel
+HEADERS = [os.path.join(CSRC, "sb_device.h"), os.path.join(ROOT, "include", "sbsim_amd.h")]
+OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(_HERE, "libsbsim_amd.so")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-fPIC"]
 
 
 def hipcc() -> str:
@@ -23,15 +26,31 @@ def hipcc() -> str:
   raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
 
 
+def _newer(target: str, deps) -> bool:
+  return os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-  deps = [SRC, os.path.join(ROOT, "include", "sbsim_amd.h")]
-  if (not force and os.path.exists(LIB)
-      and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)):
+  srcs = [os.path.join(CSRC, s) for s in SOURCES]
+  if not force and _newer(LIB, srcs + HEADERS):
     return LIB
-  cmd = [hipcc(), *HIPCC_FLAGS, "-I", os.path.join(ROOT, "include"), SRC, "-o", LIB]
-  if verbose:
-    cmd.append("-Rpass-analysis=kernel-resource-usage")
-  subprocess.run(cmd, check=True)
+  os.makedirs(OBJ_DIR, exist_ok=True)
+  cc = hipcc()
+  inc = ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+  procs, objs = [], []
+  for src in srcs:                       # the translation units compile in parallel
+    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    objs.append(obj)
+    if not force and _newer(obj, [src] + HEADERS):
+      continue
+    cmd = [cc, *HIPCC_FLAGS, *inc, "-c", src, "-o", obj]
+    if verbose:
+      cmd.append("-Rpass-analysis=kernel-resource-usage")
+    procs.append((cmd, subprocess.Popen(cmd)))
+  for cmd, pr in procs:
+    if pr.wait() != 0:
+      raise subprocess.CalledProcessError(pr.returncode, cmd)
+  subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], check=True)
   return LIB
 
 

@@ -1,0 +1,535 @@
+// step_reg.hip -- the sweep kernel whose temperature grid lives in registers.
+//
+// Layout.  The floor plan is trimmed to the bounding box of its non-exterior cells (the
+// exterior-space ring is the constant T_ambient and is handled analytically).  Row R of the
+// trimmed grid belongs to one lane; the lane keeps the row in NR registers ("slots"), column
+// c in slot (c + l) mod NR where l is the lane's index inside its wavefront.  At sweep step d
+// every lane works on slot d mod NR -- the SAME register index in all lanes -- which for lane l
+// is column d - l: the anti-diagonal wavefront that reproduces the reference's row-major
+// in-place Gauss-Seidel order (simulator.py:302-314).  Neighbours:
+//     L = slot d-1 of the lane (updated one step ago)      R = slot d+1 (old)
+//     U = slot d-1 of lane l-1 (DPP wave_shr:1, new)        D = slot d+1 of lane l+1 (DPP wave_shl:1, old)
+// so the sweep touches no memory for the grid at all.  The sweep is fully unrolled (slot
+// indices and lane masks are compile-time constants); per step it reads four coefficients
+// (two ds_read2_b64), A = ap*Tprev + g (computed once per step into LDS) and runs 4 DPP
+// moves + 4 fp64 FMAs in the association order of step_lds.hip (bit-identical iterates).
+//
+// Floor plans with more than 64 rows use two wavefronts per building (P = 2): wave 0 owns the
+// upper rows (in its TOP lanes, so that its seam row is lane 63), wave 1 the lower rows
+// (seam row = lane 0).  The two seam rows are exchanged through LDS once per 8-step chunk;
+// wave 0 counts its finished chunks in LDS and wave 1 starts chunk i only once wave 0 has
+// finished chunk i + lag (sb_create: seam_lag), which orders every cross-wave read-after-
+// write (wave 0's new seam row) and write-after-read (wave 1's old seam row) -- a workgroup
+// barrier per chunk costs ~600 cycles on gfx950, a satisfied flag check nothing.  The DPP
+// `old` operand carries the seam value into the edge lane.
+//
+// HBM state of a building: [NR][RS] float64, slot-major (one coalesced 8*RS-byte row per
+// register), pad cells 0.
+#include "sb_device.h"
+
+namespace sb {
+namespace {
+
+// Kernel modes (template parameter P): 1 = one wavefront per building, <= 64 rows;
+// 2 = two wavefronts per building (<= 128 rows); 3 = one wavefront owns rows 0..63 and the
+// last one or two rows ("tail") are finished after the wavefront's pass by a parallel scan.
+constexpr int kPair = 2, kTail = 3;
+constexpr int kLook = 2;   // steps between the LDS reads of a step and its arithmetic
+constexpr int kTS = 32;    // coefficient-table stride (classes + the pad class <= 32)
+constexpr int kSeamPad = 8;
+
+// Hides a value from loop-invariant code motion: without it the compiler precomputes every
+// table address of the unrolled loops once per kernel and spills them to scratch.
+// (An integer offset is hidden, not the pointer: the pointer keeps its address space.)
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+struct Co { double bU, bD, bL, bR, A, smU, smD; };
+struct Pipe {
+  Co co[kLook + 1];
+  unsigned long long cw[3]; // class bytes of three consecutive chunks
+};
+
+// lane l <- lane l-1 (CTRL 0x138, wave_shr:1) / lane l+1 (0x130, wave_shl:1).  SEAM: a lane
+// without source keeps `old` (bound_ctrl = 0; the DPP destination is pre-loaded with the
+// seam value, so `old` must be a register nobody else needs); otherwise it reads 0.
+template <int CTRL, bool SEAM>
+__device__ __forceinline__ double wave_shift1(double x, double old) {
+  int lo, hi;
+  if (SEAM) {
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, 0xf, false);
+  } else {
+    lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  }
+  return __hiloint2double(hi, lo);
+}
+
+// LDS reads of step PD (issued kLook steps early): coefficients by class, A, seam value.
+template <int NR, int P, int PD>
+__device__ __forceinline__ void prefetch(Pipe &p, const double *tab, const double *Arow,
+                                         const double *seam_in, const double *seam_in2) {
+  const unsigned long long cw = p.cw[(PD / 8) % 3];
+  const int c = (int)((cw >> (8 * (PD % 8))) & 0xffull);
+  const double *bt = tab + c;
+  Co &o = p.co[PD % (kLook + 1)];
+  o.bU = bt[0]; o.bD = bt[kTS]; o.bL = bt[2 * kTS]; o.bR = bt[3 * kTS];
+  o.A = Arow[PD % NR];
+  if (P == kPair) { // two reads of the same value: each DPP consumes its `old` register
+    o.smU = seam_in[PD];
+    o.smD = seam_in2[PD];
+  }
+  if (P == kTail) o.smD = seam_in[PD]; // old value of the first tail row under lane 63
+}
+
+// One Gauss-Seidel update of every lane's current cell.  lp = lane's row index inside its
+// wavefront (0x80000000 for lanes without a row): the lane holds a real column at step D
+// iff 0 <= D - lp < NR.
+template <int NR, int P, int D>
+__device__ __forceinline__ void update(double (&e)[NR], const Co &o, int lp, unsigned long long rowmask,
+                                       double &dmax) {
+  constexpr int r = D % NR, rm = (D + NR - 1) % NR, rp = (D + 1) % NR;
+  const double U = wave_shift1<0x138, P == kPair>(e[rm], o.smU);
+  const double Dn = wave_shift1<0x130, P == kPair || P == kTail>(e[rp], o.smD);
+  double t = fma(o.bD, Dn, o.A);
+  t = fma(o.bR, e[rp], t);
+  t = fma(o.bL, e[rm], t);
+  const double nv = fma(o.bU, U, t);
+  constexpr bool need_hi = D < 63;   // lp <= D can fail
+  constexpr bool need_lo = D >= NR;  // lp > D - NR can fail
+  bool act;
+  if (need_hi && need_lo) act = (unsigned)(D - lp) < (unsigned)NR;
+  else if (need_hi) act = (unsigned)lp <= (unsigned)D;
+  else if (need_lo) act = lp > D - NR;
+  else act = __builtin_amdgcn_inverse_ballot_w64(rowmask);
+  const double sel = act ? nv : e[r];
+  dmax = fmax(dmax, fabs(sel - e[r]));
+  e[r] = sel;
+}
+
+struct SweepCtx {
+  const double *tab, *Arow, *seam_in, *seam_in2; // seam_in2 == seam_in, but the compiler cannot tell
+  double *seam_out;
+  const unsigned long long *cmap;
+  unsigned long long rowmask;
+  int lane, lp, nch, edge_off;
+  bool edge;
+  // P == 2: wave 0 counts its finished chunks in *prog; wave 1 starts chunk i only when wave
+  // 0 has finished chunk i + lag (capped at wave 0's last chunk)
+  volatile int *prog;
+  int role, lag, nch0, prog_base;
+};
+
+template <int NR, int P, int CI, int K>
+__device__ __forceinline__ void chunk_steps(double (&e)[NR], Pipe &p, const SweepCtx &x, double &dmax) {
+  if constexpr (K < 8 && 8 * CI + K < NR + 63) {
+    constexpr int D = 8 * CI + K;
+    prefetch<NR, P, D + kLook>(p, x.tab, x.Arow, x.seam_in, x.seam_in2);
+    update<NR, P, D>(e, p.co[D % (kLook + 1)], x.lp, x.rowmask, dmax);
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_steps<NR, P, CI, K + 1>(e, p, x, dmax);
+  }
+}
+
+template <int NR, int P, int CI, int K>
+__device__ __forceinline__ void publish(const double (&e)[NR], double *seam_out) {
+  if constexpr (K < 8 && 8 * CI + K < NR + 63) {
+    seam_out[8 * CI + K] = e[(8 * CI + K) % NR];
+    publish<NR, P, CI, K + 1>(e, seam_out);
+  }
+}
+
+// Wave 1 waits until wave 0's progress counter reaches `target`.  `seen` caches the last
+// value read: wave 0 is usually several chunks ahead, so most chunks need no LDS read at all.
+__device__ __forceinline__ void wait_progress(volatile int *prog, int target, int &seen) {
+  while (seen < target) {
+    asm volatile("" ::: "memory");
+    seen = __builtin_amdgcn_readfirstlane(*prog);
+    if (seen < target) __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+
+template <int NR, int P, int CI>
+__device__ __forceinline__ void chunks(double (&e)[NR], Pipe &p, const SweepCtx &x, double &dmax, int &seen) {
+  constexpr int kMaxCh = (NR + 63 + 7) / 8;
+  if constexpr (CI < kMaxCh) {
+    if (CI < x.nch) { // wave-uniform
+      if (P == kPair && x.role == 1) wait_progress(x.prog, x.prog_base + min(CI + x.lag, x.nch0), seen);
+      p.cw[(CI + 2) % 3] = x.cmap[opaque(0) + (CI + 2) * 64];
+      chunk_steps<NR, P, CI, 0>(e, p, x, dmax);
+      if (P == kPair || P == kTail) {
+        // publish the edge row's new values of this chunk (columns 8*CI-edge_off .. +7)
+        const int c0 = 8 * CI - x.edge_off;
+#if !(defined(SB_EXP) && (SB_EXP & 2)) /* timing experiment 2: no seam publication */
+        if (c0 + 7 >= 0 && c0 < NR) {
+          if (x.edge) publish<NR, P, CI, 0>(e, x.seam_out);
+        }
+#endif
+      }
+      if (P == kPair) {
+        // LDS executes a wavefront's instructions in order: whoever sees the counter sees the
+        // seam values written before it, and every LDS read this wave issued so far is done
+        asm volatile("" ::: "memory");
+        if (x.role == 0 && x.lane == 0) *x.prog = x.prog_base + CI + 1;
+        asm volatile("" ::: "memory");
+      }
+      chunks<NR, P, CI + 1>(e, p, x, dmax, seen);
+    }
+  }
+}
+
+template <int NR, int P>
+__device__ __forceinline__ double sweep_reg(double (&e)[NR], const SweepCtx &x) {
+  double dmax = 0.0;
+  int seen = 0;
+  if (P == kPair && x.role == 1) wait_progress(x.prog, x.prog_base + min(x.lag, x.nch0), seen);
+  Pipe p;
+  p.cw[0] = x.cmap[opaque(0)];
+  p.cw[1] = x.cmap[opaque(0) + 64];
+  p.cw[2] = 0;
+  prefetch<NR, P, 0>(p, x.tab, x.Arow, x.seam_in, x.seam_in2);
+  prefetch<NR, P, 1>(p, x.tab, x.Arow, x.seam_in, x.seam_in2);
+  __builtin_amdgcn_sched_barrier(0);
+  chunks<NR, P, 0>(e, p, x, dmax, seen);
+  return dmax;
+}
+
+// ---------------------------------------------------------------- tail rows (mode kTail)
+// Rows 64.. of the trimmed grid (at most two) are finished after the wavefront's pass, lanes
+// = columns.  Along a row the Gauss-Seidel update is the first-order recurrence
+//     x_c = bL_c * x_{c-1} + q_c,    q_c = A + bD*D_old + bR*R_old + bU*U_new,
+// which an inclusive scan over the affine maps f_c(x) = bL_c x + q_c evaluates in
+// log2(64) DPP steps (F <- F o F_shifted; lanes without a source compose with the identity).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void scan_step(double &a, double &q) {
+  const double one = 1.0;
+  const int alo = __builtin_amdgcn_update_dpp(__double2loint(one), __double2loint(a), CTRL, ROW_MASK, 0xf, false);
+  const int ahi = __builtin_amdgcn_update_dpp(__double2hiint(one), __double2hiint(a), CTRL, ROW_MASK, 0xf, false);
+  const int qlo = __builtin_amdgcn_update_dpp(0, __double2loint(q), CTRL, ROW_MASK, 0xf, false);
+  const int qhi = __builtin_amdgcn_update_dpp(0, __double2hiint(q), CTRL, ROW_MASK, 0xf, false);
+  const double as = __hiloint2double(ahi, alo), qs = __hiloint2double(qhi, qlo);
+  q = fma(a, qs, q); // (a, q) o (as, qs) = (a*as, a*qs + q)
+  a = a * as;
+}
+__device__ __forceinline__ void affine_scan(double &a, double &q) {
+  scan_step<0x111, 0xf>(a, q); // row_shr:1,2,4,8: inclusive scan inside each row of 16 lanes
+  scan_step<0x112, 0xf>(a, q);
+  scan_step<0x114, 0xf>(a, q);
+  scan_step<0x118, 0xf>(a, q);
+  scan_step<0x142, 0xa>(a, q); // row_bcast:15 -> rows 1 and 3
+  scan_step<0x143, 0xc>(a, q); // row_bcast:31 -> rows 2 and 3
+}
+
+constexpr int kTailMax = 2;
+
+// One Gauss-Seidel pass over the tail rows; returns the lane's max |delta|.
+// tE: [T][NR+2] current values (column c at [1 + c]); r63: new values of row 63 by column.
+template <int NR>
+__device__ __forceinline__ double tail_pass(int T, int lane, const double *tab, double *tE, const double *r63,
+                                            const double (&At)[kTailMax][2], unsigned tclsw) {
+  constexpr int kBlk = (NR + 63) / 64, kRow = NR + 2;
+  double dmax = 0.0;
+#pragma unroll
+  for (int t = 0; t < kTailMax; ++t) {
+    if (t < T) {
+      double carry = 0.0;
+#pragma unroll
+      for (int blk = 0; blk < kBlk; ++blk) {
+        const int c = blk * 64 + lane;
+        const bool in = c < NR;
+        const int cc = in ? c : NR - 1;
+        const int cls = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
+        const double *bt = tab + cls;
+        const double bU = bt[0], bD = bt[kTS], bL = bt[2 * kTS], bR = bt[3 * kTS];
+        double *row = tE + t * kRow + 1;
+        const double U = t == 0 ? r63[cc] : row[cc - kRow];
+        const double Dn = t + 1 < T ? row[cc + kRow] : 0.0;
+        const double Rn = row[cc + 1], old = row[cc];
+        double q = fma(bU, U, fma(bR, Rn, fma(bD, Dn, At[t][blk])));
+        double aa = bL;
+        affine_scan(aa, q);
+        const double xv = fma(aa, carry, q);
+        __builtin_amdgcn_wave_barrier();
+        if (in) {
+          dmax = fmax(dmax, fabs(xv - old));
+          row[cc] = xv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xv), 63),
+                                 __builtin_amdgcn_readlane(__double2loint(xv), 63));
+      }
+    }
+  }
+  return dmax;
+}
+
+extern __shared__ __attribute__((aligned(16))) double lds[];
+
+template <int NR, int P>
+__global__ void __launch_bounds__(P == kPair ? 128 : 64)
+    __attribute__((amdgpu_waves_per_eu(P == kPair ? 2 : 1, P == kPair ? 2 : 1))) k_sweep_reg(Dev a) {
+  const int lane = threadIdx.x & 63;
+  const int w = P == kPair ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  constexpr int kASlots = (NR + 7) / 8, kZSlots = (NR + 3) / 4, kMaxCh = (NR + 63 + 7) / 8;
+
+  double *tab = lds;                       // [5][kTS]: bU bD bL bR ap
+  double *gtab = lds + 5 * kTS;            // [kTS]
+  double *seamD = lds + a.r_seam;          // [pad | NR | pad] old values of wave 1's first row
+  double *seamU = seamD + NR + 2 * kSeamPad; // new values of wave 0's last row
+  // mode kTail uses the same region as [pad | r63: NR | pad][tE: T x (NR + 2)]
+  double *r63 = seamD + kSeamPad;          // new values of row 63, by column
+  double *tE = seamD + NR + 2 * kSeamPad;  // tail rows, column c at [t*(NR+2) + 1 + c]
+  double *A = lds + a.r_A;                 // [RS][AS >= NR]; after the sweeps: zone sums [Z+1][RS]
+  double *xchg = lds + a.r_xchg;           // [0..3] max delta (2 sweeps x 2 waves), [4..5] grid sums, [6] progress counter
+  // every byte of LDS starts finite: seam / A reads next to the arrays' ends are multiplied by 0
+  for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 5 * kTS; i += blockDim.x) {
+    const int j = i / kTS, c = i - j * kTS;
+    tab[i] = c <= a.ncls ? a.ctab[c * 8 + j] : 0.0; // row `ncls` is the pad class: T' = Tprev (ap = 1)
+  }
+  __syncthreads();
+
+  const sb_params &p = a.p;
+  const int lw = a.lw[w], l0 = a.l0[w], rowbase = a.rowbase[w];
+  const int lp = lane - l0;
+  const bool rowvalid = lp >= 0 && lp < lw;
+  const int R = rowbase + (rowvalid ? lp : 0);
+  const int RS = a.RS;
+  SweepCtx x;
+  x.tab = tab;
+  x.Arow = A + (size_t)R * a.AS; // odd row stride: the 64 lanes of a ds_read_b64 cover all 32 banks
+  x.cmap = a.cmapS + (size_t)w * (kMaxCh + 3) * 64 + lane;
+  x.rowmask = __builtin_amdgcn_ballot_w64(rowvalid);
+  x.lane = lane; x.lp = rowvalid ? lp : (int)0x80000000; x.nch = a.nch[w];
+  x.edge_off = (P == kPair && w == 0) ? lw - 1 : (P == kTail ? 63 : 0);
+  x.edge = (P == kPair && lane == (w == 0 ? 63 : 0)) || (P == kTail && lane == 63);
+  x.seam_in = (P == kTail ? tE + 1 : (w == 0 ? seamD : seamU) + kSeamPad) - x.edge_off;
+  x.seam_in2 = x.seam_in + opaque(0);
+  x.seam_out = (P == kTail ? r63 : (w == 0 ? seamU : seamD) + kSeamPad) - x.edge_off;
+  unsigned tclsw = 0; // mode kTail: classes of the lane's tail cells, byte [t*2 + block]
+  if (P == kTail)
+    for (int t = 0; t < a.T; ++t)
+      for (int blk = 0; blk < (NR + 63) / 64; ++blk)
+        tclsw |= (unsigned)a.tcls[t * NR + min(blk * 64 + lane, NR - 1)] << (8 * (t * 2 + blk));
+  x.prog = (volatile int *)(xchg + 6);
+  x.role = w; x.lag = a.lag; x.nch0 = a.nch[0]; x.prog_base = 0;
+  const unsigned long long *amap = a.amapS + (size_t)w * kASlots * 64 + lane;
+  const unsigned long long *zmap = a.zmapS + (size_t)w * kZSlots * 64 + lane;
+
+#define SB_STAMP(i) do { if (a.dbg && b == 0 && w == 0 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+  // The lane's row of the NEXT building is loaded while this building's zone sums are reduced
+  // (its registers are free once the row is stored), so the loop never waits on HBM latency.
+  double e[NR];
+#define SB_LOAD_ROW(bb)                                                                         \
+  do {                                                                                          \
+    const double *tp_ = a.temp + (size_t)(bb) * a.state_doubles + R;                            \
+    _Pragma("unroll") for (int j = 0; j < NR; ++j) { /* pad lanes mirror a real row: never updated, never stored */ \
+      e[j] = *tp_;                                                                              \
+      tp_ += opaque(RS);                                                                        \
+    }                                                                                           \
+  } while (0)
+  if ((int)blockIdx.x < a.B) SB_LOAD_ROW(blockIdx.x);
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    SB_STAMP(0);
+    double *T = a.temp + (size_t)b * a.state_doubles + R;
+    double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 64; // mode kTail: [T][NR]
+    __builtin_amdgcn_sched_barrier(0);
+    const double t_now = a.bld[b].t_now;
+    // exterior-space cells outside the trim box all become t_now in the first sweep
+    // (simulator.py:256-258); their largest |delta| follows from their extreme values
+    const double *S = a.scal + (size_t)b * kNScal;
+    const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - S[16]), fabs(t_now - S[17])) : 0.0;
+    if (w == 0) {
+      if (P == kPair && lane == 0) *x.prog = 0;
+      if (lane < kTS) gtab[lane] = a.gtabg[(size_t)b * kTS + lane];
+      if (P == kPair) // old values of wave 1's first row (its lane 0: column c sits in slot c)
+        for (int c = lane; c < NR; c += 64)
+          seamD[kSeamPad + c] = a.temp[(size_t)b * a.state_doubles + (size_t)c * RS + a.rowbase[1]];
+      if (P == kTail)
+        for (int t = 0; t < a.T; ++t)
+          for (int c = lane; c < NR; c += 64) tE[t * (NR + 2) + 1 + c] = Ttail[t * NR + c];
+    }
+    if (P == kPair) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(1);
+    double At[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // mode kTail: A of the lane's tail cells
+    if (P == kTail) {
+#pragma unroll
+      for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+        for (int blk = 0; blk < (NR + 63) / 64; ++blk)
+          if (t < a.T) {
+            const int cls = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
+            const double tp = tE[t * (NR + 2) + 1 + min(blk * 64 + lane, NR - 1)];
+            At[t][blk] = fma(tab[4 * kTS + cls], tp, gtab[cls]);
+          }
+    }
+
+    // A = ap*Tprev + g for every cell of the lane's row (E = Tprev before the first sweep)
+    if (rowvalid) {
+      unsigned long long cw[kASlots]; // all class words first: one memory latency, not kASlots
+      {
+        const int o = opaque(0);
+#pragma unroll
+        for (int g = 0; g < kASlots; ++g) cw[g] = amap[o + g * 64];
+      }
+      double *Aw = A + (size_t)R * a.AS;
+      // groups of 8: all table reads of a group are issued before its first A write (the
+      // compiler cannot prove that A and the tables do not alias and would serialise them)
+#pragma unroll
+      for (int j0 = 0; j0 < NR; j0 += 8) {
+        double ap[8], gg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (j0 + k < NR) {
+            const int c = (int)((cw[(j0 + k) >> 3] >> (8 * ((j0 + k) & 7))) & 0xffull);
+            ap[k] = tab[4 * kTS + c];
+            gg[k] = gtab[c];
+          }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (j0 + k < NR) Aw[j0 + k] = fma(ap[k], e[j0 + k], gg[k]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(2);
+
+    int n_sweeps = 0, converged = 0;
+#pragma nounroll
+    for (int it = 0; it < p.iter_limit; ++it) { // simulator.py:348-368
+      x.prog_base = it * 32; // the counter only grows within a building's step
+      double dm = sweep_reg<NR, P>(e, x);
+#if !(defined(SB_EXP) && (SB_EXP & 1)) /* timing experiment 1: no tail pass */
+      if (P == kTail) {
+        __builtin_amdgcn_wave_barrier(); // row 63's last values are in LDS before the scan reads them
+        dm = fmax(dm, tail_pass<NR>(a.T, lane, tab, tE, r63, At, tclsw));
+      }
+#endif
+      double md = wave_max(dm);
+      if (P == kPair) {
+        double *xd = xchg + 2 * (it & 1); // double-buffered: wave 0 may finish its next sweep early
+        if (lane == 0) xd[w] = md;
+        __syncthreads();
+        md = fmax(xd[0], xd[1]);
+      }
+      if (it == 0) md = fmax(md, ring_d);
+      ++n_sweeps;
+      if (md <= p.conv_threshold) { converged = 1; break; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(3);
+
+    // grid back to HBM; the wave's share of the grid sum
+    // zone sums: every lane adds its cells into its own column of zs[zone][row] (A is dead)
+    double gpart = 0.0;
+    double *zs = A;
+    if (rowvalid) {
+      double *tp = T;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        *tp = e[j];
+        tp += opaque(RS);
+        gpart += e[j];
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (P == kTail) // the tail rows hold no zone cells (sb_create checks); they count in the grid sum
+        for (int t = 0; t < a.T; ++t)
+          for (int c = lane; c < NR; c += 64) {
+            const double tv = tE[t * (NR + 2) + 1 + c];
+            Ttail[t * NR + c] = tv;
+            gpart += tv;
+          }
+      for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * RS + R] = 0.0;
+      unsigned long long zwv[kZSlots];
+      {
+        const int o = opaque(0);
+#pragma unroll
+        for (int g = 0; g < kZSlots; ++g) zwv[g] = zmap[o + g * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const unsigned off = (unsigned)((zwv[j >> 2] >> (16 * (j & 3))) & 0xffffull);
+        __hip_atomic_fetch_add((double *)((char *)zs + off), e[j], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (b + (int)gridDim.x < a.B) SB_LOAD_ROW(b + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    gpart = wave_sum(gpart);
+    if (lane == 0) xchg[4 + w] = gpart;
+    if (P == kPair) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    SB_STAMP(4);
+
+    if (w == 0) { // hand the zone sums, the grid sum and the sweep count to k_post
+      for (int z = 0; z < a.Z; ++z) {
+        double part = 0.0;
+        for (int r = lane; r < RS; r += 64) part += zs[(size_t)z * RS + r];
+        part = wave_sum(part);
+        if (lane == 0) a.zsum[(size_t)b * a.Z + z] = part;
+      }
+      if (lane == 0) {
+        double gsum = xchg[4];
+        if (P == kPair) gsum += xchg[5];
+        a.gsum[b] = gsum + (double)a.n_ring * t_now;
+        a.nsw[b] = n_sweeps | (converged << 16);
+      }
+      SB_STAMP(8);
+      if (a.dbg && b == 0 && lane == 0) a.dbg[9] = n_sweeps;
+    }
+    // no barrier here: wave 1 touches no LDS of the next building before the barrier that
+    // follows wave 0's g-table load
+  }
+#undef SB_STAMP
+#undef SB_LOAD_ROW
+}
+
+struct Variant {
+  int NR, P;
+  const void *fn;
+  void (*launch)(const Dev &, int, hipStream_t);
+};
+
+template <int NR, int P>
+void launch_variant(const Dev &d, int workgroups, hipStream_t stream) {
+  hipLaunchKernelGGL((k_sweep_reg<NR, P>), dim3(workgroups), dim3(P == kPair ? 128 : 64),
+                     (size_t)d.lds_reg_bytes, stream, d);
+}
+
+#define SB_VARIANT(NR, P) {NR, P, (const void *)k_sweep_reg<NR, P>, launch_variant<NR, P>}
+const Variant kVariants[] = {SB_VARIANT(32, 1), SB_VARIANT(66, 1), SB_VARIANT(66, 2), SB_VARIANT(96, 1),
+                            SB_VARIANT(96, 3)};
+#undef SB_VARIANT
+
+const Variant *find_variant(int NR, int P) {
+  for (const Variant &v : kVariants)
+    if (v.NR == NR && v.P == P) return &v;
+  return nullptr;
+}
+
+} // namespace
+
+bool sweep_reg_supported(int NR, int P) { return find_variant(NR, P) != nullptr; }
+
+int prepare_sweep_reg(const Dev &d) {
+  const Variant *v = find_variant(d.NR, d.P);
+  if (!v) return (int)hipErrorInvalidValue;
+  return (int)hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_reg_bytes);
+}
+
+int launch_sweep_reg(const Dev &d, int cus, hipStream_t stream) {
+  const Variant *v = find_variant(d.NR, d.P);
+  if (!v) return (int)hipErrorInvalidValue;
+  const int wgs = std::max(1, std::min(d.B, cus * d.wg_per_cu));
+  v->launch(d, wgs, stream);
+  return (int)hipGetLastError();
+}
+
+} // namespace sb

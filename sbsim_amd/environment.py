@@ -206,20 +206,40 @@ class BatchedSimulator:
       raise _ffi.SbsimError("sbsim_amd needs a HIP device (MI355X); there is no CPU path")
     self.plan, self.config, self.B, self.device = plan, config, int(n_buildings), int(device)
     H0, W0 = plan.shape
-    # device-side orientation: whichever needs fewer wavefront steps per sweep (internal to the
-    # library; reset()/temps() convert, so callers always see the reference's [H, W] layout)
     if orientation not in ("auto", "rows", "columns"):
       raise ValueError("orientation must be 'auto', 'rows' or 'columns'")
-    self.transposed = (orientation == "columns" or
-                       (orientation == "auto" and FloorPlan.sweep_steps(W0, H0) < FloorPlan.sweep_steps(H0, W0)))
-    dev_plan = plan.transposed() if self.transposed else plan
-    self.compiled: CompiledPlan = dev_plan.compile(config.time_step_sec, h_conv)
-    cp = self.compiled
-    self.Z, self.H, self.W = cp.Z, H0, W0
-    zone_names = list(zone_names or plan.zone_names or [f"room_{i + 1}" for i in range(cp.Z)])
+    self.Z, self.H, self.W = plan.n_zones, H0, W0
+    zone_names = list(zone_names or plan.zone_names or [f"room_{i + 1}" for i in range(self.Z)])
     (self.field_names, col_ahu, col_blr, col_zone, col_aux) = observation_field_names(
         zone_names, config.ahu_has_weather_sensor)
     self.O = len(self.field_names)
+
+    def describe(p: FloorPlan):
+      cp = p.compile(config.time_step_sec, h_conv)
+      keep = dict(cls=np.ascontiguousarray(cp.cell_class), coef=np.ascontiguousarray(cp.class_coef),
+                  czone=np.ascontiguousarray(cp.class_zone), zoff=np.ascontiguousarray(cp.zone_off),
+                  zcells=np.ascontiguousarray(cp.zone_cells))
+      desc = _ffi.PlanDesc(cp.H, cp.W, cp.Z, cp.n_classes,
+                           keep["cls"].ctypes.data_as(C.POINTER(C.c_uint8)),
+                           keep["coef"].ctypes.data_as(_ffi._dp), keep["czone"].ctypes.data_as(_ffi._ip),
+                           keep["zoff"].ctypes.data_as(_ffi._ip), keep["zcells"].ctypes.data_as(_ffi._ip))
+      info = _ffi.LaunchInfo()
+      rc = self._lib.sb_plan_info(C.byref(desc), self.O, self.B, C.byref(info))
+      return cp, keep, desc, (rc, info)
+
+    # device-side orientation (internal to the library; reset()/temps() convert, so callers
+    # always see the reference's [H, W] layout): the library reports, per orientation, which
+    # step kernel it would use and how many wavefront steps one sweep takes
+    cands = {"rows": [False], "columns": [True], "auto": [False, True]}[orientation]
+    best = None
+    for tr in cands:
+      cand = describe(plan.transposed() if tr else plan)
+      rc, info = cand[3]
+      key = (rc != 0, -info.path if rc == 0 else 0, info.sweep_steps if rc == 0 else 0)
+      if best is None or key < best[0]:
+        best = (key, tr, cand)
+    self.transposed = best[1]
+    self.compiled, keep, pd_, _ = best[2]
     norm = dict(observation_normalization or {})
     mean = np.zeros(self.O)
     sigma = np.ones(self.O)
@@ -229,17 +249,8 @@ class BatchedSimulator:
       mu, var = float(np.float32(mu)), float(np.float32(var))
       mean[i] = mu
       sigma[i] = math.sqrt(var) if var > 0.0 else 0.0
-    self._keep = dict(
-        cls=np.ascontiguousarray(cp.cell_class), coef=np.ascontiguousarray(cp.class_coef),
-        czone=np.ascontiguousarray(cp.class_zone), zoff=np.ascontiguousarray(cp.zone_off),
-        zcells=np.ascontiguousarray(cp.zone_cells), colz=np.asarray(col_zone, dtype=np.int32),
-        mean=mean, sigma=sigma)
-    k = self._keep
-    pd_ = _ffi.PlanDesc(cp.H, cp.W, cp.Z, cp.n_classes,
-                        k["cls"].ctypes.data_as(C.POINTER(C.c_uint8)),
-                        k["coef"].ctypes.data_as(_ffi._dp), k["czone"].ctypes.data_as(_ffi._ip),
-                        k["zoff"].ctypes.data_as(_ffi._ip), k["zcells"].ctypes.data_as(_ffi._ip))
-    ol = _ffi.ObsLayout(self.O, col_ahu, col_blr, col_aux, k["colz"].ctypes.data_as(_ffi._ip),
+    self._keep = dict(keep, colz=np.asarray(col_zone, dtype=np.int32), mean=mean, sigma=sigma)
+    ol = _ffi.ObsLayout(self.O, col_ahu, col_blr, col_aux, self._keep["colz"].ctypes.data_as(_ffi._ip),
                         mean.ctypes.data_as(_ffi._dp), sigma.ctypes.data_as(_ffi._dp))
     params = config.to_params()
     h = C.c_void_p()
@@ -286,16 +297,19 @@ class BatchedSimulator:
     return out
 
   def step(self, actions: Optional[torch.Tensor], step_in: _ffi.StepIn, obs: torch.Tensor,
-           reward: torch.Tensor, info: Optional[torch.Tensor] = None) -> None:
+           reward: torch.Tensor, info: Optional[torch.Tensor] = None, phases: int = 7) -> None:
+    """One Environment._step for every building (sb_step).  `phases` selects a subset of its
+    three launches (1 = device algebra before the sweep, 2 = sweep kernel, 4 = reward /
+    observation) -- a measurement aid; a step is complete once all three ran in order."""
     if actions is not None:
       if actions.dtype != torch.float32 or tuple(actions.shape) != (self.B, _ffi.SB_NUM_ACTIONS):
         raise ValueError(f"actions must be float32 [{self.B}, {_ffi.SB_NUM_ACTIONS}]")
       if not actions.is_contiguous():
         actions = actions.contiguous()
-    _ffi.check(self._lib.sb_step(
+    _ffi.check(self._lib.sb_step_phases(
         self._h, C.c_void_p(actions.data_ptr()) if actions is not None else None, C.byref(step_in),
         C.c_void_p(obs.data_ptr()) if obs is not None else None, C.c_void_p(reward.data_ptr()),
-        C.c_void_p(info.data_ptr()) if info is not None else None, self._stream()), "sb_step")
+        C.c_void_p(info.data_ptr()) if info is not None else None, self._stream(), int(phases)), "sb_step")
 
   # ---- parity taps ----
   def _get(self, fn, shape, dtype):

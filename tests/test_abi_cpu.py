@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
   assert set(names) == set(_ffi.EXPORTS), (names, _ffi.EXPORTS)
   for n in names:
     assert hasattr(lib, n), n
-  assert _ffi.load().sb_abi_version() == 1
+  assert _ffi.load().sb_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -44,6 +44,38 @@ def test_struct_layouts_match_header():
     sizes = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
   assert sizes == [C.sizeof(_ffi.PlanDesc), C.sizeof(_ffi.Params), C.sizeof(_ffi.ObsLayout),
                    C.sizeof(_ffi.StepIn), C.sizeof(_ffi.LaunchInfo)]
+
+
+def _plan_info(fp, n_obs=46, n_buildings=1024):
+  import numpy as np
+  cp = fp.compile(300.0, 12.0)
+  keep = [np.ascontiguousarray(x) for x in (cp.cell_class, cp.class_coef, cp.class_zone, cp.zone_off, cp.zone_cells)]
+  desc = _ffi.PlanDesc(cp.H, cp.W, cp.Z, cp.n_classes, keep[0].ctypes.data_as(C.POINTER(C.c_uint8)),
+                       keep[1].ctypes.data_as(_ffi._dp), keep[2].ctypes.data_as(_ffi._ip),
+                       keep[3].ctypes.data_as(_ffi._ip), keep[4].ctypes.data_as(_ffi._ip))
+  info = _ffi.LaunchInfo()
+  rc = _ffi.load().sb_plan_info(C.byref(desc), n_obs, n_buildings, C.byref(info))
+  return rc, {f[0]: getattr(info, f[0]) for f in _ffi.LaunchInfo._fields_}
+
+
+def test_plan_info_picks_the_step_kernel_without_a_gpu():
+  """Host-only launch planning (sb_plan_info): R9 (68x98, 66x96 inside the exterior ring) runs
+  on the register path either way -- lanes = rows: one wavefront owns rows 0..63 and the two
+  remaining wall rows are finished by a scan; lanes = columns: two wavefronts per building --
+  and three buildings fit a CU's LDS; a small plan uses one wavefront per building."""
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  r9 = FloorPlan.from_file_input(rectangular_floor_plan((3, 3), (20, 30)), Materials.sb1(), 10.0, 300.0)
+  rc, rows = _plan_info(r9)
+  assert rc == 0 and rows["path"] == 1 and rows["waves_per_building"] == 1
+  assert 3 * ((rows["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
+  rc, cols = _plan_info(r9.transposed())
+  assert rc == 0 and cols["path"] == 1 and cols["waves_per_building"] == 2
+  assert rows["sweep_steps"] < cols["sweep_steps"]
+  assert 3 * ((cols["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024   # three buildings per CU
+  assert cols["algorithmic_bytes_per_env_step"] == 53764
+  small = FloorPlan.from_file_input(rectangular_floor_plan((1, 2), (6, 8)), Materials.sb1(), 10.0, 300.0)
+  rc, one = _plan_info(small)
+  assert rc == 0 and one["path"] == 1 and one["waves_per_building"] == 1
 
 
 def test_no_cpu_fallback_without_gpu():

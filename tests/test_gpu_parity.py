@@ -53,17 +53,26 @@ def _step_in(g, t, has_action=True, occupancy=None):
   return si
 
 
-@pytest.mark.parametrize("tag", ["random", "const"])
-def test_one_day_rollout_against_reference_golden(tag):
+@pytest.mark.parametrize("tag,kernel", [("random", "reg"), ("const", "reg-pair"), ("const", "lds"),
+                                        ("random", "lds-columns")])
+def test_one_day_rollout_against_reference_golden(tag, kernel, monkeypatch):
   """BASELINE.json configs[0] semantics on the GPU: SB1 physics on R9, 288 steps."""
   _need_gpu()
   g = load(f"h2_sb1_r9_{tag}.npz")
   B = 5
-  # "random" runs in the library's preferred orientation (columns as lanes for R9), "const" forces
-  # rows as lanes (two bands + seam): both wavefront schedules are checked against the reference
+  # "reg": the library's own choice for R9 -- rows as lanes, grid in registers, one wavefront
+  # owns rows 0..63 and the last two (wall) rows are finished by a scan; "reg-pair": columns as
+  # lanes, two wavefronts per building exchanging their seam rows through LDS; "lds": rows as
+  # lanes on the LDS-grid kernel (two bands + seam); "lds-columns": the LDS-grid kernel on the
+  # transposed grid.  All four wavefront schedules are checked against the reference.
+  if kernel.startswith("lds"):
+    monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
   sim = BatchedSimulator(_plan(load("plan_r9_sb1.npz")), SimConfig.sb1(), B, float(g["h_conv"]),
-                         orientation="auto" if tag == "random" else "rows")
-  assert sim.transposed == (tag == "random")
+                         orientation={"reg": "auto", "reg-pair": "columns", "lds": "rows",
+                                      "lds-columns": "columns"}[kernel])
+  assert sim.transposed == (kernel in ("reg-pair", "lds-columns"))
+  assert sim.launch_info["path"] == (1 if kernel.startswith("reg") else 0)
+  assert sim.launch_info["waves_per_building"] == (2 if kernel == "reg-pair" else 1)
   sim.reset()
   obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
   rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
@@ -226,7 +235,7 @@ def test_environment_api_episode_bookkeeping():
 def test_abi_error_paths():
   _need_gpu()
   L = _ffi.load()
-  assert L.sb_abi_version() == 1
+  assert L.sb_abi_version() == 2
   h = C.c_void_p()
   assert L.sb_create(None, None, None, 1, 0, C.byref(h)) == -1
   assert b"null" in L.sb_last_error()
@@ -256,13 +265,18 @@ def _oracle_twin(plan, cfg, init_flat):
   return orc.OracleBuilding(oplan, oprm, 0.0, reset_temps=init_flat)
 
 
-@pytest.mark.parametrize("rooms,room_shape,orientation", [
-    ((8, 5), (12, 14), "auto"),     # "SB2-synth": 40 zones, 109x81 grid, 2 bands either way
-    ((14, 9), (8, 7), "auto"),      # "SB1-synth": 126 zones (the real SB1's VAV count), 131x78 grid, 3 bands
-    ((2, 3), (9, 10), "rows"),      # small: single band, W < 64
-    ((5, 1), (12, 10), "generic"),  # H > 64, narrow grid, forced onto the generic (all-LDS) sweep
+@pytest.mark.parametrize("rooms,room_shape,orientation,path", [
+    ((8, 5), (12, 14), "auto", 0),     # "SB2-synth": 40 zones, 109x81 grid, 2 bands either way (LDS grid)
+    ((14, 9), (8, 7), "auto", 0),      # "SB1-synth": 126 zones (the real SB1's VAV count), 131x78 grid, 3 bands
+    ((2, 3), (9, 10), "rows", 1),      # small: 22x34 inside the ring -> registers, 1 wave, 66 slots
+    ((5, 1), (12, 10), "generic", 0),  # H > 64, narrow grid, forced onto the generic (all-LDS) sweep
+    ((2, 2), (5, 9), "rows", 1),       # 15x23 inside the ring -> registers, 1 wave, 32 slots
+    ((2, 3), (20, 30), "rows", 1),     # 45x96 -> registers, 1 wave, 96 slots
+    ((2, 5), (30, 12), "columns", 1),  # transposed 68x65 -> registers, 2 waves (uneven split), 66 slots
+    ((2, 3), (30, 30), "rows", 1),     # 65x96 -> registers, 1 wave + ONE tail row
+    ((4, 2), (30, 17), "columns", 0),  # the same family on the LDS-grid kernel, lanes = columns
 ])
-def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, monkeypatch):
+def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, monkeypatch):
   """BASELINE.json configs[2] semantics: other floor-plan classes (different H x W and zone
   counts) through the same C ABI, each checked against its CPU-oracle twin."""
   _need_gpu()
@@ -278,8 +292,10 @@ def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, monkey
   if orientation == "generic":
     monkeypatch.setenv("SBSIM_FORCE_GENERIC_SWEEP", "1")
     orientation = "rows"
+  if path == 0:
+    monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
   sim = BatchedSimulator(plan, cfg, B, float(g["h_conv"]), orientation=orientation)
-  assert sim.Z == rooms[0] * rooms[1]
+  assert sim.Z == rooms[0] * rooms[1] and sim.launch_info["path"] == path
   sim.reset(temps=torch.tensor(init, dtype=torch.float64, device="cuda"))
   twins = [_oracle_twin(plan, cfg, init[b]) for b in range(B)]
   obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
