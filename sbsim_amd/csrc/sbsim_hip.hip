@@ -307,9 +307,9 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
   r.cmapS.assign((size_t)nw * (maxch + 3) * 64, 0);
   r.amapS.assign((size_t)nw * aslots * 64, 0);
   r.zmapS.assign((size_t)nw * zslots * 64, 0);
-  r.tcls.assign((size_t)std::max(r.T, 1) * NR, (uint8_t)pad);
+  r.tcls.assign((size_t)std::max(r.T, 1) * NR, (uint8_t)(8 * pad));
   for (int t = 0; t < r.T; ++t)
-    for (int c = 0; c < NR; ++c) r.tcls[(size_t)t * NR + c] = (uint8_t)cell_class(64 + t, c);
+    for (int c = 0; c < NR; ++c) r.tcls[(size_t)t * NR + c] = (uint8_t)(8 * cell_class(64 + t, c));
   for (int w = 0; w < nw; ++w)
     for (int lane = 0; lane < 64; ++lane) {
       const int lp = lane - r.l0[w];
@@ -320,7 +320,7 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
         for (int k = 0; k < 8; ++k) {
           const int col = 8 * ch + k - lp;
           const int c = valid ? cell_class(R, col) : pad;
-          word |= (unsigned long long)c << (8 * k);
+          word |= (unsigned long long)(c * 8) << (8 * k); // class * 8: byte offset into a table column
         }
         r.cmapS[((size_t)w * (maxch + 3) + ch) * 64 + lane] = word;
       }
@@ -330,7 +330,7 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
           const int j = 8 * g + k;
           const int col = ((j - lp) % NR + NR) % NR;
           const int c = (valid && j < NR) ? cell_class(R, col) : pad;
-          word |= (unsigned long long)c << (8 * k);
+          word |= (unsigned long long)(c * 8) << (8 * k);
         }
         r.amapS[((size_t)w * aslots + g) * 64 + lane] = word;
       }

@@ -34,7 +34,10 @@ namespace {
 // 2 = two wavefronts per building (<= 128 rows); 3 = one wavefront owns rows 0..63 and the
 // last one or two rows ("tail") are finished after the wavefront's pass by a parallel scan.
 constexpr int kPair = 2, kTail = 3;
-constexpr int kLook = 2;   // steps between the LDS reads of a step and its arithmetic
+#ifndef SB_LOOK
+#define SB_LOOK 2
+#endif
+constexpr int kLook = SB_LOOK; // steps between the LDS reads of a step and its arithmetic
 constexpr int kTS = 32;    // coefficient-table stride (classes + the pad class <= 32)
 constexpr int kSeamPad = 8;
 
@@ -73,8 +76,8 @@ template <int NR, int P, int PD>
 __device__ __forceinline__ void prefetch(Pipe &p, const double *tab, const double *Arow,
                                          const double *seam_in, const double *seam_in2) {
   const unsigned long long cw = p.cw[(PD / 8) % 3];
-  const int c = (int)((cw >> (8 * (PD % 8))) & 0xffull);
-  const double *bt = tab + c;
+  const int c8 = (int)((cw >> (8 * (PD % 8))) & 0xffull); // class * 8: the byte offset into a table column
+  const double *bt = (const double *)((const char *)tab + c8);
   Co &o = p.co[PD % (kLook + 1)];
   o.bU = bt[0]; o.bD = bt[kTS]; o.bL = bt[2 * kTS]; o.bR = bt[3 * kTS];
   o.A = Arow[PD % NR];
@@ -105,7 +108,8 @@ __device__ __forceinline__ void update(double (&e)[NR], const Co &o, int lp, uns
   else if (need_hi) act = (unsigned)lp <= (unsigned)D;
   else if (need_lo) act = lp > D - NR;
   else act = __builtin_amdgcn_inverse_ballot_w64(rowmask);
-  const double sel = act ? nv : e[r];
+  // mode kTail: all 64 lanes own a row, so the middle steps need no select at all
+  const double sel = (P == kTail && !need_hi && !need_lo) ? nv : (act ? nv : e[r]);
   dmax = fmax(dmax, fabs(sel - e[r]));
   e[r] = sel;
 }
@@ -161,7 +165,7 @@ __device__ __forceinline__ void chunks(double (&e)[NR], Pipe &p, const SweepCtx 
       if (P == kPair && x.role == 1) wait_progress(x.prog, x.prog_base + min(CI + x.lag, x.nch0), seen);
       p.cw[(CI + 2) % 3] = x.cmap[opaque(0) + (CI + 2) * 64];
       chunk_steps<NR, P, CI, 0>(e, p, x, dmax);
-      if (P == kPair || P == kTail) {
+      if (P == kPair) {
         // publish the edge row's new values of this chunk (columns 8*CI-edge_off .. +7)
         const int c0 = 8 * CI - x.edge_off;
 #if !(defined(SB_EXP) && (SB_EXP & 2)) /* timing experiment 2: no seam publication */
@@ -183,9 +187,13 @@ __device__ __forceinline__ void chunks(double (&e)[NR], Pipe &p, const SweepCtx 
 }
 
 template <int NR, int P>
-__device__ __forceinline__ double sweep_reg(double (&e)[NR], const SweepCtx &x) {
+__device__ __forceinline__ double sweep_reg(double (&e)[NR], const SweepCtx &xin) {
   double dmax = 0.0;
   int seen = 0;
+  // the per-step lane predicates are one v_cmp each; hoisted out of the sweep loop they would
+  // be ~150 SGPR pairs spilled to VGPR lanes (2 v_readlane + wait states per step)
+  SweepCtx x = xin;
+  asm volatile("" : "+v"(x.lp));
   if (P == kPair && x.role == 1) wait_progress(x.prog, x.prog_base + min(x.lag, x.nch0), seen);
   Pipe p;
   p.cw[0] = x.cmap[opaque(0)];
@@ -195,6 +203,10 @@ __device__ __forceinline__ double sweep_reg(double (&e)[NR], const SweepCtx &x) 
   prefetch<NR, P, 1>(p, x.tab, x.Arow, x.seam_in, x.seam_in2);
   __builtin_amdgcn_sched_barrier(0);
   chunks<NR, P, 0>(e, p, x, dmax, seen);
+  if (P == kTail && x.edge) { // row 63's new values for the tail scan: lane 63's registers, column c in slot c + 63
+#pragma unroll
+    for (int c = 0; c < NR; ++c) x.seam_out[c + 63] = e[(c + 63) % NR];
+  }
   return dmax;
 }
 
@@ -242,8 +254,8 @@ __device__ __forceinline__ double tail_pass(int T, int lane, const double *tab, 
         const int c = blk * 64 + lane;
         const bool in = c < NR;
         const int cc = in ? c : NR - 1;
-        const int cls = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
-        const double *bt = tab + cls;
+        const int cls8 = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
+        const double *bt = (const double *)((const char *)tab + cls8);
         const double bU = bt[0], bD = bt[kTS], bL = bt[2 * kTS], bR = bt[3 * kTS];
         double *row = tE + t * kRow + 1;
         const double U = t == 0 ? r63[cc] : row[cc - kRow];
@@ -364,9 +376,10 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
 #pragma unroll
         for (int blk = 0; blk < (NR + 63) / 64; ++blk)
           if (t < a.T) {
-            const int cls = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
+            const int cls8 = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
             const double tp = tE[t * (NR + 2) + 1 + min(blk * 64 + lane, NR - 1)];
-            At[t][blk] = fma(tab[4 * kTS + cls], tp, gtab[cls]);
+            At[t][blk] = fma(*(const double *)((const char *)(tab + 4 * kTS) + cls8), tp,
+                             *(const double *)((const char *)gtab + cls8));
           }
     }
 
@@ -387,9 +400,9 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (j0 + k < NR) {
-            const int c = (int)((cw[(j0 + k) >> 3] >> (8 * ((j0 + k) & 7))) & 0xffull);
-            ap[k] = tab[4 * kTS + c];
-            gg[k] = gtab[c];
+            const int c8 = (int)((cw[(j0 + k) >> 3] >> (8 * ((j0 + k) & 7))) & 0xffull);
+            ap[k] = *(const double *)((const char *)(tab + 4 * kTS) + c8);
+            gg[k] = *(const double *)((const char *)gtab + c8);
           }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -430,6 +443,13 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     double gpart = 0.0;
     double *zs = A;
     if (rowvalid) {
+      unsigned long long zwv[kZSlots]; // zone-sum offsets: loaded while the row is stored
+      {
+        const int o = opaque(0);
+#pragma unroll
+        for (int g = 0; g < kZSlots; ++g) zwv[g] = zmap[o + g * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       double *tp = T;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
@@ -446,12 +466,6 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
             gpart += tv;
           }
       for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * RS + R] = 0.0;
-      unsigned long long zwv[kZSlots];
-      {
-        const int o = opaque(0);
-#pragma unroll
-        for (int g = 0; g < kZSlots; ++g) zwv[g] = zmap[o + g * 64];
-      }
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const unsigned off = (unsigned)((zwv[j >> 2] >> (16 * (j & 3))) & 0xffffull);
@@ -469,11 +483,17 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     SB_STAMP(4);
 
     if (w == 0) { // hand the zone sums, the grid sum and the sweep count to k_post
-      for (int z = 0; z < a.Z; ++z) {
-        double part = 0.0;
-        for (int r = lane; r < RS; r += 64) part += zs[(size_t)z * RS + r];
-        part = wave_sum(part);
-        if (lane == 0) a.zsum[(size_t)b * a.Z + z] = part;
+      for (int z0 = 0; z0 < a.Z; z0 += 4) { // four zones at a time: their LDS reads and DPP chains overlap
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (z0 + k < a.Z)
+            for (int r = lane; r < RS; r += 64) part[k] += zs[(size_t)(z0 + k) * RS + r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[k] = wave_sum(part[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (z0 + k < a.Z && lane == 0) a.zsum[(size_t)b * a.Z + z0 + k] = part[k];
       }
       if (lane == 0) {
         double gsum = xchg[4];
