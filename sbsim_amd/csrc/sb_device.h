@@ -68,7 +68,7 @@ struct Dev {
   int state_doubles;       // doubles of HBM state per building
   const uint8_t *tcls;     // mode 3: [T][NR] classes of the tail cells
   int RS;                  // rows of the trimmed grid = row stride of the HBM state [NR][RS]
-  int AS;                  // row stride of A in LDS (NR | 1 when it fits: bank-conflict free)
+  int AS;                  // row stride of A in LDS (odd when it fits: bank-conflict free)
   int Ws;                  // trimmed width
   int n_ring;              // exterior-space cells outside the trim box (all of class "ambient")
   int lw[2], l0[2], rowbase[2], nch[2]; // per wave: rows, first lane, first row, 8-step chunks
@@ -116,6 +116,7 @@ int prepare_sweep_lds(size_t lds_bytes);
 int launch_sweep_reg(const Dev &d, int cus, hipStream_t stream);
 int prepare_sweep_reg(const Dev &d);         // sets the LDS attribute; fails if (NR, P) is not built
 bool sweep_reg_supported(int NR, int P);     // is there an instantiation for this shape?
+int sweep_reg_lds_slots(int NR, int P);      // slots of A the instantiation keeps in LDS (the rest: registers)
 
 // ---------------------------------------------------------------- wave helpers
 // DPP move of a double; lanes without a source (or outside row_mask) receive 0.

@@ -247,7 +247,10 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
   if (!P) { r.why = "more than 128 rows inside the building"; return; }
   if (!NR) { r.why = "no kernel variant for this width"; return; }
   const int RS = P == 3 ? 64 : Hs;
-  if (Z + 1 > NR || (size_t)(Z + 1) * RS * 8 > 65535) { r.why = "too many zones for the zone-sum scratch"; return; }
+  if (Z + 1 > sweep_reg_lds_slots(NR, P) || (size_t)(Z + 1) * RS * 8 > 65535) {
+    r.why = "too many zones for the zone-sum scratch"; // it aliases A: (Z+1) x RS doubles
+    return;
+  }
   r.NR = NR; r.P = P; r.RS = RS; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
   r.T = P == 3 ? Hs - 64 : 0;
   r.state_doubles = NR * RS + r.T * NR;
@@ -292,10 +295,11 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
     r.lds_bytes = off * 8;
     r.wg_per_cu = std::min(4, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule));
   };
-  layout(NR);
+  const int nl = sweep_reg_lds_slots(NR, P); // slots of A in LDS (the kernel keeps the rest in registers)
+  layout(nl);
   const int plain = r.wg_per_cu;
-  layout(NR | 1);
-  if (r.wg_per_cu < plain) layout(NR);
+  layout(nl | 1);
+  if (r.wg_per_cu < plain) layout(nl);
   if (r.wg_per_cu < 1) { r.why = "one building does not fit in LDS"; return; }
 
   const int pad = ncls;

@@ -34,6 +34,11 @@ namespace {
 // 2 = two wavefronts per building (<= 128 rows); 3 = one wavefront owns rows 0..63 and the
 // last one or two rows ("tail") are finished after the wavefront's pass by a parallel scan.
 constexpr int kPair = 2, kTail = 3;
+
+// Slots of A = ap*Tprev + g kept in LDS; the remaining NR - lds_slots live in registers
+// (AGPRs).  R9 in mode kTail: 71 of 96 slots in LDS makes a building fit a quarter of a CU's
+// LDS, so all four SIMDs own a building instead of three.
+constexpr int lds_slots(int NR, int P) { return (NR == 96 && P == kTail) ? 71 : NR; }
 #ifndef SB_LOOK
 #define SB_LOOK 2
 #endif
@@ -72,15 +77,18 @@ __device__ __forceinline__ double wave_shift1(double x, double old) {
 }
 
 // LDS reads of step PD (issued kLook steps early): coefficients by class, A, seam value.
-template <int NR, int P, int PD>
+template <int NR, int P, int PD, int NAR>
 __device__ __forceinline__ void prefetch(Pipe &p, const double *tab, const double *Arow,
-                                         const double *seam_in, const double *seam_in2) {
+                                         const double (&Areg)[NAR], const double *seam_in,
+                                         const double *seam_in2) {
   const unsigned long long cw = p.cw[(PD / 8) % 3];
   const int c8 = (int)((cw >> (8 * (PD % 8))) & 0xffull); // class * 8: the byte offset into a table column
   const double *bt = (const double *)((const char *)tab + c8);
   Co &o = p.co[PD % (kLook + 1)];
   o.bU = bt[0]; o.bD = bt[kTS]; o.bL = bt[2 * kTS]; o.bR = bt[3 * kTS];
-  o.A = Arow[PD % NR];
+  constexpr int NL = lds_slots(NR, P);
+  if constexpr ((PD % NR) < NL) o.A = Arow[PD % NR];
+  else o.A = Areg[(PD % NR) - NL];
   if (P == kPair) { // two reads of the same value: each DPP consumes its `old` register
     o.smU = seam_in[PD];
     o.smD = seam_in2[PD];
@@ -127,14 +135,15 @@ struct SweepCtx {
   int role, lag, nch0, prog_base;
 };
 
-template <int NR, int P, int CI, int K>
-__device__ __forceinline__ void chunk_steps(double (&e)[NR], Pipe &p, const SweepCtx &x, double &dmax) {
+template <int NR, int P, int CI, int K, int NAR>
+__device__ __forceinline__ void chunk_steps(double (&e)[NR], const double (&Areg)[NAR], Pipe &p,
+                                            const SweepCtx &x, double &dmax) {
   if constexpr (K < 8 && 8 * CI + K < NR + 63) {
     constexpr int D = 8 * CI + K;
-    prefetch<NR, P, D + kLook>(p, x.tab, x.Arow, x.seam_in, x.seam_in2);
+    prefetch<NR, P, D + kLook>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
     update<NR, P, D>(e, p.co[D % (kLook + 1)], x.lp, x.rowmask, dmax);
     __builtin_amdgcn_sched_barrier(0);
-    chunk_steps<NR, P, CI, K + 1>(e, p, x, dmax);
+    chunk_steps<NR, P, CI, K + 1>(e, Areg, p, x, dmax);
   }
 }
 
@@ -157,14 +166,15 @@ __device__ __forceinline__ void wait_progress(volatile int *prog, int target, in
   asm volatile("" ::: "memory");
 }
 
-template <int NR, int P, int CI>
-__device__ __forceinline__ void chunks(double (&e)[NR], Pipe &p, const SweepCtx &x, double &dmax, int &seen) {
+template <int NR, int P, int CI, int NAR>
+__device__ __forceinline__ void chunks(double (&e)[NR], const double (&Areg)[NAR], Pipe &p, const SweepCtx &x,
+                                       double &dmax, int &seen) {
   constexpr int kMaxCh = (NR + 63 + 7) / 8;
   if constexpr (CI < kMaxCh) {
     if (CI < x.nch) { // wave-uniform
       if (P == kPair && x.role == 1) wait_progress(x.prog, x.prog_base + min(CI + x.lag, x.nch0), seen);
       p.cw[(CI + 2) % 3] = x.cmap[opaque(0) + (CI + 2) * 64];
-      chunk_steps<NR, P, CI, 0>(e, p, x, dmax);
+      chunk_steps<NR, P, CI, 0>(e, Areg, p, x, dmax);
       if (P == kPair) {
         // publish the edge row's new values of this chunk (columns 8*CI-edge_off .. +7)
         const int c0 = 8 * CI - x.edge_off;
@@ -181,13 +191,13 @@ __device__ __forceinline__ void chunks(double (&e)[NR], Pipe &p, const SweepCtx 
         if (x.role == 0 && x.lane == 0) *x.prog = x.prog_base + CI + 1;
         asm volatile("" ::: "memory");
       }
-      chunks<NR, P, CI + 1>(e, p, x, dmax, seen);
+      chunks<NR, P, CI + 1>(e, Areg, p, x, dmax, seen);
     }
   }
 }
 
-template <int NR, int P>
-__device__ __forceinline__ double sweep_reg(double (&e)[NR], const SweepCtx &xin) {
+template <int NR, int P, int NAR>
+__device__ __forceinline__ double sweep_reg(double (&e)[NR], const double (&Areg)[NAR], const SweepCtx &xin) {
   double dmax = 0.0;
   int seen = 0;
   // the per-step lane predicates are one v_cmp each; hoisted out of the sweep loop they would
@@ -199,10 +209,10 @@ __device__ __forceinline__ double sweep_reg(double (&e)[NR], const SweepCtx &xin
   p.cw[0] = x.cmap[opaque(0)];
   p.cw[1] = x.cmap[opaque(0) + 64];
   p.cw[2] = 0;
-  prefetch<NR, P, 0>(p, x.tab, x.Arow, x.seam_in, x.seam_in2);
-  prefetch<NR, P, 1>(p, x.tab, x.Arow, x.seam_in, x.seam_in2);
+  prefetch<NR, P, 0>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
+  prefetch<NR, P, 1>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
   __builtin_amdgcn_sched_barrier(0);
-  chunks<NR, P, 0>(e, p, x, dmax, seen);
+  chunks<NR, P, 0>(e, Areg, p, x, dmax, seen);
   if (P == kTail && x.edge) { // row 63's new values for the tail scan: lane 63's registers, column c in slot c + 63
 #pragma unroll
     for (int c = 0; c < NR; ++c) x.seam_out[c + 63] = e[(c + 63) % NR];
@@ -315,6 +325,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   SweepCtx x;
   x.tab = tab;
   x.Arow = A + (size_t)R * a.AS; // odd row stride: the 64 lanes of a ds_read_b64 cover all 32 banks
+  constexpr int kNL = lds_slots(NR, P), kNAR = NR - kNL > 0 ? NR - kNL : 1;
   x.cmap = a.cmapS + (size_t)w * (kMaxCh + 3) * 64 + lane;
   x.rowmask = __builtin_amdgcn_ballot_w64(rowvalid);
   x.lane = lane; x.lp = rowvalid ? lp : (int)0x80000000; x.nch = a.nch[w];
@@ -384,6 +395,8 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     }
 
     // A = ap*Tprev + g for every cell of the lane's row (E = Tprev before the first sweep)
+    double Areg[kNAR];
+    Areg[0] = 0.0;
     if (rowvalid) {
       unsigned long long cw[kASlots]; // all class words first: one memory latency, not kASlots
       {
@@ -406,7 +419,11 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
           }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          if (j0 + k < NR) Aw[j0 + k] = fma(ap[k], e[j0 + k], gg[k]);
+          if (j0 + k < NR) {
+            const double av = fma(ap[k], e[j0 + k], gg[k]);
+            if (j0 + k < kNL) Aw[j0 + k] = av;
+            else Areg[j0 + k - kNL] = av;
+          }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -417,7 +434,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
 #pragma nounroll
     for (int it = 0; it < p.iter_limit; ++it) { // simulator.py:348-368
       x.prog_base = it * 32; // the counter only grows within a building's step
-      double dm = sweep_reg<NR, P>(e, x);
+      double dm = sweep_reg<NR, P>(e, Areg, x);
 #if !(defined(SB_EXP) && (SB_EXP & 1)) /* timing experiment 1: no tail pass */
       if (P == kTail) {
         __builtin_amdgcn_wave_barrier(); // row 63's last values are in LDS before the scan reads them
@@ -537,6 +554,7 @@ const Variant *find_variant(int NR, int P) {
 } // namespace
 
 bool sweep_reg_supported(int NR, int P) { return find_variant(NR, P) != nullptr; }
+int sweep_reg_lds_slots(int NR, int P) { return lds_slots(NR, P); }
 
 int prepare_sweep_reg(const Dev &d) {
   const Variant *v = find_variant(d.NR, d.P);
