@@ -69,6 +69,7 @@ struct Dev {
   const uint8_t *tcls;     // mode 3: [T][NR] classes of the tail cells
   int RS;                  // rows of the trimmed grid = row stride of the HBM state [NR][RS]
   int AS;                  // row stride of A in LDS (odd when it fits: bank-conflict free)
+  int ZRS;                 // row stride of the zone-sum scratch [Z+1][ZRS] that aliases A (RS | 1)
   int Ws;                  // trimmed width
   int n_ring;              // exterior-space cells outside the trim box (all of class "ambient")
   int lw[2], l0[2], rowbase[2], nch[2]; // per wave: rows, first lane, first row, 8-step chunks

@@ -247,8 +247,9 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
   if (!P) { r.why = "more than 128 rows inside the building"; return; }
   if (!NR) { r.why = "no kernel variant for this width"; return; }
   const int RS = P == 3 ? 64 : Hs;
-  if (Z + 1 > sweep_reg_lds_slots(NR, P) || (size_t)(Z + 1) * RS * 8 > 65535) {
-    r.why = "too many zones for the zone-sum scratch"; // it aliases A: (Z+1) x RS doubles
+  const int ZRS = RS | 1; // odd stride: the zone reduce reads 16 zone rows at once
+  if ((size_t)(Z + 1) * ZRS > (size_t)RS * sweep_reg_lds_slots(NR, P) || (size_t)(Z + 1) * ZRS * 8 > 65535) {
+    r.why = "too many zones for the zone-sum scratch"; // it aliases A: (Z+1) x ZRS doubles
     return;
   }
   r.NR = NR; r.P = P; r.RS = RS; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
@@ -348,7 +349,7 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
             const int zz = zone_of[(x0 + R) * W + (y0 + col)];
             if (zz >= 0) z = zz;
           }
-          const unsigned offb = (unsigned)((z * RS + (valid ? R : 0)) * 8);
+          const unsigned offb = (unsigned)((z * ZRS + (valid ? R : 0)) * 8);
           word |= (unsigned long long)offb << (16 * k);
         }
         r.zmapS[((size_t)w * zslots + g) * 64 + lane] = word;
@@ -548,7 +549,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   if (d.reg) {
     d.pitch = d.W; d.NL = d.N; d.ts = kRegTS;
     d.NR = r.NR; d.P = r.P; d.RS = r.RS; d.Ws = r.Ws; d.n_ring = r.n_ring;
-    d.T = r.T; d.state_doubles = r.state_doubles; d.AS = r.AS;
+    d.T = r.T; d.state_doubles = r.state_doubles; d.AS = r.AS; d.ZRS = r.RS | 1;
     for (int w = 0; w < 2; ++w) { d.lw[w] = r.lw[w]; d.l0[w] = r.l0[w]; d.rowbase[w] = r.rowbase[w]; d.nch[w] = r.nch[w]; }
     d.lag = r.lag; d.nslots = r.nslots; d.nsteps = r.steps;
     d.lds_reg_bytes = r.lds_bytes; d.wg_per_cu = r.wg_per_cu;

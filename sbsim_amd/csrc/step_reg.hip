@@ -53,6 +53,10 @@ __device__ __forceinline__ int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+__device__ __forceinline__ int opaque_s(int v) { // the same for a wave-uniform value (stays in an SGPR)
+  asm volatile("" : "+s"(v));
+  return v;
+}
 
 struct Co { double bU, bD, bL, bR, A, smU, smD; };
 struct Pipe {
@@ -250,6 +254,8 @@ constexpr int kTailMax = 2;
 
 // One Gauss-Seidel pass over the tail rows; returns the lane's max |delta|.
 // tE: [T][NR+2] current values (column c at [1 + c]); r63: new values of row 63 by column.
+// A row is NR <= 128 columns = two 64-lane blocks whose scans are independent until the
+// carry (x of column 63) enters the second one, so both run interleaved.
 template <int NR>
 __device__ __forceinline__ double tail_pass(int T, int lane, const double *tab, double *tE, const double *r63,
                                             const double (&At)[kTailMax][2], unsigned tclsw) {
@@ -258,32 +264,38 @@ __device__ __forceinline__ double tail_pass(int T, int lane, const double *tab, 
 #pragma unroll
   for (int t = 0; t < kTailMax; ++t) {
     if (t < T) {
+      double *row = tE + t * kRow + 1;
+      double aa[kBlk], q[kBlk], old[kBlk];
+#pragma unroll
+      for (int blk = 0; blk < kBlk; ++blk) {
+        const int c = blk * 64 + lane;
+        const int cc = c < NR ? c : NR - 1;
+        const int cls8 = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
+        const double *bt = (const double *)((const char *)tab + cls8);
+        const double bU = bt[0], bD = bt[kTS], bL = bt[2 * kTS], bR = bt[3 * kTS];
+        const double U = t == 0 ? r63[cc] : row[cc - kRow];
+        const double Dn = t + 1 < T ? row[cc + kRow] : 0.0;
+        const double Rn = row[cc + 1];
+        old[blk] = row[cc];
+        q[blk] = fma(bU, U, fma(bR, Rn, fma(bD, Dn, At[t][blk])));
+        aa[blk] = bL;
+      }
+#pragma unroll
+      for (int blk = 0; blk < kBlk; ++blk) affine_scan(aa[blk], q[blk]);
+      __builtin_amdgcn_wave_barrier(); // every read of the row's old values is done
       double carry = 0.0;
 #pragma unroll
       for (int blk = 0; blk < kBlk; ++blk) {
         const int c = blk * 64 + lane;
-        const bool in = c < NR;
-        const int cc = in ? c : NR - 1;
-        const int cls8 = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
-        const double *bt = (const double *)((const char *)tab + cls8);
-        const double bU = bt[0], bD = bt[kTS], bL = bt[2 * kTS], bR = bt[3 * kTS];
-        double *row = tE + t * kRow + 1;
-        const double U = t == 0 ? r63[cc] : row[cc - kRow];
-        const double Dn = t + 1 < T ? row[cc + kRow] : 0.0;
-        const double Rn = row[cc + 1], old = row[cc];
-        double q = fma(bU, U, fma(bR, Rn, fma(bD, Dn, At[t][blk])));
-        double aa = bL;
-        affine_scan(aa, q);
-        const double xv = fma(aa, carry, q);
-        __builtin_amdgcn_wave_barrier();
-        if (in) {
-          dmax = fmax(dmax, fabs(xv - old));
-          row[cc] = xv;
+        const double xv = fma(aa[blk], carry, q[blk]);
+        if (c < NR) {
+          dmax = fmax(dmax, fabs(xv - old[blk]));
+          row[c] = xv;
         }
-        __builtin_amdgcn_wave_barrier();
         carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xv), 63),
                                  __builtin_amdgcn_readlane(__double2loint(xv), 63));
       }
+      __builtin_amdgcn_wave_barrier(); // the next row reads this one
     }
   }
   return dmax;
@@ -344,38 +356,61 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   const unsigned long long *amap = a.amapS + (size_t)w * kASlots * 64 + lane;
   const unsigned long long *zmap = a.zmapS + (size_t)w * kZSlots * 64 + lane;
 
-#define SB_STAMP(i) do { if (a.dbg && b == 0 && w == 0 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+// developer aid: cycle stamps of workgroup 0's 11th building (steady state, not the cold start)
+#define SB_STAMP(i) do { if (a.dbg && b == 10 * (int)gridDim.x && w == 0 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
   // The lane's row of the NEXT building is loaded while this building's zone sums are reduced
   // (its registers are free once the row is stored), so the loop never waits on HBM latency.
   double e[NR];
 #define SB_LOAD_ROW(bb)                                                                         \
   do {                                                                                          \
-    const double *tp_ = a.temp + (size_t)(bb) * a.state_doubles + R;                            \
+    const double *tp_ = a.temp + (size_t)(bb) * a.state_doubles; /* wave-uniform: SGPR base + lane offset */ \
     _Pragma("unroll") for (int j = 0; j < NR; ++j) { /* pad lanes mirror a real row: never updated, never stored */ \
-      e[j] = *tp_;                                                                              \
-      tp_ += opaque(RS);                                                                        \
+      e[j] = tp_[R];                                                                            \
+      tp_ += opaque_s(RS);                                                                      \
     }                                                                                           \
   } while (0)
-  if ((int)blockIdx.x < a.B) SB_LOAD_ROW(blockIdx.x);
+  // ... and so are the building's small inputs: its g table entry, tail rows, ambient
+  // temperature and the extremes of its exterior ring.
+  double nx_g = 0.0, nx_tail[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}, nx_tnow = 0.0, nx_lo = 0.0, nx_hi = 0.0;
+#define SB_LOAD_AUX(bb)                                                                         \
+  do {                                                                                          \
+    nx_tnow = a.bld[(bb)].t_now;                                                                \
+    nx_lo = a.scal[(size_t)(bb) * kNScal + 16];                                                 \
+    nx_hi = a.scal[(size_t)(bb) * kNScal + 17];                                                 \
+    if (w == 0) nx_g = a.gtabg[(size_t)(bb) * kTS + (lane & (kTS - 1))];                        \
+    if (P == kTail) {                                                                           \
+      const double *tt_ = a.temp + (size_t)(bb) * a.state_doubles + NR * 64;                    \
+      _Pragma("unroll") for (int t = 0; t < kTailMax; ++t)                                      \
+        _Pragma("unroll") for (int blk = 0; blk < (NR + 63) / 64; ++blk)                        \
+          if (t < a.T) nx_tail[t][blk] = tt_[t * NR + min(blk * 64 + lane, NR - 1)];            \
+    }                                                                                           \
+  } while (0)
+  if ((int)blockIdx.x < a.B) {
+    SB_LOAD_ROW(blockIdx.x);
+    SB_LOAD_AUX(blockIdx.x);
+  }
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     SB_STAMP(0);
     double *T = a.temp + (size_t)b * a.state_doubles + R;
     double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 64; // mode kTail: [T][NR]
     __builtin_amdgcn_sched_barrier(0);
-    const double t_now = a.bld[b].t_now;
+    const double t_now = nx_tnow;
     // exterior-space cells outside the trim box all become t_now in the first sweep
     // (simulator.py:256-258); their largest |delta| follows from their extreme values
-    const double *S = a.scal + (size_t)b * kNScal;
-    const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - S[16]), fabs(t_now - S[17])) : 0.0;
+    const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0;
     if (w == 0) {
       if (P == kPair && lane == 0) *x.prog = 0;
-      if (lane < kTS) gtab[lane] = a.gtabg[(size_t)b * kTS + lane];
+      if (lane < kTS) gtab[lane] = nx_g;
       if (P == kPair) // old values of wave 1's first row (its lane 0: column c sits in slot c)
         for (int c = lane; c < NR; c += 64)
           seamD[kSeamPad + c] = a.temp[(size_t)b * a.state_doubles + (size_t)c * RS + a.rowbase[1]];
-      if (P == kTail)
-        for (int t = 0; t < a.T; ++t)
-          for (int c = lane; c < NR; c += 64) tE[t * (NR + 2) + 1 + c] = Ttail[t * NR + c];
+      if (P == kTail) {
+#pragma unroll
+        for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+          for (int blk = 0; blk < (NR + 63) / 64; ++blk)
+            if (t < a.T && blk * 64 + lane < NR) tE[t * (NR + 2) + 1 + blk * 64 + lane] = nx_tail[t][blk];
+      }
     }
     if (P == kPair) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -405,25 +440,33 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
         for (int g = 0; g < kASlots; ++g) cw[g] = amap[o + g * 64];
       }
       double *Aw = A + (size_t)R * a.AS;
-      // groups of 8: all table reads of a group are issued before its first A write (the
-      // compiler cannot prove that A and the tables do not alias and would serialise them)
+      // groups of 8, software-pipelined: the table reads of group g+1 are issued before the
+      // A values of group g are written (the compiler cannot prove that A and the tables do
+      // not alias and would serialise every read behind the previous write)
+      constexpr int kGroups = (NR + 7) / 8;
+      double ap[2][8], gg[2][8];
+      auto fetch = [&](int g, double (&pa)[8], double (&pg)[8]) {
 #pragma unroll
-      for (int j0 = 0; j0 < NR; j0 += 8) {
-        double ap[8], gg[8];
+        for (int k = 0; k < 8; ++k) {
+          const int j = min(8 * g + k, NR - 1);
+          const int c8 = (int)((cw[j >> 3] >> (8 * (j & 7))) & 0xffull);
+          pa[k] = *(const double *)((const char *)(tab + 4 * kTS) + c8);
+          pg[k] = *(const double *)((const char *)gtab + c8);
+        }
+      };
+      fetch(0, ap[0], gg[0]);
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        if (g + 1 < kGroups) fetch(g + 1, ap[(g + 1) & 1], gg[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          if (j0 + k < NR) {
-            const int c8 = (int)((cw[(j0 + k) >> 3] >> (8 * ((j0 + k) & 7))) & 0xffull);
-            ap[k] = *(const double *)((const char *)(tab + 4 * kTS) + c8);
-            gg[k] = *(const double *)((const char *)gtab + c8);
+          if (8 * g + k < NR) {
+            const double av = fma(ap[g & 1][k], e[8 * g + k], gg[g & 1][k]);
+            if (8 * g + k < kNL) Aw[8 * g + k] = av;
+            else Areg[8 * g + k - kNL] = av;
           }
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (j0 + k < NR) {
-            const double av = fma(ap[k], e[j0 + k], gg[k]);
-            if (j0 + k < kNL) Aw[j0 + k] = av;
-            else Areg[j0 + k - kNL] = av;
-          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -454,11 +497,13 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(3);
+    SB_STAMP(4);
 
-    // grid back to HBM; the wave's share of the grid sum
-    // zone sums: every lane adds its cells into its own column of zs[zone][row] (A is dead)
-    double gpart = 0.0;
+    // grid back to HBM.  Zone sums (A is dead now): every lane adds its cells into its own
+    // column of zs[zone][row]; row Z collects every cell outside a zone, so that the sum of all
+    // rows is the grid sum.
     double *zs = A;
+    const int ZRS = a.ZRS;
     if (rowvalid) {
       unsigned long long zwv[kZSlots]; // zone-sum offsets: loaded while the row is stored
       {
@@ -467,22 +512,22 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
         for (int g = 0; g < kZSlots; ++g) zwv[g] = zmap[o + g * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      double *tp = T;
+      double *tp = a.temp + (size_t)b * a.state_doubles;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        *tp = e[j];
-        tp += opaque(RS);
-        gpart += e[j];
-        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        tp[R] = e[j];
+        tp += opaque_s(RS);
       }
-      if (P == kTail) // the tail rows hold no zone cells (sb_create checks); they count in the grid sum
+      for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + R] = 0.0;
+      __builtin_amdgcn_wave_barrier();
+      if (P == kTail) // the tail rows hold no zone cells (sb_create checks): all into row Z
         for (int t = 0; t < a.T; ++t)
           for (int c = lane; c < NR; c += 64) {
             const double tv = tE[t * (NR + 2) + 1 + c];
             Ttail[t * NR + c] = tv;
-            gpart += tv;
+            __hip_atomic_fetch_add(zs + (size_t)a.Z * ZRS + lane, tv, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
           }
-      for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * RS + R] = 0.0;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const unsigned off = (unsigned)((zwv[j >> 2] >> (16 * (j & 3))) & 0xffffull);
@@ -492,40 +537,44 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (b + (int)gridDim.x < a.B) SB_LOAD_ROW(b + gridDim.x);
+    SB_STAMP(5);
+    if (b + (int)gridDim.x < a.B) {
+      SB_LOAD_ROW(b + gridDim.x);
+      SB_LOAD_AUX(b + gridDim.x);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    gpart = wave_sum(gpart);
-    if (lane == 0) xchg[4 + w] = gpart;
+    SB_STAMP(6);
     if (P == kPair) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-    SB_STAMP(4);
+    SB_STAMP(7);
 
     if (w == 0) { // hand the zone sums, the grid sum and the sweep count to k_post
-      for (int z0 = 0; z0 < a.Z; z0 += 4) { // four zones at a time: their LDS reads and DPP chains overlap
-        double part[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (z0 + k < a.Z)
-            for (int r = lane; r < RS; r += 64) part[k] += zs[(size_t)(z0 + k) * RS + r];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) part[k] = wave_sum(part[k]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (z0 + k < a.Z && lane == 0) a.zsum[(size_t)b * a.Z + z0 + k] = part[k];
+      // 16 zones x 4 row groups per pass: lane (zone = lane & 15, group = lane >> 4) adds every
+      // fourth row of its zone, two xor-shuffles combine the groups
+      double gacc = 0.0;
+      for (int zb = 0; zb <= a.Z; zb += 16) {
+        const int zz = zb + (lane & 15), g = lane >> 4;
+        double v = 0.0;
+        if (zz <= a.Z)
+          for (int r = g; r < RS; r += 4) v += zs[(size_t)zz * ZRS + r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16 && zz < a.Z) a.zsum[(size_t)b * a.Z + zz] = v;
+        if (lane < 16 && zz <= a.Z) gacc += v;
       }
+      const double gsum = wave_sum(gacc);
       if (lane == 0) {
-        double gsum = xchg[4];
-        if (P == kPair) gsum += xchg[5];
         a.gsum[b] = gsum + (double)a.n_ring * t_now;
         a.nsw[b] = n_sweeps | (converged << 16);
       }
       SB_STAMP(8);
-      if (a.dbg && b == 0 && lane == 0) a.dbg[9] = n_sweeps;
+      if (a.dbg && b == 10 * (int)gridDim.x && lane == 0) a.dbg[9] = n_sweeps;
     }
     // no barrier here: wave 1 touches no LDS of the next building before the barrier that
     // follows wave 0's g-table load
   }
 #undef SB_STAMP
 #undef SB_LOAD_ROW
+#undef SB_LOAD_AUX
 }
 
 struct Variant {

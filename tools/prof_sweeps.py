@@ -33,7 +33,7 @@ if os.environ.get("SBSIM_PHASE_TIMING"):
   env = BatchedEnvironment(plan, B, holiday_calendar=None, collect_info=True)
   env.reset()
   env.sim.reset(temps=torch.tensor(t_init, dtype=torch.float64, device="cuda")[:, None].expand(B, 68 * 98).contiguous())
-  names = ["thermostat+tables", "grid->LDS", "sweeps", "VAV+demand", "write-back", "zone means+prod", "reward", "obs"]
+  names = ["setup(g,tail,wait rows)", "A pass", "sweeps", "-", "store+scatter", "next-row loads", "gsum", "zone reduce"]
   for t in range(8):
     env.step(acts[t])
     buf = (C.c_longlong * 16)()
