@@ -10,9 +10,9 @@ cmd="python $PWD/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline"
 echo "$cmd" > $out/command.txt
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$tag -o bench -- $cmd > $out/bench_under_rocprof.json 2> /tmp/prof_stats_$tag.err)
 find /tmp/prof_stats_$tag -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
-find /tmp/prof_stats_$tag -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > '"$out"'/kernel_trace_k_step.csv; grep -E "k_step|k_reset" "$1" >> '"$out"'/kernel_trace_k_step.csv' _ {} \;
+find /tmp/prof_stats_$tag -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > '"$out"'/kernel_trace_sb.csv; grep -E "k_sweep|k_pre|k_post|k_reset" "$1" >> '"$out"'/kernel_trace_sb.csv' _ {} \;
 # PMC: one counter per pass (FETCH_SIZE needs 3 of the 4 TCC slots); plus a calibration run with
-# iteration_limit=1 (exactly one sweep: the only big read is the LDS-DMA grid load, N*8 bytes/building)
+# iteration_limit=1 whose traffic is known by construction (the state is read once and written once)
 for ctr in FETCH_SIZE WRITE_SIZE; do
   for variant in main calib; do
     extra=""; [ $variant = calib ] && extra="--iteration-limit 1"
@@ -29,32 +29,45 @@ def vals(ctr, variant, kernel):
         rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
         v += [float(r["Counter_Value"]) for r in rows]
     return v
-B, N, NP = 65536, 68 * 98, 68 * 98 + 16
-res = {"tag": tag, "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB"}
-f_main, w_main = vals("FETCH_SIZE", "main", "k_step"), vals("WRITE_SIZE", "main", "k_step")
-f_cal, w_cal = vals("FETCH_SIZE", "calib", "k_step"), vals("WRITE_SIZE", "calib", "k_step")
-w_reset = vals("WRITE_SIZE", "main", "k_reset")
+B = 65536
+bench = {}
+for line in open(out + "/bench_under_rocprof.json"):
+    if line.startswith("{"):
+        bench = json.loads(line)
+li = bench.get("config", {}).get("launch", {})
+Z, O = bench.get("config", {}).get("zones", 9), 46
+# sb_launch_info.state_bytes_per_env_step = 16*state_doubles + per-zone/scalar/obs bytes (sbsim_hip.hip)
+state_bytes = (li.get("state_bytes_per_env_step", 0) - ((8 * 4 + 4 * 2) * Z + 16 * 16 + 8 + 4 * O + 4)) // 2
+kern = "k_sweep"
+res = {"tag": tag, "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB", "kernel": kern,
+       "state_bytes_per_building": state_bytes}
+f_main, w_main = vals("FETCH_SIZE", "main", kern), vals("WRITE_SIZE", "main", kern)
+f_cal, w_cal = vals("FETCH_SIZE", "calib", kern), vals("WRITE_SIZE", "calib", kern)
 res["fetch_kib_per_launch_all"] = f_main
 res["write_kib_per_launch_all"] = w_main
 ft, wt = f_main[warm:], w_main[warm:]
 res["fetch_kib_timed_mean"] = sum(ft) / max(len(ft), 1)
 res["write_kib_timed_mean"] = sum(wt) / max(len(wt), 1)
-# calibration on known byte counts (MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of a wide coalesced
-# stream on gfx950; WRITE_SIZE uncalibrated): one-sweep k_step reads B*(N*8 + ~300) bytes,
-# k_reset writes B*(N+16)*8 bytes.
-exp_read = B * (N * 8 + 300)
-exp_write_reset = B * NP * 8
-fc = f_cal[warm:] or f_cal
+# calibration on known byte counts in this kernel's own access pattern (MI355X_MICROARCH.md, HBM):
+# a sweep launch reads every building's state once (8 B/lane, 512-byte rows) + its g table
+# (256 B), Bld record (112 B) and ring extremes (16 B), and writes the state + zone sums back --
+# whatever the number of sweeps; the iteration_limit=1 run is the reference point.
+exp_read = B * (state_bytes + 256 + 112 + 16)
+exp_write = B * (state_bytes + 8 * Z + 12)
+fc, wc = f_cal[warm:] or f_cal, w_cal[warm:] or w_cal
 res["calib_fetch_kib_one_sweep"] = sum(fc) / max(len(fc), 1)
+res["calib_write_kib_one_sweep"] = sum(wc) / max(len(wc), 1)
+res["expected_read_bytes_per_launch"] = exp_read
+res["expected_write_bytes_per_launch"] = exp_write
 res["fetch_correction"] = exp_read / (res["calib_fetch_kib_one_sweep"] * 1024) if fc else None
-res["calib_write_kib_k_reset"] = max(w_reset) if w_reset else None
-res["write_correction"] = exp_write_reset / (max(w_reset) * 1024) if w_reset else None
+res["write_correction"] = exp_write / (res["calib_write_kib_one_sweep"] * 1024) if wc else None
 fcorr = res["fetch_correction"] or 2.0
 wcorr = res["write_correction"] or 1.0
 res["hbm_bytes_per_launch"] = res["fetch_kib_timed_mean"] * 1024 * fcorr + res["write_kib_timed_mean"] * 1024 * wcorr
 res["source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps ... --warmup {warm}`, "
-                 f"timed launches only, corrected by x{fcorr:.3f} (reads, calibrated on a one-sweep run) and x{wcorr:.3f} "
-                 "(writes, calibrated on k_reset); profiles/" + tag + "_traffic.json")
+                 f"sweep-kernel launches of the timed region only, corrected by x{fcorr:.3f} (reads) and x{wcorr:.3f} (writes), "
+                 "both calibrated on an iteration_limit=1 run of the same command whose traffic is known by construction; "
+                 "profiles/" + tag + "_traffic.json")
 json.dump(res, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if not k.endswith("_all")}, indent=1))
 PY
