@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SBSIM_LIB") or os.path.join(_HERE, "libsbsim_amd.so")
 
 SB_NUM_ACTIONS = 2
 SB_NUM_AUX = 7
+SB_ABI_VERSION = 2   # include/sbsim_amd.h
 SB_INFO_STRIDE = 8
 SB_NUM_SCALARS = 16
 

@@ -235,7 +235,7 @@ def test_environment_api_episode_bookkeeping():
 def test_abi_error_paths():
   _need_gpu()
   L = _ffi.load()
-  assert L.sb_abi_version() == 2
+  assert L.sb_abi_version() == _ffi.SB_ABI_VERSION
   h = C.c_void_p()
   assert L.sb_create(None, None, None, 1, 0, C.byref(h)) == -1
   assert b"null" in L.sb_last_error()
