@@ -97,6 +97,8 @@ struct Dev {
   double *zsum;            // [B][Z] post-update zone sums
   double *gsum;            // [B] sum of the whole grid after the update
   int *nsw;                // [B] sweeps | converged << 16
+  int *next_b;             // next building a sweep workgroup draws (k_pre resets it to sweep_wgs)
+  int sweep_wgs;           // workgroups of the sweep kernel
   // observation layout
   int O, col_ahu, col_blr, col_aux;
   const int *col_zone;

@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(256) k_pre(Dev a, StepArgs s) {
   const int per_wave = ((3 * a.Z + 1) & ~1) + ((a.Z + 1) / 2 + 1);
   double *zscr = lds_phase + (size_t)wib * per_wave;
   int *zmode = (int *)(zscr + ((3 * a.Z + 1) & ~1));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_b = a.sweep_wgs;
   for (int b = wave; b < a.B; b += nwaves) {
     Bld v;
     phase_begin(a, s, b, lane, zscr, zmode, a.gtabg + (size_t)b * a.ts, v);
@@ -457,7 +458,7 @@ struct sb_handle {
   sb_launch_info info{};
   DevBuf<uint8_t> cls, tcls;
   DevBuf<double> ctab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum;
-  DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone, cell_state, nsw;
+  DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone, cell_state, nsw, next_b;
   DevBuf<Bld> bld;
   DevBuf<uint4> zl16;
   DevBuf<int4> sched;
@@ -648,7 +649,10 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   SB_TRY(alloc_zero(h->zsum, (size_t)d.B * d.Z));
   SB_TRY(alloc_zero(h->gsum, (size_t)d.B));
   SB_TRY(alloc_zero(h->nsw, (size_t)d.B));
+  SB_TRY(alloc_zero(h->next_b, 1));
 #undef SB_TRY
+  d.next_b = h->next_b.p;
+  d.sweep_wgs = h->info.workgroups;
   d.bld = h->bld.p; d.gtabg = h->gtabg.p; d.zsum = h->zsum.p; d.gsum = h->gsum.p; d.nsw = h->nsw.p;
   d.ctab = h->ctab.p; d.czone = h->czone.p; d.zone_off = h->zone_off.p;
   d.zone_cells_l = h->zone_cells_l.p; d.temp = h->temp.p; d.zmean = h->zmean.p;

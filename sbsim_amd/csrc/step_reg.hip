@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   const unsigned long long *zmap = a.zmapS + (size_t)w * kZSlots * 64 + lane;
 
 // developer aid: cycle stamps of workgroup 0's 11th building (steady state, not the cold start)
-#define SB_STAMP(i) do { if (a.dbg && b == 10 * (int)gridDim.x && w == 0 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define SB_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && iter == 10 && w == 0 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
   // The lane's row of the NEXT building is loaded while this building's zone sums are reduced
   // (its registers are free once the row is stored), so the loop never waits on HBM latency.
   double e[NR];
@@ -389,7 +389,19 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     SB_LOAD_ROW(blockIdx.x);
     SB_LOAD_AUX(blockIdx.x);
   }
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  // Buildings need different numbers of sweeps, so a static split would leave the last
+  // workgroups running alone: after its first building a workgroup draws the next one from a
+  // device counter (k_pre resets it to the grid size).  The two-wavefront mode keeps the
+  // static stride (both waves must agree on the building without a round trip through LDS).
+  auto draw = [&](int cur) {
+    if (P == kPair) return cur + (int)gridDim.x;
+    int nb = 0;
+    if (lane == 0) nb = atomicAdd(a.next_b, 1);
+    return __builtin_amdgcn_readfirstlane(nb);
+  };
+  int iter = 0;
+  for (int b = blockIdx.x, bn = 0; b < a.B; b = bn, ++iter) {
+    bn = draw(b); // early: the epilogue prefetches building bn
     SB_STAMP(0);
     double *T = a.temp + (size_t)b * a.state_doubles + R;
     double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 64; // mode kTail: [T][NR]
@@ -538,9 +550,9 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(5);
-    if (b + (int)gridDim.x < a.B) {
-      SB_LOAD_ROW(b + gridDim.x);
-      SB_LOAD_AUX(b + gridDim.x);
+    if (bn < a.B) {
+      SB_LOAD_ROW(bn);
+      SB_LOAD_AUX(bn);
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(6);
@@ -567,7 +579,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
         a.nsw[b] = n_sweeps | (converged << 16);
       }
       SB_STAMP(8);
-      if (a.dbg && b == 10 * (int)gridDim.x && lane == 0) a.dbg[9] = n_sweeps;
+      if (a.dbg && blockIdx.x == 0 && iter == 10 && lane == 0) a.dbg[9] = n_sweeps;
     }
     // no barrier here: wave 1 touches no LDS of the next building before the barrier that
     // follows wave 0's g-table load
@@ -614,8 +626,8 @@ int prepare_sweep_reg(const Dev &d) {
 int launch_sweep_reg(const Dev &d, int cus, hipStream_t stream) {
   const Variant *v = find_variant(d.NR, d.P);
   if (!v) return (int)hipErrorInvalidValue;
-  const int wgs = std::max(1, std::min(d.B, cus * d.wg_per_cu));
-  v->launch(d, wgs, stream);
+  (void)cus;
+  v->launch(d, d.sweep_wgs, stream); // == min(B, CUs * wg_per_cu); k_pre resets the draw counter to it
   return (int)hipGetLastError();
 }
 
