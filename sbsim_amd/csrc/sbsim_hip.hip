@@ -104,12 +104,9 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps) {
 
 __global__ void k_observe(Dev a, float *obs, float aux0, float aux1, float aux2, float aux3,
                           float aux4, float aux5, float aux6, double t_amb) {
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * (blockDim.x >> 6);
   const float aux[SB_NUM_AUX] = {aux0, aux1, aux2, aux3, aux4, aux5, aux6};
-  for (int b = wave; b < a.B; b += nwaves)
-    write_obs(a, b, lane, obs, aux, t_amb, a.scal + (size_t)b * kNScal);
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
+    write_obs(a, b, obs, aux, t_amb, a.scal + (size_t)b * kNScal);
 }
 
 // building.temp in the caller's row-major layout, whichever state layout the handle uses.
@@ -140,40 +137,16 @@ __global__ void k_copy_scalars(Dev a, double *out) {
     out[i] = a.scal[(i / kNScalOut) * kNScal + (i % kNScalOut)];
 }
 
-// Per-building algebra before the sweep: one wavefront per building, lane = zone.
-// LDS per wave: zscr[3Z] doubles, zmode[Z] ints.
-extern __shared__ __attribute__((aligned(16))) double lds_phase[];
-
-__global__ void __launch_bounds__(256) k_pre(Dev a, StepArgs s) {
-  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + wib, nwaves = gridDim.x * (blockDim.x >> 6);
-  const int per_wave = ((3 * a.Z + 1) & ~1) + ((a.Z + 1) / 2 + 1);
-  double *zscr = lds_phase + (size_t)wib * per_wave;
-  int *zmode = (int *)(zscr + ((3 * a.Z + 1) & ~1));
+// Per-building algebra before / after the sweep kernel: one thread per building (sb_device.h).
+__global__ void __launch_bounds__(64) k_pre(Dev a, StepArgs s) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_b = a.sweep_wgs;
-  for (int b = wave; b < a.B; b += nwaves) {
-    Bld v;
-    phase_begin(a, s, b, lane, zscr, zmode, a.gtabg + (size_t)b * a.ts, v);
-    phase_vav(a, s, b, lane, zscr, zmode, v);
-    if (lane == 0) a.bld[b] = v;
-    __builtin_amdgcn_wave_barrier();
-  }
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
+    pre_building(a, s, b);
 }
 
-// reward_info, reward, observation, scalar state from the sweep kernel's zone sums.
-__global__ void __launch_bounds__(256) k_post(Dev a, StepArgs s) {
-  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + wib, nwaves = gridDim.x * (blockDim.x >> 6);
-  double *zscr = lds_phase + (size_t)wib * ((2 * a.Z + 1) & ~1) - a.Z; // only [Z..2Z) is used
-  for (int b = wave; b < a.B; b += nwaves) {
-    const Bld v = a.bld[b];
-    for (int z = lane; z < a.Z; z += 64) zscr[a.Z + z] = a.zsum[(size_t)b * a.Z + z];
-    __builtin_amdgcn_wave_barrier();
-    const int nsw = a.nsw[b];
-    phase_end(a, s, b, lane, zscr, [&](int z) { return a.zone_off[z + 1] - a.zone_off[z]; }, v,
-              a.gsum[b] / (double)a.N, nsw & 0xffff, nsw >> 16, v.t_now);
-    __builtin_amdgcn_wave_barrier();
-  }
+__global__ void __launch_bounds__(64) k_post(Dev a, StepArgs s) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
+    post_building(a, s, b);
 }
 
 template <typename Tp>
@@ -701,9 +674,8 @@ int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *s
 int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, float *obs_dev, void *stream) {
   if (!h || !aux || !obs_dev) return fail(SB_ERR_INVALID, "sb_observe: null argument");
   SB_HIP(hipSetDevice(h->device));
-  const int wpb = 4;
-  const int blocks = std::min((h->d.B + wpb - 1) / wpb, 4096);
-  hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(64 * wpb), 0, (hipStream_t)stream, h->d, obs_dev, aux[0],
+  const int blocks = std::max(1, std::min((h->d.B + 63) / 64, 4096));
+  hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->d, obs_dev, aux[0],
                      aux[1], aux[2], aux[3], aux[4], aux[5], aux[6], t_amb);
   SB_HIP(hipGetLastError());
   return SB_OK;
@@ -717,12 +689,9 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   StepArgs s;
   s.actions = actions_dev; s.obs = obs_dev; s.reward = reward_dev; s.info = info_dev; s.in = *in;
   const Dev &d = h->d;
-  const int wpb = 4;
-  const int blocks = std::max(1, std::min((d.B + wpb - 1) / wpb, h->cus * 8));
-  const size_t lds_pre = (size_t)wpb * (((3 * d.Z + 1) & ~1) + ((d.Z + 1) / 2 + 1)) * 8;
-  const size_t lds_post = (size_t)wpb * ((2 * d.Z + 1) & ~1) * 8;
+  const int blocks = std::max(1, std::min((d.B + 63) / 64, h->cus * 16)); // one thread per building
   if (phases & SB_PHASE_PRE) {
-    hipLaunchKernelGGL(k_pre, dim3(blocks), dim3(64 * wpb), lds_pre, (hipStream_t)stream, d, s);
+    hipLaunchKernelGGL(k_pre, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s);
     SB_HIP(hipGetLastError());
   }
   if (phases & SB_PHASE_SWEEP) {
@@ -733,7 +702,7 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
       return fail(SB_ERR_HIP, std::string("sweep kernel launch: ") + hipGetErrorString((hipError_t)e));
   }
   if (phases & SB_PHASE_POST) {
-    hipLaunchKernelGGL(k_post, dim3(blocks), dim3(64 * wpb), lds_post, (hipStream_t)stream, d, s);
+    hipLaunchKernelGGL(k_post, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s);
     SB_HIP(hipGetLastError());
   }
   return SB_OK;
