@@ -144,10 +144,18 @@ __device__ __forceinline__ double wave_sum(double v) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(t), 63);
   return __hiloint2double(hi, lo);
 }
+// Wave-wide max of non-negative values, same DPP pattern (lanes without a source read 0).
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  double t = fmax(v, dpp_or_zero<0x111, 0xf>(v));
+  t = fmax(t, dpp_or_zero<0x112, 0xf>(v));
+  t = fmax(t, dpp_or_zero<0x113, 0xf>(v));
+  t = fmax(t, dpp_or_zero<0x114, 0xf>(t));
+  t = fmax(t, dpp_or_zero<0x118, 0xf>(t));
+  t = fmax(t, dpp_or_zero<0x142, 0xa>(t));
+  t = fmax(t, dpp_or_zero<0x143, 0xc>(t));
+  const int lo = __builtin_amdgcn_readlane(__double2loint(t), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(t), 63);
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll

@@ -200,6 +200,62 @@ def test_divergent_buildings_against_oracle():
     assert np.abs(grid[b] - twins[b].grid()).max() < T_TOL, b
 
 
+def test_per_building_weather_and_per_zone_occupancy():
+  """The optional DEVICE inputs of sb_step_in: `t_amb_dev` [B][2] (every building its own
+  ambient temperature now / next) and `occupancy_dev` [Z] (per-zone occupancy) -- BASELINE.json
+  configs[2] semantics (per-instance weather).  Each building against its own oracle twin."""
+  _need_gpu()
+  g = load("h2_sb1_r9_random.npz")
+  p = load("plan_r9_sb1.npz")
+  B, T = 8, 12
+  rs = np.random.RandomState(3)
+  init = np.clip(294.0 + rs.randn(B, 1, 1) + 0.2 * rs.randn(B, 68, 98), 285.0, 305.0)
+  acts = rs.uniform(-1, 1, size=(T, B, 2)).astype(np.float32)
+  sim = BatchedSimulator(_plan(p), SimConfig.sb1(), B, float(g["h_conv"]))
+  sim.reset(temps=torch.tensor(init.reshape(B, -1), dtype=torch.float64, device="cuda"))
+  plan, prm = oracle_plan(p), oracle_params(g["params_json"])
+  twins = [orc.OracleBuilding(plan, prm, 0.0, reset_temps=init[b].reshape(-1)) for b in range(B)]
+  obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  rng_w, rng_a = (310.0, 355.0), (285.0, 300.0)
+  offs = np.linspace(-12.0, 9.0, B)                       # building b lives in a climate offs[b] K away
+  occ = np.array([0.0, 1.0, 2.5, 4.0, 0.5, 3.0, 1.5, 0.0, 2.0])[:sim.Z]
+  occ_dev = torch.tensor(occ, dtype=torch.float64, device="cuda")
+  for t in range(T):
+    tt = t + 100
+    amb = np.stack([float(g["t_amb_now"][tt]) + offs + 0.05 * t, float(g["t_amb_next"][tt]) + offs + 0.05 * (t + 1)], axis=1)
+    amb_dev = torch.tensor(amb, dtype=torch.float64, device="cuda")
+    si = _step_in(g, tt)
+    si.t_amb_dev = amb_dev.data_ptr()
+    si.occupancy_dev = occ_dev.data_ptr()
+    sim.step(torch.tensor(acts[t], device="cuda"), si, obs, rew, info)
+    i = info.cpu().numpy().astype(np.float64)
+    zt = sim.zone_temps().cpu().numpy()
+    r = rew.cpu().numpy()
+    for b in range(B):
+      a = acts[t, b]
+      native = [np.float32((float(a[0]) + 1.0) / 2.0 * (rng_w[1] - rng_w[0]) + rng_w[0]),
+                np.float32((float(a[1]) + 1.0) / 2.0 * (rng_a[1] - rng_a[0]) + rng_a[0])]
+      o = twins[b].step(
+          now_ts=300.0 * t, t_amb_now=float(amb[b, 0]), h_conv=float(g["h_conv"]),
+          t_amb_next=float(amb[b, 1]), comfort_now=bool(g["comfort_now"][tt]),
+          comfort_prev=g["comfort_prev"][tt] == 1, comfort_next=bool(g["comfort_next"][tt]),
+          occupancy=occ, e_price=float(g["e_price"][tt]), e_carbon=float(g["e_carbon"][tt]),
+          g_price=float(g["g_price"][tt]), g_carbon=float(g["g_carbon"][tt]), action=native, observe=True)
+      assert i[b, 4] == o["n_sweeps"], (t, b, i[b, 4], o["n_sweeps"])
+      assert np.abs(zt[b] - o["zone_temp_post"]).max() < T_TOL, (t, b)
+      ref = np.array([o["blower_rate"], o["ac_rate"], o["gas_rate"], o["pump_rate"]], np.float64)
+      assert np.allclose(i[b, :4], ref, rtol=2e-6, atol=1e-6), (t, b)
+      assert abs(float(r[b]) - o["reward"]) < 1e-6, (t, b)
+  grid = sim.temps().cpu().numpy()
+  for b in range(B):
+    assert np.abs(grid[b] - twins[b].grid()).max() < T_TOL, b
+  # the exterior ring holds each building's own ambient temperature
+  assert np.allclose(grid[:, 0, 0], amb[:, 0], atol=1e-12)
+  assert len(set(np.round(grid[:, 0, 0], 6))) == B
+
+
 def test_environment_api_episode_bookkeeping():
   """environment.py:1165-1212,1311-1368: restart / N transitions / termination / auto-reset,
   plus observation normalisation and auxiliary features."""
