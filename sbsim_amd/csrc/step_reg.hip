@@ -23,8 +23,9 @@
 // barrier per chunk costs ~600 cycles on gfx950, a satisfied flag check nothing.  The DPP
 // `old` operand carries the seam value into the edge lane.
 //
-// HBM state of a building: [NR][RS] float64, slot-major (one coalesced 8*RS-byte row per
-// register), pad cells 0.
+// HBM state of a building: [NR/2][RS][2] float64: slot pairs (2k, 2k+1) of a row are adjacent, so
+// one 16-byte access per lane moves two registers and a wavefront instruction moves a coalesced
+// 16*RS-byte row; pad cells 0.
 #include "sb_device.h"
 
 namespace sb {
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   const int lp = lane - l0;
   const bool rowvalid = lp >= 0 && lp < lw;
   const int R = rowbase + (rowvalid ? lp : 0);
-  const int RS = a.RS;
+  const int RS = P == kTail ? 64 : a.RS; // mode kTail: a compile-time stride -> immediate offsets
   SweepCtx x;
   x.tab = tab;
   x.Arow = A + (size_t)R * a.AS; // odd row stride: the 64 lanes of a ds_read_b64 cover all 32 banks
@@ -363,10 +364,12 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   double e[NR];
 #define SB_LOAD_ROW(bb)                                                                         \
   do {                                                                                          \
-    const double *tp_ = a.temp + (size_t)(bb) * a.state_doubles; /* wave-uniform: SGPR base + lane offset */ \
-    _Pragma("unroll") for (int j = 0; j < NR; ++j) { /* pad lanes mirror a real row: never updated, never stored */ \
-      e[j] = tp_[R];                                                                            \
-      tp_ += opaque_s(RS);                                                                      \
+    const double2 *tp_ = (const double2 *)(a.temp + (size_t)(bb) * a.state_doubles); /* SGPR base + lane offset */ \
+    _Pragma("unroll") for (int j = 0; j < NR; j += 2) { /* pad lanes mirror a real row: never updated, never stored */ \
+      const double2 v_ = tp_[R];                                                                \
+      e[j] = v_.x;                                                                              \
+      e[j + 1] = v_.y;                                                                          \
+      tp_ += P == kTail ? RS : opaque_s(RS);                                                    \
     }                                                                                           \
   } while (0)
   // ... and so are the building's small inputs: its g table entry, tail rows, ambient
@@ -415,7 +418,8 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       if (lane < kTS) gtab[lane] = nx_g;
       if (P == kPair) // old values of wave 1's first row (its lane 0: column c sits in slot c)
         for (int c = lane; c < NR; c += 64)
-          seamD[kSeamPad + c] = a.temp[(size_t)b * a.state_doubles + (size_t)c * RS + a.rowbase[1]];
+          seamD[kSeamPad + c] =
+              a.temp[(size_t)b * a.state_doubles + (size_t)(c >> 1) * 2 * RS + 2 * a.rowbase[1] + (c & 1)];
       if (P == kTail) {
 #pragma unroll
         for (int t = 0; t < kTailMax; ++t)
@@ -524,11 +528,11 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
         for (int g = 0; g < kZSlots; ++g) zwv[g] = zmap[o + g * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      double *tp = a.temp + (size_t)b * a.state_doubles;
+      double2 *tp = (double2 *)(a.temp + (size_t)b * a.state_doubles);
 #pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        tp[R] = e[j];
-        tp += opaque_s(RS);
+      for (int j = 0; j < NR; j += 2) {
+        tp[R] = make_double2(e[j], e[j + 1]);
+        tp += P == kTail ? RS : opaque_s(RS);
       }
       for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + R] = 0.0;
       __builtin_amdgcn_wave_barrier();
