@@ -98,7 +98,7 @@ struct Dev {
   double *gsum;            // [B] sum of the whole grid after the update
   int *nsw;                // [B] sweeps | converged << 16
   int *next_b;             // next building a sweep workgroup draws (k_pre resets it to sweep_wgs)
-  int sweep_wgs;           // workgroups of the sweep kernel
+  int sweep_wgs;           // first value of next_b: buildings handed out statically (one per workgroup / wavefront)
   // observation layout
   int O, col_ahu, col_blr, col_aux;
   const int *col_zone;

@@ -626,7 +626,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   SB_TRY(alloc_zero(h->next_b, 1));
 #undef SB_TRY
   d.next_b = h->next_b.p;
-  d.sweep_wgs = h->info.workgroups;
+  // first value of the draw counter: register path = workgroups, LDS-grid path = wavefronts
+  d.sweep_wgs = d.reg ? h->info.workgroups : h->info.workgroups * h->info.waves_per_workgroup;
   d.bld = h->bld.p; d.gtabg = h->gtabg.p; d.zsum = h->zsum.p; d.gsum = h->gsum.p; d.nsw = h->nsw.p;
   d.ctab = h->ctab.p; d.czone = h->czone.p; d.zone_off = h->zone_off.p;
   d.zone_cells_l = h->zone_cells_l.p; d.temp = h->temp.p; d.zmean = h->zmean.p;

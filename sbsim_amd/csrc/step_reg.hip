@@ -183,11 +183,9 @@ __device__ __forceinline__ void chunks(double (&e)[NR], const double (&Areg)[NAR
       if (P == kPair) {
         // publish the edge row's new values of this chunk (columns 8*CI-edge_off .. +7)
         const int c0 = 8 * CI - x.edge_off;
-#if !(defined(SB_EXP) && (SB_EXP & 2)) /* timing experiment 2: no seam publication */
         if (c0 + 7 >= 0 && c0 < NR) {
           if (x.edge) publish<NR, P, CI, 0>(e, x.seam_out);
         }
-#endif
       }
       if (P == kPair) {
         // LDS executes a wavefront's instructions in order: whoever sees the counter sees the
@@ -494,12 +492,10 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     for (int it = 0; it < p.iter_limit; ++it) { // simulator.py:348-368
       x.prog_base = it * 32; // the counter only grows within a building's step
       double dm = sweep_reg<NR, P>(e, Areg, x);
-#if !(defined(SB_EXP) && (SB_EXP & 1)) /* timing experiment 1: no tail pass */
       if (P == kTail) {
         __builtin_amdgcn_wave_barrier(); // row 63's last values are in LDS before the scan reads them
         dm = fmax(dm, tail_pass<NR>(a.T, lane, tab, tE, r63, At, tclsw));
       }
-#endif
       double md = wave_max(dm);
       if (P == kPair) {
         double *xd = xchg + 2 * (it & 1); // double-buffered: wave 0 may finish its next sweep early
