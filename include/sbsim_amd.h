@@ -85,16 +85,27 @@ typedef struct sb_params {
   double act_lo[SB_NUM_ACTIONS], act_hi[SB_NUM_ACTIONS]; /* bounded_action_normalizer.py:73-98 */
 } sb_params;
 
-/* Observation vector layout (environment.py:543-553,783-813): columns of device fields in
- * sorted (device_id, field) order, then the auxiliary features. */
+/* Observation vector layout (environment.py:543-553,783-813): the device fields in sorted
+ * (device_id, field) order -- the "source" order -- then the auxiliary features.  Without a
+ * reducer (n_src == 0) source index == output column.  With the optional HistogramReducer
+ * (utils/histogram_reducer.py:136-146,204-471; environment.py:731-777,1032-1071) every source
+ * field is either passed through to an output column or counted into the bins of its
+ * measurement's histogram (over all devices that report it, on the NORMALISED value). */
 typedef struct sb_obs_layout {
-  int32_t n_obs;           /* O */
-  int32_t col_ahu;         /* first column of the air handler's 8 (+1) fields */
-  int32_t col_boiler;      /* first column of the boiler's 3 fields */
-  int32_t col_aux;         /* first column of the SB_NUM_AUX auxiliary features */
-  const int32_t *col_zone; /* [Z] first column of each VAV's 3 fields */
-  const double *mean;      /* [O] StandardScoreObservationNormalizer sample_mean (0 for aux) */
-  const double *sigma;     /* [O] sqrt(sample_variance) (1 for aux); <=0 -> output 0 */
+  int32_t n_obs;           /* O: width of the observation row */
+  int32_t col_ahu;         /* source index of the air handler's first field (8 fields, +1 with weather) */
+  int32_t col_boiler;      /* source index of the boiler's first field (3 fields) */
+  int32_t col_aux;         /* OUTPUT column of the first of the SB_NUM_AUX auxiliary features */
+  const int32_t *col_zone; /* [Z] source index of each VAV's first field (3 fields) */
+  const double *mean;      /* [max(O, n_src)] by source index: StandardScoreObservationNormalizer sample_mean */
+  const double *sigma;     /* same shape: sqrt(sample_variance); <=0 -> output 0 */
+  int32_t n_src;           /* 0: no reducer.  Else the number of device fields (3Z + AHU + boiler) */
+  int32_t n_hist;          /* histogram features */
+  const int32_t *src_dest; /* [n_src] >= 0: output column of a pass-through field; -(k+1): histogram k */
+  const int32_t *hist_col; /* [n_hist] first output column of histogram k (one column per bin) */
+  const int32_t *hist_off; /* [n_hist+1] offsets into hist_bins */
+  const double *hist_bins; /* concatenated ascending bin values */
+  int32_t hist_normalize;  /* HistogramReducer(normalize_reduce=True): counts / number of devices */
 } sb_obs_layout;
 
 /* Host-resolved inputs of one step at simulator time t (all buildings are in lock-step). */

@@ -52,7 +52,9 @@ class Params(C.Structure):
 
 class ObsLayout(C.Structure):
   _fields_ = [("n_obs", C.c_int32), ("col_ahu", C.c_int32), ("col_boiler", C.c_int32),
-              ("col_aux", C.c_int32), ("col_zone", _ip), ("mean", _dp), ("sigma", _dp)]
+              ("col_aux", C.c_int32), ("col_zone", _ip), ("mean", _dp), ("sigma", _dp),
+              ("n_src", C.c_int32), ("n_hist", C.c_int32), ("src_dest", _ip), ("hist_col", _ip),
+              ("hist_off", _ip), ("hist_bins", _dp), ("hist_normalize", C.c_int32)]
 
 
 class StepIn(C.Structure):

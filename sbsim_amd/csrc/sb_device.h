@@ -99,10 +99,13 @@ struct Dev {
   int *nsw;                // [B] sweeps | converged << 16
   int *next_b;             // next building a sweep workgroup draws (k_pre resets it to sweep_wgs)
   int sweep_wgs;           // first value of next_b: buildings handed out statically (one per workgroup / wavefront)
-  // observation layout
+  // observation layout (sb_obs_layout): sources in sorted (device, field) order
   int O, col_ahu, col_blr, col_aux;
   const int *col_zone;
   const double *obs_mean, *obs_sigma;
+  int n_src, n_hist, hist_normalize; // optional HistogramReducer
+  const int *src_dest, *hist_col, *hist_off;
+  const double *hist_bins;
   long long *dbg;          // optional [16] phase time stamps of wave 0's first building
   sb_params p;
 };
@@ -182,12 +185,29 @@ __device__ __forceinline__ int default_control(int mode, double tz, double hsp, 
 
 // ---------------------------------------------------------------- observation row
 // environment.py:873-985 + observation_normalizer.py:68-91: native value -> proto float
-// (fp32) -> (x - mean)/sigma in float64 -> proto float -> float32 observation.
-__device__ __forceinline__ void put_obs(const Dev &a, float *row, int col, double native) {
+// (fp32) -> (x - mean)/sigma in float64 -> proto float -> float32 observation.  `src` is the
+// field's index in sorted (device, field) order.  With a HistogramReducer the normalised
+// value is either passed through or counted into its measurement's histogram
+// (histogram_reducer.py:136-146: clip to [bins[0], bins[-1]], bin i = [bins[i], bins[i+1]),
+// the last bin holds v >= bins[-1]).
+__device__ __forceinline__ void put_obs(const Dev &a, float *row, int src, double native) {
   float x = (float)native;
-  double sg = a.obs_sigma[col];
-  double v = sg > 0.0 ? ((double)x - a.obs_mean[col]) / sg : 0.0;
-  row[col] = (float)v;
+  double sg = a.obs_sigma[src];
+  double v = sg > 0.0 ? ((double)x - a.obs_mean[src]) / sg : 0.0;
+  const float vf = (float)v;
+  const int dest = a.n_src ? a.src_dest[src] : src;
+  if (dest >= 0) {
+    row[dest] = vf;
+    return;
+  }
+  const int k = -dest - 1;
+  const double *bins = a.hist_bins + a.hist_off[k];
+  const int n = a.hist_off[k + 1] - a.hist_off[k];
+  const double m = (double)vf;
+  int idx = 0;
+  for (int j = 1; j < n; ++j)
+    if (m >= bins[j]) idx = j;
+  row[a.hist_col[k] + idx] += 1.0f;
 }
 
 // One building's observation row, written by one thread.  S: the building's scalar state
@@ -196,6 +216,8 @@ __device__ __forceinline__ void put_obs(const Dev &a, float *row, int col, doubl
 __device__ inline void write_obs(const Dev &a, int b, float *obs, const float *aux, double t_amb_obs,
                                  const double *S) {
   float *row = obs + (size_t)b * a.O;
+  for (int k = 0; k < a.n_hist; ++k)
+    for (int j = a.hist_off[k]; j < a.hist_off[k + 1]; ++j) row[a.hist_col[k] + j - a.hist_off[k]] = 0.0f;
   for (int z = 0; z < a.Z; ++z) {
     const int c0 = a.col_zone[z];
     put_obs(a, row, c0 + 0, a.damper[(size_t)b * a.Z + z]); // supply_air_damper_percentage_command
@@ -224,6 +246,14 @@ __device__ inline void write_obs(const Dev &a, int b, float *obs, const float *a
   put_obs(a, row, a.col_blr + 0, S[6]); // heating_request_count
   put_obs(a, row, a.col_blr + 1, S[4]); // supply_water_setpoint
   put_obs(a, row, a.col_blr + 2, S[8]); // supply_water_temperature_sensor
+  if (a.hist_normalize) // counts / devices, in float64 then fp32 like the reference's DataFrame
+    for (int k = 0; k < a.n_hist; ++k) {
+      const int n = a.hist_off[k + 1] - a.hist_off[k];
+      float *h = row + a.hist_col[k];
+      double tot = 0.0;
+      for (int j = 0; j < n; ++j) tot += (double)h[j];
+      for (int j = 0; j < n; ++j) h[j] = (float)((double)h[j] / tot);
+    }
   for (int i = 0; i < SB_NUM_AUX; ++i) row[a.col_aux + i] = aux[i];
 }
 

@@ -431,8 +431,10 @@ struct sb_handle {
   int device = 0, cus = 256;
   sb_launch_info info{};
   DevBuf<uint8_t> cls, tcls;
-  DevBuf<double> ctab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum;
-  DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone, cell_state, nsw, next_b;
+  DevBuf<double> ctab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum,
+      hist_bins;
+  DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone, cell_state, nsw, next_b, src_dest,
+      hist_col, hist_off;
   DevBuf<Bld> bld;
   DevBuf<uint4> zl16;
   DevBuf<int4> sched;
@@ -610,8 +612,36 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.smask = h->smask.p;
   }
   SB_TRY(upload(h->col_zone, obs->col_zone, (size_t)d.Z));
-  SB_TRY(upload(h->obs_mean, obs->mean, (size_t)obs->n_obs));
-  SB_TRY(upload(h->obs_sigma, obs->sigma, (size_t)obs->n_obs));
+  const size_t n_norm = (size_t)std::max(obs->n_obs, obs->n_src);
+  SB_TRY(upload(h->obs_mean, obs->mean, n_norm));
+  SB_TRY(upload(h->obs_sigma, obs->sigma, n_norm));
+  d.n_src = obs->n_src; d.n_hist = obs->n_src ? obs->n_hist : 0; d.hist_normalize = obs->hist_normalize;
+  if (obs->n_src) { // optional HistogramReducer
+    const int n_dev_fields = 3 * d.Z + (params->ahu_has_weather ? 9 : 8) + 3;
+    if (obs->n_src != n_dev_fields || !obs->src_dest || obs->n_hist < 0 ||
+        (obs->n_hist > 0 && (!obs->hist_col || !obs->hist_off || !obs->hist_bins))) {
+      delete h;
+      return fail(SB_ERR_INVALID, "sb_create: inconsistent histogram-reducer layout");
+    }
+    for (int i = 0; i < obs->n_src; ++i)
+      if (obs->src_dest[i] >= obs->n_obs || obs->src_dest[i] < -obs->n_hist) {
+        delete h;
+        return fail(SB_ERR_INVALID, "sb_create: histogram-reducer destination out of range");
+      }
+    for (int k = 0; k < obs->n_hist; ++k) {
+      const int n = obs->hist_off[k + 1] - obs->hist_off[k];
+      if (n < 1 || obs->hist_col[k] < 0 || obs->hist_col[k] + n > obs->n_obs) {
+        delete h;
+        return fail(SB_ERR_INVALID, "sb_create: histogram columns out of range");
+      }
+    }
+    SB_TRY(upload(h->src_dest, obs->src_dest, (size_t)obs->n_src));
+    SB_TRY(upload(h->hist_col, obs->hist_col, (size_t)obs->n_hist));
+    SB_TRY(upload(h->hist_off, obs->hist_off, (size_t)obs->n_hist + 1));
+    SB_TRY(upload(h->hist_bins, obs->hist_bins, (size_t)(obs->n_hist ? obs->hist_off[obs->n_hist] : 0)));
+    d.src_dest = h->src_dest.p; d.hist_col = h->hist_col.p; d.hist_off = h->hist_off.p;
+    d.hist_bins = h->hist_bins.p;
+  }
   SB_TRY(alloc_zero(h->zmean, (size_t)d.B * d.Z));
   SB_TRY(alloc_zero(h->zair, (size_t)d.B * d.Z));
   SB_TRY(alloc_zero(h->damper, (size_t)d.B * d.Z));

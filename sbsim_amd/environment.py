@@ -191,6 +191,39 @@ def observation_field_names(zone_names: Sequence[str], ahu_has_weather: bool,
   return names, col_ahu, col_blr, col_zone, col_aux
 
 
+def histogram_reducer_layout(source_names: Sequence[str],
+                             histogram_parameters: Sequence[Tuple[str, Sequence[float]]]):
+  """Output layout of the observation HistogramReducer (utils/histogram_reducer.py:204-471) in
+  the field order of ``Environment._get_observation_spec_histogram_reducer``
+  (environment.py:731-777): devices sorted by id, fields sorted; a reduced measurement
+  contributes one column per bin (``<measurement>_h_<bin:.2f>``) where it is first met, every
+  other field passes through.  ``source_names`` are the device fields ("device/field") in that
+  sorted order.  Returns (names, src_dest, hist_col, hist_off, hist_bins)."""
+  bins = {}
+  for name, values in histogram_parameters:
+    b = [float(v) for v in values]
+    if len(b) < 1 or any(b[i] >= b[i + 1] for i in range(len(b) - 1)):
+      raise ValueError(f"histogram bins of {name} must be ascending")
+    bins[name] = b
+  names: list = []
+  src_dest = [0] * len(source_names)
+  feature_index, hist_col, hist_off, hist_bins = {}, [], [0], []
+  for i, full in enumerate(source_names):
+    _, meas = full.split("/", 1)
+    if meas in bins:
+      if meas not in feature_index:
+        feature_index[meas] = len(hist_col)
+        hist_col.append(len(names))
+        hist_bins += bins[meas]
+        hist_off.append(len(hist_bins))
+        names += [f"{meas}_h_{v:.2f}" for v in bins[meas]]
+      src_dest[i] = -(feature_index[meas] + 1)
+    else:
+      src_dest[i] = len(names)
+      names.append(full)
+  return names, src_dest, hist_col, hist_off, hist_bins
+
+
 class BatchedSimulator:
   """Thin owner of the C-ABI handle: B building instances of one floor plan on one GPU.
 
@@ -200,7 +233,9 @@ class BatchedSimulator:
   def __init__(self, plan: FloorPlan, config: SimConfig, n_buildings: int, h_conv: float,
                device: int = 0,
                observation_normalization: Optional[Mapping[str, Tuple[float, float]]] = None,
-               zone_names: Optional[Sequence[str]] = None, orientation: str = "auto"):
+               zone_names: Optional[Sequence[str]] = None, orientation: str = "auto",
+               histogram_parameters: Optional[Sequence[Tuple[str, Sequence[float]]]] = None,
+               normalize_reduce: bool = False):
     self._lib = _ffi.load()
     if not torch.cuda.is_available():
       raise _ffi.SbsimError("sbsim_amd needs a HIP device (MI355X); there is no CPU path")
@@ -210,8 +245,18 @@ class BatchedSimulator:
       raise ValueError("orientation must be 'auto', 'rows' or 'columns'")
     self.Z, self.H, self.W = plan.n_zones, H0, W0
     zone_names = list(zone_names or plan.zone_names or [f"room_{i + 1}" for i in range(self.Z)])
-    (self.field_names, col_ahu, col_blr, col_zone, col_aux) = observation_field_names(
+    (source_names, col_ahu, col_blr, col_zone, n_src) = observation_field_names(
         zone_names, config.ahu_has_weather_sensor)
+    aux_names, source_names = source_names[n_src:], source_names[:n_src]
+    # optional HistogramReducer (environment.py:731-777,1032-1071): device-side binning
+    if histogram_parameters:
+      out_names, src_dest, hist_col, hist_off, hist_bins = histogram_reducer_layout(
+          source_names, histogram_parameters)
+    else:
+      out_names, src_dest, hist_col, hist_off, hist_bins = list(source_names), None, [], [0], []
+    col_aux = len(out_names)
+    self.field_names = out_names + list(aux_names)
+    self.source_names = source_names
     self.O = len(self.field_names)
 
     def describe(p: FloorPlan):
@@ -241,17 +286,26 @@ class BatchedSimulator:
     self.transposed = best[1]
     self.compiled, keep, pd_, _ = best[2]
     norm = dict(observation_normalization or {})
-    mean = np.zeros(self.O)
-    sigma = np.ones(self.O)
-    for i, name in enumerate(self.field_names[:col_aux]):
+    mean = np.zeros(max(self.O, n_src))     # by source index
+    sigma = np.ones(max(self.O, n_src))
+    for i, name in enumerate(source_names):
       mu, var = norm.get(name.split("/", 1)[1], (0.0, 1.0))
       # ContinuousVariableInfo fields are proto floats (smart_control_normalization.proto)
       mu, var = float(np.float32(mu)), float(np.float32(var))
       mean[i] = mu
       sigma[i] = math.sqrt(var) if var > 0.0 else 0.0
     self._keep = dict(keep, colz=np.asarray(col_zone, dtype=np.int32), mean=mean, sigma=sigma)
-    ol = _ffi.ObsLayout(self.O, col_ahu, col_blr, col_aux, self._keep["colz"].ctypes.data_as(_ffi._ip),
-                        mean.ctypes.data_as(_ffi._dp), sigma.ctypes.data_as(_ffi._dp))
+    self._keep.update(src_dest=np.asarray(src_dest if src_dest is not None else [0], dtype=np.int32),
+                      hist_col=np.asarray(hist_col or [0], dtype=np.int32),
+                      hist_off=np.asarray(hist_off, dtype=np.int32),
+                      hist_bins=np.asarray(hist_bins or [0.0], dtype=np.float64))
+    kp = self._keep
+    ol = _ffi.ObsLayout(self.O, col_ahu, col_blr, col_aux, kp["colz"].ctypes.data_as(_ffi._ip),
+                        mean.ctypes.data_as(_ffi._dp), sigma.ctypes.data_as(_ffi._dp),
+                        n_src if src_dest is not None else 0, len(hist_col),
+                        kp["src_dest"].ctypes.data_as(_ffi._ip), kp["hist_col"].ctypes.data_as(_ffi._ip),
+                        kp["hist_off"].ctypes.data_as(_ffi._ip), kp["hist_bins"].ctypes.data_as(_ffi._dp),
+                        1 if normalize_reduce else 0)
     params = config.to_params()
     h = C.c_void_p()
     with torch.cuda.device(self.device):
@@ -344,7 +398,9 @@ class BatchedEnvironment:
                num_days_in_episode: float = 3, discount_factor: float = 1.0, device: int = 0,
                observation_normalization: Optional[Mapping[str, Tuple[float, float]]] = None,
                occupancy_normalization_constant: float = 0.0, holiday_calendar="us",
-               electricity_energy_cost=None, natural_gas_energy_cost=None, collect_info: bool = False):
+               electricity_energy_cost=None, natural_gas_energy_cost=None, collect_info: bool = False,
+               observation_histogram_parameters: Optional[Sequence[Tuple[str, Sequence[float]]]] = None,
+               normalize_reduce: bool = False):
     if discount_factor <= 0 or discount_factor > 1:
       raise ValueError("Discount factor must be in (0,1]")   # environment.py:454-455
     self.config = config or SimConfig.sb1()
@@ -360,7 +416,9 @@ class BatchedEnvironment:
     self._occ_norm = float(occupancy_normalization_constant)
     h_conv = self.weather.get_air_convection_coefficient(self._start_timestamp)
     self.sim = BatchedSimulator(plan, self.config, n_buildings, h_conv, device,
-                                observation_normalization)
+                                observation_normalization,
+                                histogram_parameters=observation_histogram_parameters,
+                                normalize_reduce=normalize_reduce)
     self.batch_size = self.sim.B
     self._step_interval = dt.timedelta(seconds=self.config.time_step_sec)
     # environment.py:427-435
