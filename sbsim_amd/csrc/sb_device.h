@@ -97,8 +97,8 @@ struct Dev {
   double *zsum;            // [B][Z] post-update zone sums
   double *gsum;            // [B] sum of the whole grid after the update
   int *nsw;                // [B] sweeps | converged << 16
-  int *next_b;             // next building a sweep workgroup draws (k_pre resets it to sweep_wgs)
-  int sweep_wgs;           // first value of next_b: buildings handed out statically (one per workgroup / wavefront)
+  int *next_b;             // draw counter of the sweep kernel (zeroed before every launch)
+  int sweep_wgs;           // buildings handed out statically (one per workgroup / wavefront) before the draws
   // observation layout (sb_obs_layout): sources in sorted (device, field) order
   int O, col_ahu, col_blr, col_aux;
   const int *col_zone;

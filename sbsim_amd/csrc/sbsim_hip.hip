@@ -139,7 +139,6 @@ __global__ void k_copy_scalars(Dev a, double *out) {
 
 // Per-building algebra before / after the sweep kernel: one thread per building (sb_device.h).
 __global__ void __launch_bounds__(64) k_pre(Dev a, StepArgs s) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_b = a.sweep_wgs;
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
     pre_building(a, s, b);
 }
@@ -656,7 +655,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   SB_TRY(alloc_zero(h->next_b, 1));
 #undef SB_TRY
   d.next_b = h->next_b.p;
-  // first value of the draw counter: register path = workgroups, LDS-grid path = wavefronts
+  // buildings handed out statically before the draw counter: register path = workgroups, LDS-grid path = wavefronts
   d.sweep_wgs = d.reg ? h->info.workgroups : h->info.workgroups * h->info.waves_per_workgroup;
   d.bld = h->bld.p; d.gtabg = h->gtabg.p; d.zsum = h->zsum.p; d.gsum = h->gsum.p; d.nsw = h->nsw.p;
   d.ctab = h->ctab.p; d.czone = h->czone.p; d.zone_off = h->zone_off.p;
@@ -727,6 +726,7 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
     SB_HIP(hipGetLastError());
   }
   if (phases & SB_PHASE_SWEEP) {
+    SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream)); // the sweep kernel's draw counter
     const int e = d.reg ? launch_sweep_reg(d, h->cus, (hipStream_t)stream)
                         : launch_sweep_lds(d, h->info.workgroups, h->info.waves_per_workgroup,
                                            (size_t)h->info.lds_bytes_per_workgroup, (hipStream_t)stream);

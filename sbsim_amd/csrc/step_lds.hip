@@ -318,8 +318,8 @@ __global__ void __launch_bounds__(256) k_sweep_lds(Dev a) {
 
   const sb_params &p = a.p;
 #define SB_STAMP(i) do { if (a.dbg && b == 0 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
-  // after its first building a wavefront draws the next one from a device counter (k_pre
-  // resets it to the number of wavefronts): buildings need different numbers of sweeps
+  // after its first building a wavefront draws the next one from a device counter (zeroed
+  // before every launch): buildings need different numbers of sweeps
   for (int b = wave; b < a.B;) {
     SB_STAMP(0);
     double *T = a.temp + (size_t)b * a.Np + kPad; // T[-kPad..-1] and T[N..N+kPad) are zero
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) k_sweep_lds(Dev a) {
     SB_STAMP(8);
     if (a.dbg && b == 0 && lane == 0) a.dbg[9] = n_sweeps;
     int nb = 0;
-    if (lane == 0) nb = atomicAdd(a.next_b, 1);
+    if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
     b = __builtin_amdgcn_readfirstlane(nb);
   }
 #undef SB_STAMP

@@ -392,12 +392,12 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   }
   // Buildings need different numbers of sweeps, so a static split would leave the last
   // workgroups running alone: after its first building a workgroup draws the next one from a
-  // device counter (k_pre resets it to the grid size).  The two-wavefront mode keeps the
+  // device counter (zeroed before every launch).  The two-wavefront mode keeps the
   // static stride (both waves must agree on the building without a round trip through LDS).
   auto draw = [&](int cur) {
     if (P == kPair) return cur + (int)gridDim.x;
     int nb = 0;
-    if (lane == 0) nb = atomicAdd(a.next_b, 1);
+    if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
     return __builtin_amdgcn_readfirstlane(nb);
   };
   int iter = 0;
@@ -627,7 +627,7 @@ int launch_sweep_reg(const Dev &d, int cus, hipStream_t stream) {
   const Variant *v = find_variant(d.NR, d.P);
   if (!v) return (int)hipErrorInvalidValue;
   (void)cus;
-  v->launch(d, d.sweep_wgs, stream); // == min(B, CUs * wg_per_cu); k_pre resets the draw counter to it
+  v->launch(d, d.sweep_wgs, stream); // == min(B, CUs * wg_per_cu)
   return (int)hipGetLastError();
 }
 
