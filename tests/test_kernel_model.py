@@ -44,3 +44,55 @@ def test_skewed_class_table_sweep_matches_oracle(name):
   got2, n2 = fm.fd_timestep(g["prev"], float(g["t_amb"]), qz, 0.01, 60)
   assert n2 == n_ref
   assert np.abs(got2 - ref).max() < 1e-10
+
+
+# ---- register-resident sweep (step_reg.hip): schedule, tail recurrence, seam protocol ----
+def _r9_like(rooms, room_shape):
+  from sbsim_amd.floorplan import Materials, rectangular_floor_plan
+  return FloorPlan.from_file_input(rectangular_floor_plan(rooms, room_shape), Materials.sb1(), 10.0, 300.0)
+
+
+@pytest.mark.parametrize("rooms,room_shape,transpose,mode,schedule", [
+    ((2, 2), (5, 9), False, 1, "tight"),      # 15x23 inside the ring: one wavefront, 32 slots
+    ((2, 3), (9, 10), False, 1, "tight"),     # 23x36: one wavefront, 66 slots
+    ((3, 3), (20, 30), False, 3, "tight"),    # R9, lanes = rows: 64 rows + 2 tail rows, 96 slots
+    ((2, 3), (30, 30), False, 3, "tight"),    # one tail row
+    ((3, 3), (20, 30), True, 2, "tight"),     # R9, lanes = columns: two wavefronts, wave 1 as early as allowed
+    ((3, 3), (20, 30), True, 2, "late"),      # ... and as late as possible: same grid
+    ((2, 5), (30, 12), True, 2, "tight"),     # uneven split
+])
+def test_register_sweep_schedule_matches_oracle(rooms, room_shape, transpose, mode, schedule):
+  from tests.kernel_model import RegSweepModel
+  fp0 = _r9_like(rooms, room_shape)
+  fp = fp0.transposed() if transpose else fp0
+  dt, h = 300.0, 100.0
+  cp = fp.compile(dt, h)
+  m = RegSweepModel(cp)
+  assert m.mode == mode
+  rs = np.random.RandomState(5)
+  H, W = fp.shape
+  prev = np.clip(293.0 + 1.5 * rs.randn(H, W), 285.0, 300.0)
+  qz = rs.uniform(-400.0, 900.0, size=cp.Z)
+  q = np.zeros((H, W))
+  for z, cells in enumerate(fp.zone_cell_lists()):
+    q.reshape(-1)[cells] = qz[z] * fp.diffusers.reshape(-1)[cells]
+  plan = orc.OraclePlan(fp.conductivity, fp.density, fp.heat_capacity, fp.exterior_space,
+                        fp.zone_cell_lists(), fp.diffusers, fp.cv_size_cm, fp.floor_height_cm)
+  ref, n_ref, _ = orc.fd_timestep(plan, prev, q, 279.5, h, dt, 0.05, 40)
+  got, n_got = m.fd_timestep(prev, 279.5, qz, 0.05, 40, schedule=schedule)
+  assert n_got == n_ref and n_ref >= 3
+  assert np.abs(got - ref).max() < 1e-10
+
+
+def test_seam_lag_is_tight():
+  """One chunk less lag and wave 1 would read a seam value before it is published."""
+  from tests import kernel_model as km
+  fp = _r9_like((3, 3), (20, 30)).transposed()
+  cp = fp.compile(300.0, 100.0)
+  m = km.RegSweepModel(cp)
+  assert m.mode == 2 and m.lag == km.seam_lag(m.lw[0])
+  H, W = fp.shape
+  prev = np.full((H, W), 294.0)
+  m.lag -= 1
+  with pytest.raises(AssertionError, match="before wave 0 published"):
+    m.fd_timestep(prev, 280.0, np.zeros(cp.Z), 0.05, 2, schedule="tight")
