@@ -330,6 +330,7 @@ def _oracle_twin(plan, cfg, init_flat):
     ((2, 3), (20, 30), "rows", 1),     # 45x96 -> registers, 1 wave, 96 slots
     ((2, 5), (30, 12), "columns", 1),  # transposed 68x65 -> registers, 2 waves (uneven split), 66 slots
     ((2, 3), (30, 30), "rows", 1),     # 65x96 -> registers, 1 wave + ONE tail row
+    ((4, 5), (10, 8), "rows", 1),      # 47x48, 20 zones -> registers, zone reduce in two 16-zone passes
     ((4, 2), (30, 17), "columns", 0),  # the same family on the LDS-grid kernel, lanes = columns
 ])
 def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, monkeypatch):
