@@ -67,7 +67,7 @@ struct Dev {
   int T;                   // mode 3: rows 64..64+T-1 are finished by the tail scan (T <= 2)
   int state_doubles;       // doubles of HBM state per building
   const uint8_t *tcls;     // mode 3: [T][NR] classes of the tail cells
-  int RS;                  // rows of the trimmed grid; HBM state [NR/2][RS][2]
+  int RS;                  // rows of the trimmed grid = row stride of the HBM state [NR][RS]
   int AS;                  // row stride of A in LDS (odd when it fits: bank-conflict free)
   int ZRS;                 // row stride of the zone-sum scratch [Z+1][ZRS] that aliases A (RS | 1)
   int Ws;                  // trimmed width
@@ -84,7 +84,7 @@ struct Dev {
   const int *cell_state;   // [N] >= 0: index into the building's state; < 0: -(ring index + 1)
   double *ring;            // [B][n_ring] exterior-space cells as set by sb_reset (until the first step)
   // state
-  double *temp;            // LDS-grid kernel: [B][Np], grid at +kPad; register path: [B][NR/2][RS][2] (+ [T][NR])
+  double *temp;            // LDS-grid kernel: [B][Np], grid at +kPad; register path: [B][NR][RS] (+ [T][NR])
   double *zmean;           // [B][Z] zone means of the current grid
   double *zair;            // [B][Z] Vav._zone_air_temperature
   double *damper;          // [B][Z]

@@ -337,8 +337,7 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
       if (P == 3 && R >= 64) { r.cell_state[x * W + y] = NR * 64 + (R - 64) * NR + col; continue; }
       const int w = (P == 2 && R >= r.lw[0]) ? 1 : 0;
       const int lp = R - r.rowbase[w];
-      const int slot = (col + lp) % NR; // state layout [NR/2][RS][2]
-      r.cell_state[x * W + y] = (slot >> 1) * 2 * RS + 2 * R + (slot & 1);
+      r.cell_state[x * W + y] = ((col + lp) % NR) * RS + R; // state layout [NR][RS]
     }
   r.ok = true;
 }

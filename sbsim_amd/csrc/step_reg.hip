@@ -23,9 +23,8 @@
 // barrier per chunk costs ~600 cycles on gfx950, a satisfied flag check nothing.  The DPP
 // `old` operand carries the seam value into the edge lane.
 //
-// HBM state of a building: [NR/2][RS][2] float64: slot pairs (2k, 2k+1) of a row are adjacent, so
-// one 16-byte access per lane moves two registers and a wavefront instruction moves a coalesced
-// 16*RS-byte row; pad cells 0.
+// HBM state of a building: [NR][RS] float64, slot-major (one coalesced 8*RS-byte row per
+// register), pad cells 0.
 #include "sb_device.h"
 
 namespace sb {
@@ -357,16 +356,24 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
 
 // developer aid: cycle stamps of workgroup 0's 11th building (steady state, not the cold start)
 #define SB_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && iter == 10 && w == 0 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+  // The lane's class bytes by slot (A pass) do not depend on the building: loaded once, they
+  // live in AGPRs between their uses (the allocator spills what the sweep does not touch)
+  // instead of costing a global round trip per building.  (The two-wavefront mode has no
+  // registers to spare and reloads them.)
+  unsigned long long amapw[kASlots];
+  if (P != kPair) {
+#pragma unroll
+    for (int g = 0; g < kASlots; ++g) amapw[g] = amap[g * 64];
+  }
+
   // The lane's row of the NEXT building is loaded while this building's zone sums are reduced
   // (its registers are free once the row is stored), so the loop never waits on HBM latency.
   double e[NR];
 #define SB_LOAD_ROW(bb)                                                                         \
   do {                                                                                          \
-    const double2 *tp_ = (const double2 *)(a.temp + (size_t)(bb) * a.state_doubles); /* SGPR base + lane offset */ \
-    _Pragma("unroll") for (int j = 0; j < NR; j += 2) { /* pad lanes mirror a real row: never updated, never stored */ \
-      const double2 v_ = tp_[R];                                                                \
-      e[j] = v_.x;                                                                              \
-      e[j + 1] = v_.y;                                                                          \
+    const double *tp_ = a.temp + (size_t)(bb) * a.state_doubles; /* wave-uniform: SGPR base + lane offset */ \
+    _Pragma("unroll") for (int j = 0; j < NR; ++j) { /* pad lanes mirror a real row: never updated, never stored */ \
+      e[j] = tp_[R];                                                                            \
       tp_ += P == kTail ? RS : opaque_s(RS);                                                    \
     }                                                                                           \
   } while (0)
@@ -416,8 +423,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       if (lane < kTS) gtab[lane] = nx_g;
       if (P == kPair) // old values of wave 1's first row (its lane 0: column c sits in slot c)
         for (int c = lane; c < NR; c += 64)
-          seamD[kSeamPad + c] =
-              a.temp[(size_t)b * a.state_doubles + (size_t)(c >> 1) * 2 * RS + 2 * a.rowbase[1] + (c & 1)];
+          seamD[kSeamPad + c] = a.temp[(size_t)b * a.state_doubles + (size_t)c * RS + a.rowbase[1]];
       if (P == kTail) {
 #pragma unroll
         for (int t = 0; t < kTailMax; ++t)
@@ -447,12 +453,12 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     double Areg[kNAR];
     Areg[0] = 0.0;
     if (rowvalid) {
-      unsigned long long cw[kASlots]; // all class words first: one memory latency, not kASlots
-      {
+      if (P == kPair) {
         const int o = opaque(0);
 #pragma unroll
-        for (int g = 0; g < kASlots; ++g) cw[g] = amap[o + g * 64];
+        for (int g = 0; g < kASlots; ++g) amapw[g] = amap[o + g * 64];
       }
+      const unsigned long long(&cw)[kASlots] = amapw;
       double *Aw = A + (size_t)R * a.AS;
       // groups of 8, software-pipelined: the table reads of group g+1 are issued before the
       // A values of group g are written (the compiler cannot prove that A and the tables do
@@ -524,10 +530,12 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
         for (int g = 0; g < kZSlots; ++g) zwv[g] = zmap[o + g * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      double2 *tp = (double2 *)(a.temp + (size_t)b * a.state_doubles);
+      // one 8-byte store per register straight from e[]: a wider store would have to be
+      // assembled in a temporary that the next store overwrites (measured 6x slower)
+      double *tp = a.temp + (size_t)b * a.state_doubles;
 #pragma unroll
-      for (int j = 0; j < NR; j += 2) {
-        tp[R] = make_double2(e[j], e[j + 1]);
+      for (int j = 0; j < NR; ++j) {
+        tp[R] = e[j];
         tp += P == kTail ? RS : opaque_s(RS);
       }
       for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + R] = 0.0;
