@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 2
+#define SB_ABI_VERSION 3
 #define SB_NUM_ACTIONS 2   /* boiler supply_water_setpoint, AHU supply_air_heating_temperature_setpoint */
 #define SB_NUM_AUX 7       /* hod cos/sin, dow cos/sin, comfort_now, comfort_soon, num_occupants */
 #define SB_INFO_STRIDE 8   /* floats per building in the optional info output */
@@ -113,6 +113,11 @@ typedef struct sb_step_in {
   double t_amb_now;        /* weather.get_current_temp(t): drives the sweep and the AHU */
   double t_amb_next;       /* weather.get_current_temp(t+dt): reward_info / observation */
   const double *t_amb_dev; /* optional DEVICE [B][2] per-building (now, next); overrides */
+  /* optional per-building sinusoid weather generated on the device (weather_controller.py:93-123):
+   * T_b = f * (high_b - low_b) + low_b with the wave-uniform factor f = 0.5*(sin(rad(t)) + 1);
+   * overrides t_amb_now/next and t_amb_dev */
+  const double *weather_lohi_dev; /* DEVICE [B][2] (low, high) in force at this step */
+  double weather_f_now, weather_f_next;
   int32_t comfort_now;     /* schedule.is_comfort_mode(t) */
   int32_t comfort_prev;    /* is_comfort_mode(previous thermostat timestamp); -1 = none */
   int32_t comfort_next;    /* is_comfort_mode(t+dt): setpoint window seen by the reward */
@@ -150,9 +155,10 @@ int sb_get_launch_info(const sb_handle *h, sb_launch_info *out);
  * devices <- constructor values.  Thermostat modes are NOT restored (vav.py:93-99). */
 int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *stream);
 
-/* request_observations() at the current simulator time: writes obs_dev [B][O] fp32. */
-int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, float *obs_dev,
-               void *stream);
+/* request_observations() at the current simulator time: writes obs_dev [B][O] fp32.
+ * t_amb_dev: optional DEVICE [B] per-building ambient temperature (overrides t_amb). */
+int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
+               float *obs_dev, void *stream);
 
 /* One Environment._step for every building.  actions_dev [B][2] fp32 in [-1,1] (or NULL
  * when in->has_action == 0); obs_dev [B][O] fp32; reward_dev [B] fp32; info_dev optional

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("SBSIM_LIB") or os.path.join(_HERE, "libsbsim_amd.so")
 
 SB_NUM_ACTIONS = 2
 SB_NUM_AUX = 7
-SB_ABI_VERSION = 2   # include/sbsim_amd.h
+SB_ABI_VERSION = 3   # include/sbsim_amd.h
 SB_INFO_STRIDE = 8
 SB_NUM_SCALARS = 16
 
@@ -59,6 +59,7 @@ class ObsLayout(C.Structure):
 
 class StepIn(C.Structure):
   _fields_ = [("t_amb_now", C.c_double), ("t_amb_next", C.c_double), ("t_amb_dev", C.c_void_p),
+              ("weather_lohi_dev", C.c_void_p), ("weather_f_now", C.c_double), ("weather_f_next", C.c_double),
               ("comfort_now", C.c_int32), ("comfort_prev", C.c_int32),
               ("comfort_next", C.c_int32), ("has_action", C.c_int32),
               ("occupancy", C.c_double), ("occupancy_dev", C.c_void_p),
@@ -106,7 +107,7 @@ def load():
   L.sb_destroy.restype = None
   L.sb_get_launch_info.argtypes = [vp, C.POINTER(LaunchInfo)]
   L.sb_reset.argtypes = [vp, C.c_double, vp, vp]
-  L.sb_observe.argtypes = [vp, C.POINTER(C.c_float), C.c_double, vp, vp]
+  L.sb_observe.argtypes = [vp, C.POINTER(C.c_float), C.c_double, vp, vp, vp]
   L.sb_step.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp]
   L.sb_step_phases.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp, C.c_int32]
   for name in ("sb_get_temps", "sb_get_zone_temps", "sb_get_scalars", "sb_get_modes",

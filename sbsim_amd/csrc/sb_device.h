@@ -279,8 +279,14 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   const double *S = a.scal + (size_t)b * kNScal;
   const size_t zb = (size_t)b * a.Z;
   Bld v;
-  v.t_now = in.t_amb_dev ? in.t_amb_dev[2 * b] : in.t_amb_now;
-  v.t_next = in.t_amb_dev ? in.t_amb_dev[2 * b + 1] : in.t_amb_next;
+  if (in.weather_lohi_dev) { // weather_controller.py:119-121, per building; no fma: the reference's two roundings
+    const double lo = in.weather_lohi_dev[2 * b], hi = in.weather_lohi_dev[2 * b + 1];
+    v.t_now = __dadd_rn(__dmul_rn(in.weather_f_now, hi - lo), lo);
+    v.t_next = __dadd_rn(__dmul_rn(in.weather_f_next, hi - lo), lo);
+  } else {
+    v.t_now = in.t_amb_dev ? in.t_amb_dev[2 * b] : in.t_amb_now;
+    v.t_next = in.t_amb_dev ? in.t_amb_dev[2 * b + 1] : in.t_amb_next;
+  }
   v.heat_sp = S[0]; v.cool_sp = S[1]; v.blr_sp = S[4];
   if (in.has_action) { // bounded_action_normalizer.py:73-98, then the proto float field
     const double a0 = (double)s.actions[2 * b], a1 = (double)s.actions[2 * b + 1];

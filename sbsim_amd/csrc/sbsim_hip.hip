@@ -103,10 +103,10 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps) {
 }
 
 __global__ void k_observe(Dev a, float *obs, float aux0, float aux1, float aux2, float aux3,
-                          float aux4, float aux5, float aux6, double t_amb) {
+                          float aux4, float aux5, float aux6, double t_amb, const double *t_amb_b) {
   const float aux[SB_NUM_AUX] = {aux0, aux1, aux2, aux3, aux4, aux5, aux6};
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
-    write_obs(a, b, obs, aux, t_amb, a.scal + (size_t)b * kNScal);
+    write_obs(a, b, obs, aux, t_amb_b ? t_amb_b[b] : t_amb, a.scal + (size_t)b * kNScal);
 }
 
 // building.temp in the caller's row-major layout, whichever state layout the handle uses.
@@ -701,12 +701,13 @@ int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *s
   return SB_OK;
 }
 
-int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, float *obs_dev, void *stream) {
+int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
+               float *obs_dev, void *stream) {
   if (!h || !aux || !obs_dev) return fail(SB_ERR_INVALID, "sb_observe: null argument");
   SB_HIP(hipSetDevice(h->device));
   const int blocks = std::max(1, std::min((h->d.B + 63) / 64, 4096));
   hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->d, obs_dev, aux[0],
-                     aux[1], aux[2], aux[3], aux[4], aux[5], aux[6], t_amb);
+                     aux[1], aux[2], aux[3], aux[4], aux[5], aux[6], t_amb, t_amb_dev);
   SB_HIP(hipGetLastError());
   return SB_OK;
 }

@@ -343,11 +343,17 @@ class BatchedSimulator:
     t0 = self.config.initial_temp if initial_temp is None else float(initial_temp)
     _ffi.check(self._lib.sb_reset(self._h, t0, ptr, self._stream()), "sb_reset")
 
-  def observe(self, aux: Sequence[float], t_amb: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+  def observe(self, aux: Sequence[float], t_amb, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """t_amb: one ambient temperature, or a float64 [B] device tensor (per-building weather)."""
     out = out if out is not None else torch.empty((self.B, self.O), dtype=torch.float32, device=self.tdev)
     a = (C.c_float * _ffi.SB_NUM_AUX)(*[float(x) for x in aux])
-    _ffi.check(self._lib.sb_observe(self._h, a, float(t_amb), C.c_void_p(out.data_ptr()), self._stream()),
-               "sb_observe")
+    per_b = None
+    if isinstance(t_amb, torch.Tensor):
+      if t_amb.dtype != torch.float64 or tuple(t_amb.shape) != (self.B,):
+        raise ValueError("per-building t_amb must be a float64 [B] tensor")
+      per_b, t_amb = C.c_void_p(t_amb.contiguous().data_ptr()), 0.0
+    _ffi.check(self._lib.sb_observe(self._h, a, float(t_amb), per_b, C.c_void_p(out.data_ptr()),
+                                    self._stream()), "sb_observe")
     return out
 
   def step(self, actions: Optional[torch.Tensor], step_in: _ffi.StepIn, obs: torch.Tensor,
@@ -420,6 +426,12 @@ class BatchedEnvironment:
                                 histogram_parameters=observation_histogram_parameters,
                                 normalize_reduce=normalize_reduce)
     self.batch_size = self.sim.B
+    self._weather_lohi = None
+    if isinstance(self.weather, host_inputs.BatchedSinusoidWeather):
+      if self.weather.low.shape[0] != self.batch_size:
+        raise ValueError("BatchedSinusoidWeather needs one (low, high) pair per building")
+      self._weather_lohi = torch.tensor(np.stack([self.weather.low, self.weather.high], axis=1),
+                                        dtype=torch.float64, device=self.sim.tdev).contiguous()
     self._step_interval = dt.timedelta(seconds=self.config.time_step_sec)
     # environment.py:427-435
     self._num_timesteps_in_episode = int(dt.timedelta(days=num_days_in_episode) / self._step_interval)
@@ -480,8 +492,12 @@ class BatchedEnvironment:
   def make_step_in(self, ts: dt.datetime, has_action: bool = True) -> _ffi.StepIn:
     nxt = ts + self._step_interval
     si = _ffi.StepIn()
-    si.t_amb_now = self.weather.get_current_temp(ts)
-    si.t_amb_next = self.weather.get_current_temp(nxt)
+    if isinstance(self.weather, host_inputs.BatchedSinusoidWeather):   # per-building weather, on the device
+      si.weather_lohi_dev = self._weather_lohi.data_ptr()
+      si.weather_f_now, si.weather_f_next = self.weather.factor(ts), self.weather.factor(nxt)
+    else:
+      si.t_amb_now = self.weather.get_current_temp(ts)
+      si.t_amb_next = self.weather.get_current_temp(nxt)
     si.comfort_now = int(self.schedule.is_comfort_mode(ts))
     si.comfort_prev = (-1 if self._prev_thermostat_ts is None
                        else int(self.schedule.is_comfort_mode(self._prev_thermostat_ts)))
@@ -504,7 +520,11 @@ class BatchedEnvironment:
     self._episode_count += 1
     self._step_count = 0
     self._needs_reset = False
-    self.sim.observe(self._aux(self._now), self.weather.get_current_temp(self._now), self._obs)
+    if isinstance(self.weather, host_inputs.BatchedSinusoidWeather):
+      t_amb = torch.tensor(self.weather.temps(self._now), dtype=torch.float64, device=self.sim.tdev)
+    else:
+      t_amb = self.weather.get_current_temp(self._now)
+    self.sim.observe(self._aux(self._now), t_amb, self._obs)
     first = torch.full((self.batch_size,), STEP_FIRST, dtype=torch.int32, device=self.sim.tdev)
     return TimeStep(first, self._zero, torch.ones_like(self._discount), self._obs)
 

@@ -89,6 +89,37 @@ class WeatherController:
     return self.convection_coefficient
 
 
+class BatchedSinusoidWeather:
+  """One sinusoid WeatherController per building (per-building low / high bounds): the same
+  formula as ``WeatherController.get_current_temp`` (weather_controller.py:93-123),
+  ``T_b = 0.5*(sin(rad)+1) * (high_b - low_b) + low_b``.  The time-only factor is computed on
+  the host, the per-building temperatures on the device (sb_step_in.weather_lohi_dev), so no
+  per-building host work is left in a step.  Special days are not modelled."""
+
+  def __init__(self, low_temps, high_temps, convection_coefficient: float = 12.0):
+    import numpy as np
+    self.low = np.ascontiguousarray(low_temps, dtype=np.float64)
+    self.high = np.ascontiguousarray(high_temps, dtype=np.float64)
+    if self.low.shape != self.high.shape or self.low.ndim != 1:
+      raise ValueError("low_temps and high_temps must be 1-D arrays of the same length")
+    if (self.low > self.high).any():
+      raise ValueError("default_low_temp cannot be greater than default_high_temp.")
+    self.convection_coefficient = convection_coefficient
+    self._one = WeatherController(0.0, 1.0)
+
+  def factor(self, timestamp) -> float:
+    """0.5*(sin(rad(t))+1): what a (low=0, high=1) controller returns."""
+    return self._one.get_current_temp(timestamp)
+
+  def temps(self, timestamp):
+    """[B] float64 ambient temperatures, bit-identical to B separate WeatherControllers."""
+    f = self.factor(timestamp)
+    return f * (self.high - self.low) + self.low
+
+  def get_air_convection_coefficient(self, timestamp) -> float:
+    return self.convection_coefficient
+
+
 class ReplayWeatherController:
   """Linear interpolation of an hourly ``Time,TempF`` CSV
   (simulator/weather_controller.py:166-218)."""

@@ -256,6 +256,62 @@ def test_per_building_weather_and_per_zone_occupancy():
   assert len(set(np.round(grid[:, 0, 0], 6))) == B
 
 
+def test_device_side_per_building_weather_through_the_environment_api():
+  """SURVEY 8(f) rank 2 (weather half): BatchedSinusoidWeather -- every building its own
+  (low, high), temperatures generated on the device from one host factor -- through
+  BatchedEnvironment.reset()/step(); every building against an oracle twin driven by its own
+  host WeatherController."""
+  _need_gpu()
+  import datetime as dt
+  from sbsim_amd.environment import BatchedEnvironment
+  from sbsim_amd.host_inputs import BatchedSinusoidWeather, WeatherController
+  p = load("plan_r9_sb1.npz")
+  g = load("h2_sb1_r9_random.npz")
+  B, T = 6, 10
+  rs = np.random.RandomState(9)
+  low = np.array([262.0, 268.5, 273.0, 277.25, 281.0, 255.0])
+  high = low + np.array([4.0, 9.5, 10.0, 12.0, 6.5, 20.0])
+  weather = BatchedSinusoidWeather(low, high, convection_coefficient=float(g["h_conv"]))
+  start = dt.datetime(2023, 7, 6, 9, 30, 0)
+  env = BatchedEnvironment(_plan(p), B, config=SimConfig.sb1(), weather=weather, start_timestamp=start,
+                           holiday_calendar=None, collect_info=True)
+  ts0 = env.reset()
+  names = env.field_names
+  oat = names.index("air_handler_id/outside_air_temperature_sensor")
+  assert np.allclose(ts0.observation.cpu().numpy()[:, oat], weather.temps(start).astype(np.float32))
+  plan, prm = oracle_plan(p), oracle_params(g["params_json"])
+  twins = [orc.OracleBuilding(plan, prm, float(env.config.initial_temp)) for _ in range(B)]
+  ctrl = [WeatherController(lo, hi) for lo, hi in zip(low, high)]
+  acts = rs.uniform(-1, 1, size=(T, B, 2)).astype(np.float32)
+  rng_w, rng_a = env.config.action_ranges
+  for t in range(T):
+    now = env.current_simulation_timestamp
+    si = env.make_step_in(now)
+    out = env.step(torch.tensor(acts[t], device="cuda"))
+    zt = env.sim.zone_temps().cpu().numpy()
+    info = env.info.cpu().numpy()
+    nxt = now + dt.timedelta(seconds=300)
+    for b in range(B):
+      a = acts[t, b]
+      native = [np.float32((float(a[0]) + 1.0) / 2.0 * (rng_w[1] - rng_w[0]) + rng_w[0]),
+                np.float32((float(a[1]) + 1.0) / 2.0 * (rng_a[1] - rng_a[0]) + rng_a[0])]
+      o = twins[b].step(
+          now_ts=300.0 * t, t_amb_now=ctrl[b].get_current_temp(now), h_conv=float(g["h_conv"]),
+          t_amb_next=ctrl[b].get_current_temp(nxt), comfort_now=bool(si.comfort_now),
+          comfort_prev=si.comfort_prev == 1, comfort_next=bool(si.comfort_next), occupancy=si.occupancy,
+          e_price=si.e_price, e_carbon=si.e_carbon, g_price=si.g_price, g_carbon=si.g_carbon,
+          action=native, observe=True)
+      assert int(info[b, 4]) == o["n_sweeps"], (t, b, info[b, 4], o["n_sweeps"])
+      assert np.abs(zt[b] - o["zone_temp_post"]).max() < T_TOL, (t, b)
+      assert abs(float(out.reward[b]) - o["reward"]) < 1e-6, (t, b)
+    assert np.allclose(out.observation.cpu().numpy()[:, oat], weather.temps(nxt).astype(np.float32))
+  grid = env.sim.temps().cpu().numpy()
+  for b in range(B):
+    assert np.abs(grid[b] - twins[b].grid()).max() < T_TOL, b
+  assert np.array_equal(grid[:, 0, 0], weather.temps(now))   # the exterior ring: the device's own T_ambient, bit for bit
+  env.close()
+
+
 def test_environment_api_episode_bookkeeping():
   """environment.py:1165-1212,1311-1368: restart / N transitions / termination / auto-reset,
   plus observation normalisation and auxiliary features."""

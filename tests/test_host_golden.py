@@ -112,3 +112,23 @@ def test_schedule_timezone_conversion():
   assert not s.is_comfort_mode(dt.datetime(2023, 7, 6, 5, 0))                # naive = UTC clock
   with pytest.raises(ValueError):
     hi.SetpointSchedule(20, 19, (294, 297), (289, 298))
+
+
+def test_batched_sinusoid_weather_equals_one_controller_per_building():
+  """BatchedSinusoidWeather (per-building bounds, generated on the device from one host factor)
+  gives bit-identical temperatures to B separate WeatherControllers
+  (weather_controller.py:93-123), whose traces are pinned to the reference above."""
+  import datetime as dt
+  from sbsim_amd.host_inputs import BatchedSinusoidWeather, WeatherController
+  rs = np.random.RandomState(2)
+  low = 250.0 + 40.0 * rs.rand(17)
+  high = low + 25.0 * rs.rand(17)
+  w = BatchedSinusoidWeather(low, high, convection_coefficient=100.0)
+  for k in range(0, 2 * 288, 7):
+    ts = dt.datetime(2023, 7, 6, 0, 0, 0) + dt.timedelta(seconds=300 * k)
+    want = np.array([WeatherController(lo, hi).get_current_temp(ts) for lo, hi in zip(low, high)])
+    assert np.array_equal(w.temps(ts), want)
+    f = w.factor(ts)
+    assert np.array_equal(f * (high - low) + low, want)       # what the device evaluates
+  with pytest.raises(ValueError):
+    BatchedSinusoidWeather([300.0], [290.0])
