@@ -93,7 +93,8 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
     step_times.append(time.perf_counter() - t0)
     t_cpu += step_times[-1]
     sweeps += sum(outs[b].n_sweeps for b in range(nb))
-    if t_cpu * threads >= target_cpu_seconds or t_cpu > 60.0:
+    # bounded sample: all of the timed steps unless the host is so busy that it would take long
+    if (t_cpu * threads >= target_cpu_seconds and len(step_times) >= 12) or t_cpu > 20.0:
       break
   env._prev_thermostat_ts = None
   zones = oplan.Z
