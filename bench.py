@@ -5,8 +5,10 @@ SB1-physics building on the reference's 3x3-room floor plan R9 (68x98 control vo
 zones), per-building initial temperatures 294 + N(0,1) K (seed 7, clipped to [285,305]),
 random setpoint actions U[-1,1]^2 per building per step (torch.Generator seed 1234+rank),
 shared sinusoid weather 273-283 K, step-function occupancy, start 2023-07-06 07:00.
-A "step" is one BatchedEnvironment.step(): one launch of the fused HIP step kernel over
-the whole batch, inputs already resident in HBM.  Synthetic data, float64 arithmetic.
+A "step" is one BatchedEnvironment.step() over the whole batch = sb_step = three launches
+(per-building device algebra, Gauss-Seidel sweep kernel, reward / observation), inputs
+already resident in HBM.  Synthetic data, float64 arithmetic.  The roofline object prices the
+sweep kernel (> 95 % of a step), bracketed by HIP events through sb_step_phases.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; under torchrun one rank per GPU
 (weak scaling: 65 536 buildings per GPU, no data-path collective; one RCCL all_gather of

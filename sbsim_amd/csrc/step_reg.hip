@@ -14,7 +14,9 @@
 // (two ds_read2_b64), A = ap*Tprev + g (computed once per step into LDS) and runs 4 DPP
 // moves + 4 fp64 FMAs in the association order of step_lds.hip (bit-identical iterates).
 //
-// Floor plans with more than 64 rows use two wavefronts per building (P = 2): wave 0 owns the
+// One or two rows beyond the 64th (R9 has 66) are finished after the wavefront's pass by a
+// scan along the row (mode 3, tail_pass below).  Otherwise floor plans with more than 64
+// rows use two wavefronts per building (mode 2): wave 0 owns the
 // upper rows (in its TOP lanes, so that its seam row is lane 63), wave 1 the lower rows
 // (seam row = lane 0).  The two seam rows are exchanged through LDS once per 8-step chunk;
 // wave 0 counts its finished chunks in LDS and wave 1 starts chunk i only once wave 0 has

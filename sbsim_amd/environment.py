@@ -11,8 +11,9 @@ Mirrors ``smart_control/environment/environment.py`` ``Environment`` (a TF-Agent
     action_spec()/observation_spec() (:1215-1221)   same names; shapes without the batch axis
     steps_per_episode (:522), current_simulation_timestamp (:816), discount_factor
 
-Every step is ONE HIP kernel launch through the C ABI (include/sbsim_amd.h) on the current
-torch stream; observations, rewards and actions stay in HBM as torch tensors.  Calendar,
+Every step is one call through the C ABI (include/sbsim_amd.h: sb_step = three HIP kernel
+launches on the current torch stream); observations, rewards and actions stay in HBM as torch
+tensors.  Calendar,
 weather, occupancy and tariffs are resolved on the host once per step (all buildings share
 the simulator clock) by ``sbsim_amd.host_inputs``.  Episode bookkeeping follows
 ``environment.py:427-435,1311-1368``: an episode is N transitions plus one terminal step;

@@ -1,7 +1,7 @@
 """NumPy model of the HIP sweep's schedule (test utility, CPU only).
 
 Replays exactly the lane/band/step mapping of ``sweep()`` in
-sbsim_amd/csrc/sbsim_hip.hip -- 64 lanes in lock-step, reads of a step before its writes
+sbsim_amd/csrc/step_lds.hip -- 64 lanes in lock-step, reads of a step before its writes
 -- on top of the class tables from ``FloorPlan.compile``.  Comparing it with the oracle
 validates, without a GPU, (1) that the skewed schedule reproduces the reference's
 row-major in-place Gauss-Seidel order and (2) that the seven-term class-table update is

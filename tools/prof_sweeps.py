@@ -1,4 +1,4 @@
-"""Dev tool: per-sweep and fixed cost of k_step (caps the sweep count via iteration_limit)."""
+"""Dev tool: per-sweep and fixed cost of a step (caps the sweep count via iteration_limit)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
