@@ -312,6 +312,49 @@ def test_device_side_per_building_weather_through_the_environment_api():
   env.close()
 
 
+def test_full_size_batch_register_and_lds_kernels_agree(monkeypatch):
+  """BASELINE.json configs[1] at its full size (65,536 R9 buildings, random per-building
+  initial temperatures and actions): the two independent sweep kernels -- grid in registers
+  with the tail scan, grid in LDS with the banded DPP sweep -- must take the same number of
+  Gauss-Seidel sweeps for EVERY building at every step and end within 1e-9 K of each other;
+  sb_reset(temps) / sb_get_temps round-trips the caller's layout exactly."""
+  _need_gpu()
+  B, T = 65536, 10
+  p = load("plan_r9_sb1.npz")
+  g = load("h2_sb1_r9_random.npz")
+  gen = torch.Generator(device="cuda")
+  gen.manual_seed(5)
+  t0 = (294.0 + torch.randn((B, 1), generator=gen, device="cuda", dtype=torch.float64)).clamp(285.0, 305.0)
+  init = (t0 + 0.05 * torch.randn((B, 68 * 98), generator=gen, device="cuda", dtype=torch.float64)).contiguous()
+  acts = torch.rand((T, B, 2), generator=gen, device="cuda", dtype=torch.float32) * 2.0 - 1.0
+  sims = []
+  for force_lds in (False, True):
+    if force_lds:
+      monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
+    sim = BatchedSimulator(_plan(p), SimConfig.sb1(), B, float(g["h_conv"]))
+    assert sim.launch_info["path"] == (0 if force_lds else 1)
+    sim.reset(temps=init)
+    assert torch.equal(sim.temps().reshape(B, -1), init)
+    sims.append(sim)
+  obs = [torch.zeros((B, s.O), dtype=torch.float32, device="cuda") for s in sims]
+  rew = [torch.zeros((B,), dtype=torch.float32, device="cuda") for _ in sims]
+  info = [torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda") for _ in sims]
+  total = 0.0
+  for t in range(T):
+    si = _step_in(g, 100 + t)
+    for k, sim in enumerate(sims):
+      sim.step(acts[t], si, obs[k], rew[k], info[k])
+    assert torch.equal(info[0][:, 4], info[1][:, 4]), t          # sweeps, every building
+    assert bool((info[0][:, 5] == 1).all())                       # all converged
+    total += float(info[0][:, 4].sum())
+    assert float((sims[0].zone_temps() - sims[1].zone_temps()).abs().max()) < 1e-9, t
+    assert float((rew[0] - rew[1]).abs().max()) < 1e-6, t
+  assert float((sims[0].temps() - sims[1].temps()).abs().max()) < 1e-9
+  assert 2.0 < total / (B * T) < 30.0
+  for sim in sims:
+    sim.close()
+
+
 def test_environment_api_episode_bookkeeping():
   """environment.py:1165-1212,1311-1368: restart / N transitions / termination / auto-reset,
   plus observation normalisation and auxiliary features."""
