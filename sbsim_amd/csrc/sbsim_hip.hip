@@ -378,6 +378,12 @@ int check_plan(const sb_plan_desc *plan) {
   if (!plan) return fail(SB_ERR_INVALID, "null floor plan");
   if (plan->H < 1 || plan->W < 1 || plan->Z < 0 || plan->n_classes < 1 || plan->n_classes > 255)
     return fail(SB_ERR_INVALID, "sb_create: bad floor-plan dimensions");
+  if (!plan->cell_class || !plan->class_coef || !plan->class_zone || !plan->zone_off ||
+      (plan->zone_off[plan->Z] > 0 && !plan->zone_cells))
+    return fail(SB_ERR_INVALID, "sb_create: null floor-plan table");
+  for (int z = 0; z < plan->Z; ++z)
+    if (plan->zone_off[z + 1] < plan->zone_off[z] || plan->zone_off[0] != 0)
+      return fail(SB_ERR_INVALID, "sb_create: zone offsets must start at 0 and be non-decreasing");
   const int N = plan->H * plan->W;
   for (int i = 0; i < plan->zone_off[plan->Z]; ++i)
     if (plan->zone_cells[i] < 0 || plan->zone_cells[i] >= N)
@@ -486,6 +492,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   if (params->ahu_cool_sp <= params->ahu_heat_sp) // air_handler.py:60-64
     return fail(SB_ERR_INVALID, "cooling_air_temp_setpoint must greater than heating_air_temp_setpoint");
   if (obs->n_obs < 1) return fail(SB_ERR_INVALID, "sb_create: empty observation layout");
+  if (!obs->mean || !obs->sigma || (plan->Z > 0 && !obs->col_zone))
+    return fail(SB_ERR_INVALID, "sb_create: null observation-layout table");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(SB_ERR_NO_DEVICE, "sb_create: no HIP device visible (this library has no CPU path)");

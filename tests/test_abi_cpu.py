@@ -78,6 +78,29 @@ def test_plan_info_picks_the_step_kernel_without_a_gpu():
   assert rc == 0 and one["path"] == 1 and one["waves_per_building"] == 1
 
 
+def test_plan_checks_reject_bad_tables_without_a_gpu():
+  """Host-side validation shared by sb_plan_info and sb_create: status codes, not crashes."""
+  import numpy as np
+  L = _ffi.load()
+  info = _ffi.LaunchInfo()
+  cls = np.zeros(6, np.uint8); coef = np.zeros((1, 8)); coef[0, 5] = 1.0
+  cz = np.full(1, -1, np.int32); zoff = np.zeros(1, np.int32); zc = np.zeros(1, np.int32)
+  def desc(**kw):
+    d = dict(H=2, W=3, Z=0, n=1, cls=cls.ctypes.data_as(C.POINTER(C.c_uint8)), coef=coef.ctypes.data_as(_ffi._dp),
+             cz=cz.ctypes.data_as(_ffi._ip), zoff=zoff.ctypes.data_as(_ffi._ip), zc=zc.ctypes.data_as(_ffi._ip))
+    d.update(kw)
+    return _ffi.PlanDesc(d["H"], d["W"], d["Z"], d["n"], d["cls"], d["coef"], d["cz"], d["zoff"], d["zc"])
+  assert L.sb_plan_info(C.byref(desc()), 20, 4, C.byref(info)) == 0     # all exterior: LDS-grid kernel
+  assert info.path == 0
+  assert L.sb_plan_info(C.byref(desc(H=0)), 20, 4, C.byref(info)) == -1
+  assert L.sb_plan_info(C.byref(desc(cls=None)), 20, 4, C.byref(info)) == -1
+  assert b"null floor-plan table" in L.sb_last_error()
+  bad = np.full(6, 7, np.uint8)
+  assert L.sb_plan_info(C.byref(desc(cls=bad.ctypes.data_as(C.POINTER(C.c_uint8)))), 20, 4, C.byref(info)) == -1
+  assert L.sb_plan_info(None, 20, 4, C.byref(info)) == -1
+  assert L.sb_plan_info(C.byref(desc()), 20, 4, None) == -1
+
+
 def test_no_cpu_fallback_without_gpu():
   import torch
   if torch.cuda.is_available():
