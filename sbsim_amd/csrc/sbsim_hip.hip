@@ -267,7 +267,9 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
     r.r_xchg = off; off += 8;
     r.AS = AS;
     r.lds_bytes = off * 8;
-    r.wg_per_cu = std::min(4, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule));
+    // workgroups per CU: LDS, and the registers (4 SIMDs x wavefronts per SIMD / wavefronts per building)
+    const int by_regs = 4 * sweep_reg_waves_per_simd(NR, P) / (P == 2 ? 2 : 1);
+    r.wg_per_cu = std::min(by_regs, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule));
   };
   const int nl = sweep_reg_lds_slots(NR, P); // slots of A in LDS (the kernel keeps the rest in registers)
   layout(nl);

@@ -40,7 +40,12 @@ constexpr int kPair = 2, kTail = 3;
 // Slots of A = ap*Tprev + g kept in LDS; the remaining NR - lds_slots live in registers
 // (AGPRs).  R9 in mode kTail: 71 of 96 slots in LDS makes a building fit a quarter of a CU's
 // LDS, so all four SIMDs own a building instead of three.
-constexpr int lds_slots(int NR, int P) { return (NR == 96 && P == kTail) ? 71 : NR; }
+// The 96-slot two-wavefront variant (up to 128 x 96 cells) keeps 89 slots in LDS: two buildings
+// per CU (it runs one wavefront per SIMD: 192 registers of grid + the rest do not fit twice).
+constexpr int lds_slots(int NR, int P) {
+  return (NR == 96 && P == kTail) ? 71 : ((NR == 96 && P == kPair) ? 89 : NR);
+}
+constexpr int waves_per_simd(int NR, int P) { return (P == kPair && NR <= 66) ? 2 : 1; }
 #ifndef SB_LOOK
 #define SB_LOOK 2
 #endif
@@ -305,7 +310,7 @@ extern __shared__ __attribute__((aligned(16))) double lds[];
 
 template <int NR, int P>
 __global__ void __launch_bounds__(P == kPair ? 128 : 64)
-    __attribute__((amdgpu_waves_per_eu(P == kPair ? 2 : 1, P == kPair ? 2 : 1))) k_sweep_reg(Dev a) {
+    __attribute__((amdgpu_waves_per_eu(waves_per_simd(NR, P), waves_per_simd(NR, P)))) k_sweep_reg(Dev a) {
   const int lane = threadIdx.x & 63;
   const int w = P == kPair ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   constexpr int kASlots = (NR + 7) / 8, kZSlots = (NR + 3) / 4, kMaxCh = (NR + 63 + 7) / 8;
@@ -613,7 +618,7 @@ void launch_variant(const Dev &d, int workgroups, hipStream_t stream) {
 
 #define SB_VARIANT(NR, P) {NR, P, (const void *)k_sweep_reg<NR, P>, launch_variant<NR, P>}
 const Variant kVariants[] = {SB_VARIANT(32, 1), SB_VARIANT(66, 1), SB_VARIANT(66, 2), SB_VARIANT(96, 1),
-                            SB_VARIANT(96, 3)};
+                            SB_VARIANT(96, 2), SB_VARIANT(96, 3)};
 #undef SB_VARIANT
 
 const Variant *find_variant(int NR, int P) {
@@ -626,6 +631,7 @@ const Variant *find_variant(int NR, int P) {
 
 bool sweep_reg_supported(int NR, int P) { return find_variant(NR, P) != nullptr; }
 int sweep_reg_lds_slots(int NR, int P) { return lds_slots(NR, P); }
+int sweep_reg_waves_per_simd(int NR, int P) { return waves_per_simd(NR, P); }
 
 int prepare_sweep_reg(const Dev &d) {
   const Variant *v = find_variant(d.NR, d.P);

@@ -421,7 +421,8 @@ def _oracle_twin(plan, cfg, init_flat):
 
 
 @pytest.mark.parametrize("rooms,room_shape,orientation,path", [
-    ((8, 5), (12, 14), "auto", 0),     # "SB2-synth": 40 zones, 109x81 grid, 2 bands either way (LDS grid)
+    ((8, 5), (12, 14), "auto", 0),     # "SB2-synth": 40 zones, 109x80 grid, 51 cell classes -> LDS grid, 2 bands
+    ((4, 3), (25, 28), "rows", 1),     # 107x90 inside the ring -> registers, 2 waves, 96 slots (1 wave per SIMD)
     ((14, 9), (8, 7), "auto", 0),      # "SB1-synth": 126 zones (the real SB1's VAV count), 131x78 grid, 3 bands
     ((2, 3), (9, 10), "rows", 1),      # small: 22x34 inside the ring -> registers, 1 wave, 66 slots
     ((5, 1), (12, 10), "generic", 0),  # H > 64, narrow grid, forced onto the generic (all-LDS) sweep
