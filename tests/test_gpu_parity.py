@@ -11,6 +11,8 @@ Tolerances (BASELINE.json north_star: "temperatures within 1e-4 C of reference")
 import ctypes as C
 import datetime as dt
 
+import os
+
 import numpy as np
 import pytest
 
@@ -352,6 +354,40 @@ def test_full_size_batch_register_and_lds_kernels_agree(monkeypatch):
   assert float((sims[0].temps() - sims[1].temps()).abs().max()) < 1e-9
   assert 2.0 < total / (B * T) < 30.0
   for sim in sims:
+    sim.close()
+
+
+def test_full_size_isothermal_fixed_point():
+  """A size-independent property at the full BASELINE batch: a building that is everywhere at
+  the ambient temperature, with the air handler passing that air through (heating setpoint <=
+  T_amb <= cooling setpoint) and every thermostat OFF, is a fixed point of the step: VAV power
+  0, one Gauss-Seidel sweep, the grid unchanged to round-off -- for all 65,536 buildings, on
+  both sweep kernels."""
+  _need_gpu()
+  B = 65536
+  p = load("plan_r9_sb1.npz")
+  g = load("h2_sb1_r9_random.npz")
+  t_amb = 295.0
+  for force_lds in (False, True):
+    if force_lds:
+      os.environ["SBSIM_FORCE_LDS_PATH"] = "1"
+    try:
+      sim = BatchedSimulator(_plan(p), SimConfig.sb1(), B, float(g["h_conv"]))
+    finally:
+      os.environ.pop("SBSIM_FORCE_LDS_PATH", None)
+    sim.reset(initial_temp=t_amb)
+    obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
+    rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+    info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+    si = _step_in(g, 100)            # mid-morning: comfort window 294..297 K around 295 K
+    si.t_amb_now = si.t_amb_next = t_amb
+    si.has_action = 0                 # setpoints stay at the constructor values (285 / 298 K)
+    for _ in range(3):
+      sim.step(None, si, obs, rew, info)
+      assert bool((info[:, 4] == 1).all()) and bool((info[:, 5] == 1).all())
+      assert float(sim.zone_power().abs().max()) < 1e-6
+      assert float((sim.temps() - t_amb).abs().max()) < 1e-10
+    assert bool((sim.modes() == 0).all())
     sim.close()
 
 
