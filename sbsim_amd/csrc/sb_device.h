@@ -122,6 +122,7 @@ int prepare_sweep_lds(size_t lds_bytes);
 int launch_sweep_reg(const Dev &d, int cus, hipStream_t stream);
 int prepare_sweep_reg(const Dev &d);         // sets the LDS attribute; fails if (NR, P) is not built
 bool sweep_reg_supported(int NR, int P);     // is there an instantiation for this shape?
+int sweep_reg_table_stride(int NR, int P);   // coefficient-table stride of the instantiation (classes + 1 <= stride)
 int sweep_reg_lds_slots(int NR, int P);      // slots of A the instantiation keeps in LDS (the rest: registers)
 int sweep_reg_waves_per_simd(int NR, int P); // register budget of the instantiation: wavefronts per SIMD
 

@@ -159,7 +159,7 @@ struct DevBuf {
 struct RegPlan {
   bool ok = false;
   std::string why;
-  int NR = 0, P = 0, RS = 0, Ws = 0, r0 = 0, c0 = 0, n_ring = 0, T = 0, state_doubles = 0;
+  int NR = 0, P = 0, RS = 0, Ws = 0, r0 = 0, c0 = 0, n_ring = 0, T = 0, state_doubles = 0, ts = 32;
   std::vector<uint8_t> tcls;
   int lw[2] = {0, 0}, l0[2] = {0, 0}, rowbase[2] = {0, 0}, nch[2] = {0, 0};
   int lag = 0, nslots = 0, steps = 0;
@@ -168,7 +168,7 @@ struct RegPlan {
   std::vector<int> cell_state;
 };
 
-constexpr int kRegTS = 32, kRegSeamPad = 8, kLdsCap = 160 * 1024;
+constexpr int kRegSeamPad = 8, kLdsCap = 160 * 1024;
 constexpr int kLdsGranule = 1280; // LDS is allocated to workgroups in blocks of this many bytes (gfx950)
 constexpr int kRegSlots[] = {32, 66, 96};
 
@@ -176,7 +176,8 @@ constexpr int kRegSlots[] = {32, 66, 96};
 // workgroup barrier between its write and its (2-steps-early) read, in both directions
 int seam_lag(int lw0) { return (lw0 + 8) / 8 + 1; }
 
-void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
+// lds_per_cu: buildings per CU the LDS-grid kernel would hold (0: the plan does not fit it).
+void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   const int H = plan->H, W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = H * W;
   auto coef = [&](int c, int j) { return plan->class_coef[c * 8 + j]; };
   auto cls_at = [&](int x, int y) { return (int)plan->cell_class[x * W + y]; };
@@ -193,7 +194,6 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
       }
   if (x1 < 0) { r.why = "no cell inside the building"; return; }
   const int Hs = x1 - x0 + 1, Ws = y1 - y0 + 1;
-  if (ncls + 1 > kRegTS) { r.why = "more than 31 cell classes"; return; }
   // nothing may couple to a cell outside the trim box
   for (int y = y0; y <= y1; ++y)
     if (coef(cls_at(x0, y), 0) != 0 || coef(cls_at(x1, y), 1) != 0) { r.why = "coupling across the trim box"; return; }
@@ -202,9 +202,9 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
   std::vector<int> zone_of(N, -1);
   for (int z = 0; z < Z; ++z)
     for (int i = plan->zone_off[z]; i < plan->zone_off[z + 1]; ++i) zone_of[plan->zone_cells[i]] = z;
-  auto pick_slots = [&](int mode) {
+  auto pick_slots = [&](int mode) { // narrowest instantiation that holds the width and the class count
     for (int s : kRegSlots)
-      if (s >= Ws && sweep_reg_supported(s, mode)) return s;
+      if (s >= Ws && sweep_reg_supported(s, mode) && ncls + 1 <= sweep_reg_table_stride(s, mode)) return s;
     return 0;
   };
   // mode 1: one wavefront; mode 3: one wavefront + one or two tail rows finished by a scan
@@ -216,9 +216,19 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
       for (int y = y0; y <= y1; ++y) zone_free = zone_free && zone_of[x * W + y] < 0;
     if (zone_free) { P = 3; NR = pick_slots(3); }
   }
-  if (!P && Hs <= 128) { P = 2; NR = pick_slots(2); }
+  if (!P && Hs <= 128) {
+    P = 2; NR = pick_slots(2);
+    // a two-wavefront variant that runs one wavefront per SIMD holds two buildings per CU and
+    // pays the seam lag: measured no faster than the LDS-grid kernel at two buildings per CU
+    if (NR && sweep_reg_waves_per_simd(NR, 2) == 1 && lds_per_cu >= 2) {
+      r.why = "the LDS-grid kernel holds as many buildings per CU";
+      return;
+    }
+  }
   if (!P) { r.why = "more than 128 rows inside the building"; return; }
-  if (!NR) { r.why = "no kernel variant for this width"; return; }
+  if (!NR) { r.why = "no kernel variant for this width and class count"; return; }
+  const int TS = sweep_reg_table_stride(NR, P), cscale = 256 / TS; // class byte = class * cscale
+  r.ts = TS;
   const int RS = P == 3 ? 64 : Hs;
   const int ZRS = RS | 1; // odd stride: the zone reduce reads 16 zone rows at once
   if ((size_t)(Z + 1) * ZRS > (size_t)RS * sweep_reg_lds_slots(NR, P) || (size_t)(Z + 1) * ZRS * 8 > 65535) {
@@ -260,7 +270,7 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
   // stride spreads the 64 lanes over all banks (stride 96 doubles would put them all on one)
   // -- unless the extra column costs a resident building.
   auto layout = [&](int AS) {
-    int off = 5 * kRegTS + kRegTS;
+    int off = 5 * TS + TS;
     r.r_seam = off;
     off += P == 2 ? 2 * (NR + 2 * kRegSeamPad) : (P == 3 ? ((NR + 2 * kRegSeamPad + r.T * (NR + 2) + 1) & ~1) : 0);
     r.r_A = off; off += RS * AS;
@@ -300,7 +310,7 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
         for (int k = 0; k < 8; ++k) {
           const int col = 8 * ch + k - lp;
           const int c = valid ? cell_class(R, col) : pad;
-          word |= (unsigned long long)(c * 8) << (8 * k); // class * 8: byte offset into a table column
+          word |= (unsigned long long)(c * cscale) << (8 * k); // stride 32: the byte offset into a table column
         }
         r.cmapS[((size_t)w * (maxch + 3) + ch) * 64 + lane] = word;
       }
@@ -310,7 +320,7 @@ void plan_reg(const sb_plan_desc *plan, RegPlan &r) {
           const int j = 8 * g + k;
           const int col = ((j - lp) % NR + NR) % NR;
           const int c = (valid && j < NR) ? cell_class(R, col) : pad;
-          word |= (unsigned long long)(c * 8) << (8 * k);
+          word |= (unsigned long long)(c * cscale) << (8 * k);
         }
         r.amapS[((size_t)w * aslots + g) * 64 + lane] = word;
       }
@@ -374,6 +384,10 @@ LdsPlan plan_lds(const sb_plan_desc *plan) {
   q.wave_bytes = (size_t)off * 8;
   q.fits = q.shared_bytes + q.wave_bytes <= (size_t)kLdsCap && q.NL < 65535;
   return q;
+}
+
+int lds_buildings_per_cu(const LdsPlan &q) {
+  return q.fits ? (int)(((size_t)kLdsCap - q.shared_bytes) / q.wave_bytes) : 0;
 }
 
 int check_plan(const sb_plan_desc *plan) {
@@ -475,8 +489,8 @@ int sb_plan_info(const sb_plan_desc *plan, int32_t n_obs, int32_t n_buildings, s
   int rc = check_plan(plan);
   if (rc != SB_OK) return rc;
   RegPlan r;
-  if (!env_flag("SBSIM_FORCE_LDS_PATH")) plan_reg(plan, r);
   const LdsPlan q = plan_lds(plan);
+  if (!env_flag("SBSIM_FORCE_LDS_PATH")) plan_reg(plan, lds_buildings_per_cu(q), r);
   if (!r.ok && !q.fits)
     return fail(SB_ERR_TOO_LARGE, "one building's float64 grid does not fit in 160 KiB of LDS");
   fill_launch_info(plan, r, q, n_obs, 256, std::max(n_buildings, 1), out);
@@ -505,8 +519,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   SB_HIP(hipGetDeviceProperties(&prop, device));
 
   RegPlan r;
-  if (!env_flag("SBSIM_FORCE_LDS_PATH")) plan_reg(plan, r);
   const LdsPlan q = plan_lds(plan);
+  if (!env_flag("SBSIM_FORCE_LDS_PATH")) plan_reg(plan, lds_buildings_per_cu(q), r);
   if (!r.ok && !q.fits)
     return fail(SB_ERR_TOO_LARGE, "sb_create: one building's float64 grid does not fit in 160 KiB of LDS");
 
@@ -532,7 +546,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   SB_TRY(upload(h->czone, plan->class_zone, (size_t)d.ncls));
   SB_TRY(upload(h->zone_off, plan->zone_off, (size_t)d.Z + 1));
   if (d.reg) {
-    d.pitch = d.W; d.NL = d.N; d.ts = kRegTS;
+    d.pitch = d.W; d.NL = d.N; d.ts = r.ts;
     d.NR = r.NR; d.P = r.P; d.RS = r.RS; d.Ws = r.Ws; d.n_ring = r.n_ring;
     d.T = r.T; d.state_doubles = r.state_doubles; d.AS = r.AS; d.ZRS = r.RS | 1;
     for (int w = 0; w < 2; ++w) { d.lw[w] = r.lw[w]; d.l0[w] = r.l0[w]; d.rowbase[w] = r.rowbase[w]; d.nch[w] = r.nch[w]; }

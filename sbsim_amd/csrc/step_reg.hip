@@ -50,7 +50,10 @@ constexpr int waves_per_simd(int NR, int P) { return (P == kPair && NR <= 66) ? 
 #define SB_LOOK 2
 #endif
 constexpr int kLook = SB_LOOK; // steps between the LDS reads of a step and its arithmetic
-constexpr int kTS = 32;    // coefficient-table stride (classes + the pad class <= 32)
+// Coefficient-table stride: classes + the pad class <= stride.  The class maps hold
+// class * (256 / stride) in a byte; times stride / 32 that is the class's byte offset into a
+// table column (stride 32: the byte IS the offset, one SDWA add per step).
+constexpr int table_stride(int NR, int P) { return (NR == 96 && P == 2) ? 64 : 32; }
 constexpr int kSeamPad = 8;
 
 // Hides a value from loop-invariant code motion: without it the compiler precomputes every
@@ -93,7 +96,8 @@ __device__ __forceinline__ void prefetch(Pipe &p, const double *tab, const doubl
                                          const double (&Areg)[NAR], const double *seam_in,
                                          const double *seam_in2) {
   const unsigned long long cw = p.cw[(PD / 8) % 3];
-  const int c8 = (int)((cw >> (8 * (PD % 8))) & 0xffull); // class * 8: the byte offset into a table column
+  constexpr int kTS = table_stride(NR, P);
+  const int c8 = (int)((cw >> (8 * (PD % 8))) & 0xffull) * (kTS / 32); // the class's byte offset into a table column
   const double *bt = (const double *)((const char *)tab + c8);
   Co &o = p.co[PD % (kLook + 1)];
   o.bU = bt[0]; o.bD = bt[kTS]; o.bL = bt[2 * kTS]; o.bR = bt[3 * kTS];
@@ -264,7 +268,8 @@ constexpr int kTailMax = 2;
 template <int NR>
 __device__ __forceinline__ double tail_pass(int T, int lane, const double *tab, double *tE, const double *r63,
                                             const double (&At)[kTailMax][2], unsigned tclsw) {
-  constexpr int kBlk = (NR + 63) / 64, kRow = NR + 2;
+  constexpr int kBlk = (NR + 63) / 64, kRow = NR + 2, kTS = table_stride(NR, kTail);
+  static_assert(kTS == 32, "the tail-row class bytes are byte offsets");
   double dmax = 0.0;
 #pragma unroll
   for (int t = 0; t < kTailMax; ++t) {
@@ -314,6 +319,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   const int lane = threadIdx.x & 63;
   const int w = P == kPair ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   constexpr int kASlots = (NR + 7) / 8, kZSlots = (NR + 3) / 4, kMaxCh = (NR + 63 + 7) / 8;
+  constexpr int kTS = table_stride(NR, P);
 
   double *tab = lds;                       // [5][kTS]: bU bD bL bR ap
   double *gtab = lds + 5 * kTS;            // [kTS]
@@ -476,7 +482,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int j = min(8 * g + k, NR - 1);
-          const int c8 = (int)((cw[j >> 3] >> (8 * (j & 7))) & 0xffull);
+          const int c8 = (int)((cw[j >> 3] >> (8 * (j & 7))) & 0xffull) * (kTS / 32);
           pa[k] = *(const double *)((const char *)(tab + 4 * kTS) + c8);
           pg[k] = *(const double *)((const char *)gtab + c8);
         }
@@ -630,6 +636,7 @@ const Variant *find_variant(int NR, int P) {
 } // namespace
 
 bool sweep_reg_supported(int NR, int P) { return find_variant(NR, P) != nullptr; }
+int sweep_reg_table_stride(int NR, int P) { return table_stride(NR, P); }
 int sweep_reg_lds_slots(int NR, int P) { return lds_slots(NR, P); }
 int sweep_reg_waves_per_simd(int NR, int P) { return waves_per_simd(NR, P); }
 

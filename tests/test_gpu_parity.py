@@ -457,8 +457,9 @@ def _oracle_twin(plan, cfg, init_flat):
 
 
 @pytest.mark.parametrize("rooms,room_shape,orientation,path", [
-    ((8, 5), (12, 14), "auto", 0),     # "SB2-synth": 40 zones, 109x80 grid, 51 cell classes -> LDS grid, 2 bands
-    ((4, 3), (25, 28), "rows", 1),     # 107x90 inside the ring -> registers, 2 waves, 96 slots (1 wave per SIMD)
+    ((8, 5), (12, 14), "auto", 0),     # "SB2-synth": 40 zones, 109x80 grid, 51 cell classes -> LDS grid (2 per CU, as many as the register variant)
+    ((6, 4), (17, 21), "rows", 1),     # 107x89 inside the ring, 24 zones, > 31 cell classes -> registers, 2 waves, 64-entry tables
+    ((4, 3), (25, 28), "rows", 0),     # 109x92: two of them fit a CU's LDS -> LDS grid preferred over the 96-slot pair variant
     ((14, 9), (8, 7), "auto", 0),      # "SB1-synth": 126 zones (the real SB1's VAV count), 131x78 grid, 3 bands
     ((2, 3), (9, 10), "rows", 1),      # small: 22x34 inside the ring -> registers, 1 wave, 66 slots
     ((5, 1), (12, 10), "generic", 0),  # H > 64, narrow grid, forced onto the generic (all-LDS) sweep
