@@ -38,12 +38,12 @@ namespace {
 constexpr int kPair = 2, kTail = 3;
 
 // Slots of A = ap*Tprev + g kept in LDS; the remaining NR - lds_slots live in registers
-// (AGPRs).  R9 in mode kTail: 71 of 96 slots in LDS makes a building fit a quarter of a CU's
-// LDS, so all four SIMDs own a building instead of three.
+// (AGPRs).  96-slot plans on one wavefront (R9 in mode kTail): 71 of 96 slots in LDS make a
+// building fit a quarter of a CU's LDS, so all four SIMDs own a building instead of three.
 // The 96-slot two-wavefront variant (up to 128 x 96 cells) keeps 89 slots in LDS: two buildings
 // per CU (it runs one wavefront per SIMD: 192 registers of grid + the rest do not fit twice).
 constexpr int lds_slots(int NR, int P) {
-  return (NR == 96 && P == kTail) ? 71 : ((NR == 96 && P == kPair) ? 89 : NR);
+  return (NR == 96 && P != kPair) ? 71 : ((NR == 96 && P == kPair) ? 89 : NR);
 }
 constexpr int waves_per_simd(int NR, int P) { return (P == kPair && NR <= 66) ? 2 : 1; }
 #ifndef SB_LOOK

@@ -548,3 +548,36 @@ class BatchedEnvironment:
 
   def close(self) -> None:
     self.sim.close()
+
+
+class GymVectorEnv:
+  """gymnasium.vector-style view of a ``BatchedEnvironment`` (no gymnasium import needed):
+
+      obs, info = venv.reset()
+      obs, reward, terminated, truncated, info = venv.step(actions)      # all [B, ...] tensors in HBM
+
+  Every sub-environment shares the simulator clock, so they terminate together: the terminal
+  step of an episode (``environment.py:1366-1368``) returns ``terminated = True`` for all of
+  them, and -- gymnasium's "next-step" autoreset mode -- the following ``step`` ignores its
+  actions and returns the first observation of the next episode with zero reward."""
+
+  def __init__(self, env: BatchedEnvironment):
+    self.env = env
+    self.num_envs = env.batch_size
+    self.single_action_shape = tuple(env.action_spec().shape)
+    self.single_observation_shape = tuple(env.observation_spec().shape)
+    self.action_low, self.action_high = -1.0, 1.0
+
+  def reset(self, seed=None, options=None):
+    del seed, options   # the simulator is deterministic; inputs come from the host controllers
+    ts = self.env.reset()
+    return ts.observation, {"step_type": ts.step_type}
+
+  def step(self, actions: torch.Tensor):
+    ts = self.env.step(actions)
+    terminated = ts.step_type == STEP_LAST
+    truncated = torch.zeros_like(terminated)
+    return ts.observation, ts.reward, terminated, truncated, {"step_type": ts.step_type, "discount": ts.discount}
+
+  def close(self) -> None:
+    self.env.close()

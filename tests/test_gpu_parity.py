@@ -423,6 +423,39 @@ def test_environment_api_episode_bookkeeping():
   env.close()
 
 
+def test_gym_vector_view_autoresets_like_gymnasium():
+  """GymVectorEnv: (obs, reward, terminated, truncated, info) over a short episode and the
+  next-step autoreset; the same numbers as the TimeStep API."""
+  _need_gpu()
+  from sbsim_amd.environment import BatchedEnvironment, GymVectorEnv
+  B = 4
+  plan = _plan(load("plan_r9_sb1.npz"))
+  steps = 5                                       # 5 transitions + the terminal step
+  mk = lambda: BatchedEnvironment(plan, B, num_days_in_episode=steps * 300.0 / 86400.0, holiday_calendar=None)
+  venv, ref = GymVectorEnv(mk()), mk()
+  assert venv.num_envs == B and venv.single_action_shape == (2,) and venv.single_observation_shape == (ref.sim.O,)
+  obs, info = venv.reset()
+  ts = ref.reset()
+  assert torch.equal(obs, ts.observation) and bool((info["step_type"] == 0).all())
+  rs = np.random.RandomState(1)
+  seen_terminal = 0
+  for t in range(2 * (steps + 2)):
+    a = torch.tensor(rs.uniform(-1, 1, size=(B, 2)).astype(np.float32), device="cuda")
+    obs, rew, term, trunc, info = venv.step(a)
+    ts = ref.step(a)
+    assert torch.equal(obs, ts.observation) and torch.equal(rew, ts.reward)
+    assert not bool(trunc.any())
+    assert bool(term.all()) == bool((ts.step_type == 2).all()) and bool(term.all()) == bool(term.any())
+    if bool(term.all()):
+      seen_terminal += 1
+      obs2, rew2, term2, _, info2 = venv.step(a)    # next-step autoreset: first observation, zero reward
+      ts2 = ref.step(a)
+      assert bool((info2["step_type"] == 0).all()) and float(rew2.abs().max()) == 0.0 and not bool(term2.any())
+      assert torch.equal(obs2, ts2.observation)
+  assert seen_terminal == 2
+  venv.close(); ref.close()
+
+
 def test_abi_error_paths():
   _need_gpu()
   L = _ffi.load()
