@@ -412,17 +412,17 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   }
   // Buildings need different numbers of sweeps, so a static split would leave the last
   // workgroups running alone: after its first building a workgroup draws the next one from a
-  // device counter (zeroed before every launch).  The two-wavefront mode keeps the
-  // static stride (both waves must agree on the building without a round trip through LDS).
-  auto draw = [&](int cur) {
-    if (P == kPair) return cur + (int)gridDim.x;
-    int nb = 0;
-    if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
-    return __builtin_amdgcn_readfirstlane(nb);
-  };
+  // device counter (zeroed before every launch).  In the two-wavefront mode wave 0 draws
+  // and hands the index to wave 1 through LDS at the building's first barrier.
+  int *draw_slot = (int *)(xchg + 7);
   int iter = 0;
   for (int b = blockIdx.x, bn = 0; b < a.B; b = bn, ++iter) {
-    bn = draw(b); // early: the epilogue prefetches building bn
+    if (w == 0) { // early: the epilogue prefetches building bn
+      int nb = 0;
+      if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
+      bn = __builtin_amdgcn_readfirstlane(nb);
+      if (P == kPair && lane == 0) *draw_slot = bn;
+    }
     SB_STAMP(0);
     double *T = a.temp + (size_t)b * a.state_doubles + R;
     double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 64; // mode kTail: [T][NR]
@@ -446,6 +446,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       }
     }
     if (P == kPair) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    if (P == kPair && w == 1) bn = __builtin_amdgcn_readfirstlane(*draw_slot);
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(1);
     double At[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // mode kTail: A of the lane's tail cells
