@@ -308,7 +308,8 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
       for (int ch = 0; ch < maxch + 3; ++ch) {
         unsigned long long word = 0;
         for (int k = 0; k < 8; ++k) {
-          const int col = 8 * ch + k - lp;
+          int col = 8 * ch + k - lp;
+          if (P == 3 && col >= NR) col -= NR; // overlapped sweeps: the lane is in its next sweep
           const int c = valid ? cell_class(R, col) : pad;
           word |= (unsigned long long)(c * cscale) << (8 * k); // stride 32: the byte offset into a table column
         }

@@ -68,6 +68,22 @@ __device__ __forceinline__ int opaque_s(int v) { // the same for a wave-uniform 
   return v;
 }
 
+// Lanes 0..J as a lane predicate without a VALU compare: the mask is built by one SALU
+// instruction where it is used (a compare per step costs a VALU slot plus wait states before
+// the select; masks computed once per kernel would be ~130 SGPR pairs, i.e. spilled).
+#ifndef SB_BFM
+#define SB_BFM 1
+#endif
+template <int J>
+__device__ __forceinline__ bool lanes_upto(int lp) {
+  if (SB_BFM) {
+    unsigned long long m;
+    asm volatile("s_bfm_b64 %0, %1, 0" : "=s"(m) : "n"(J + 1));
+    return __builtin_amdgcn_inverse_ballot_w64(m);
+  }
+  return (unsigned)lp <= (unsigned)J;
+}
+
 struct Co { double bU, bD, bL, bR, A, smU, smD; };
 struct Pipe {
   Co co[kLook + 1];
@@ -128,7 +144,7 @@ __device__ __forceinline__ void update(double (&e)[NR], const Co &o, int lp, uns
   constexpr bool need_lo = D >= NR;  // lp > D - NR can fail
   bool act;
   if (need_hi && need_lo) act = (unsigned)(D - lp) < (unsigned)NR;
-  else if (need_hi) act = (unsigned)lp <= (unsigned)D;
+  else if (need_hi) act = P == kTail ? lanes_upto<(D < 63 ? D : 0)>(lp) : (unsigned)lp <= (unsigned)D; // kTail: lp == lane
   else if (need_lo) act = lp > D - NR;
   else act = __builtin_amdgcn_inverse_ballot_w64(rowmask);
   // mode kTail: all 64 lanes own a row, so the middle steps need no select at all
@@ -231,6 +247,69 @@ __device__ __forceinline__ double sweep_reg(double (&e)[NR], const double (&Areg
     for (int c = 0; c < NR; ++c) x.seam_out[c + 63] = e[(c + 63) % NR];
   }
   return dmax;
+}
+
+// ---------------------------------------------------------------- overlapped sweeps (mode kTail)
+// With all 64 lanes owning a row, the slot of a step is the same register in every lane no
+// matter which sweep the lane is in, as long as consecutive sweeps start exactly NR steps
+// apart: lane l then works on column (s - l) mod NR at global step s.  So lanes 0..j START
+// sweep k+1 during steps j = 0..62 of a period while lanes j+1..63 FINISH sweep k -- no lane
+// idles on the ramps, a sweep costs NR steps instead of NR + 63.  The price: whether sweep k
+// was the last one (simulator.py:360) is known only after step 62 (plus the tail pass), so the
+// start of sweep k+1 is speculative; every step of the window first copies the value it
+// overwrites (bk[j]), and the last period restores lanes <= j from the copies.  Max |delta|
+// goes to the accumulator of the lane's own sweep (dcur: sweep k, dnext: sweep k+1).
+#ifndef SB_ROLL
+#define SB_ROLL 1
+#endif
+constexpr bool kRoll = SB_ROLL != 0;
+constexpr int kWin = 63; // steps of a period in which the lanes are in two different sweeps
+
+template <int NR, int J>
+__device__ __forceinline__ void update_mixed(double (&e)[NR], double (&bk)[kWin], const Co &o, int lp,
+                                             double &dcur, double &dnext) {
+  constexpr int r = J, rm = (J + NR - 1) % NR, rp = J + 1;
+  const double U = wave_shift1<0x138, false>(e[rm], 0.0);
+  const double Dn = wave_shift1<0x130, true>(e[rp], o.smD);
+  double t = fma(o.bD, Dn, o.A);
+  t = fma(o.bR, e[rp], t);
+  t = fma(o.bL, e[rm], t);
+  const double nv = fma(o.bU, U, t);
+  const double d = nv - e[r];
+  bk[J] = e[r];
+  e[r] = nv;
+  // |d| into one accumulator, (almost) zero into the other: only the high word is switched,
+  // the low word alone is a subnormal < 5e-314
+  const bool nw = lanes_upto<J>(lp);
+  const int hi = __double2hiint(d), lo = __double2loint(d);
+  dnext = fmax(dnext, fabs(__hiloint2double(nw ? hi : 0, lo)));
+  dcur = fmax(dcur, fabs(__hiloint2double(nw ? 0 : hi, lo)));
+  // here, not after the window: e[J] and bk[J] both survive the window, so the compiler would
+  // sink all of this behind it and keep 63 lane masks alive (spilled SGPRs)
+  asm volatile("" : "+v"(dcur), "+v"(dnext));
+}
+
+// Steps D0 <= D < D1 of the overlapped schedule: D < 63 ramp-up of the first sweep (lanes > D
+// idle), 63 <= D < NR all lanes in one sweep, NR <= D < NR + 63 the mixed window.
+template <int NR, int D, int D1, int NAR>
+__device__ __forceinline__ void roll_steps(double (&e)[NR], double (&bk)[kWin], const double (&Areg)[NAR],
+                                           Pipe &p, const SweepCtx &x, double &dcur, double &dnext) {
+  if constexpr (D < D1) {
+    if constexpr (D % 8 == 0) p.cw[(D / 8 + 2) % 3] = x.cmap[opaque(0) + (D / 8 + 2) * 64];
+    if constexpr (D + kLook < D1) prefetch<NR, kTail, D + kLook>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
+    if constexpr (D < NR) update<NR, kTail, D>(e, p.co[D % (kLook + 1)], x.lp, x.rowmask, dcur);
+    else update_mixed<NR, D - NR>(e, bk, p.co[D % (kLook + 1)], x.lp, dcur, dnext);
+    __builtin_amdgcn_sched_barrier(0);
+    roll_steps<NR, D + 1, D1>(e, bk, Areg, p, x, dcur, dnext);
+  }
+}
+
+template <int NR, int J>
+__device__ __forceinline__ void roll_back(double (&e)[NR], const double (&bk)[kWin], int lp) {
+  if constexpr (J < kWin) {
+    e[J] = lanes_upto<J>(lp) ? bk[J] : e[J];
+    roll_back<NR, J + 1>(e, bk, lp);
+  }
 }
 
 // ---------------------------------------------------------------- tail rows (mode kTail)
@@ -373,8 +452,9 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   // live in AGPRs between their uses (the allocator spills what the sweep does not touch)
   // instead of costing a global round trip per building.  (The two-wavefront mode has no
   // registers to spare and reloads them.)
+  constexpr bool kReloadAmap = P == kPair || (P == kTail && kRoll); // no registers to spare
   unsigned long long amapw[kASlots];
-  if (P != kPair) {
+  if (!kReloadAmap) {
 #pragma unroll
     for (int g = 0; g < kASlots; ++g) amapw[g] = amap[g * 64];
   }
@@ -424,6 +504,11 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       if (P == kPair && lane == 0) *draw_slot = bn;
     }
     SB_STAMP(0);
+    if (kReloadAmap && P == kTail) { // issued here, used by the A pass: the setup hides the latency
+      const int o = opaque(0);
+#pragma unroll
+      for (int g = 0; g < kASlots; ++g) amapw[g] = amap[o + g * 64];
+    }
     double *T = a.temp + (size_t)b * a.state_doubles + R;
     double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 64; // mode kTail: [T][NR]
     __builtin_amdgcn_sched_barrier(0);
@@ -467,7 +552,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     double Areg[kNAR];
     Areg[0] = 0.0;
     if (rowvalid) {
-      if (P == kPair) {
+      if (kReloadAmap && P == kPair) {
         const int o = opaque(0);
 #pragma unroll
         for (int g = 0; g < kASlots; ++g) amapw[g] = amap[o + g * 64];
@@ -508,6 +593,54 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     SB_STAMP(2);
 
     int n_sweeps = 0, converged = 0;
+    if constexpr (P == kTail && kRoll) {
+      static_assert(P != kTail || NR > kWin + kLook, "the period must hold the mixed window");
+      SweepCtx xr = x;
+      asm volatile("" : "+v"(xr.lp)); // one v_cmp per step instead of hoisted, spilled masks
+      Pipe pp;
+      double dcur = 0.0, dnext = 0.0, bk[kWin];
+      pp.cw[0] = xr.cmap[opaque(0)];
+      pp.cw[1] = xr.cmap[opaque(0) + 64];
+      pp.cw[2] = 0;
+      prefetch<NR, P, 0>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
+      prefetch<NR, P, 1>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
+      __builtin_amdgcn_sched_barrier(0);
+      roll_steps<NR, 0, kWin>(e, bk, Areg, pp, xr, dcur, dnext);
+      // class bytes of steps 56..79: loaded before the tail pass that precedes their use
+      auto restart_classes = [&]() {
+        pp.cw[(kWin / 8) % 3] = xr.cmap[opaque(0) + (kWin / 8) * 64];
+        pp.cw[(kWin / 8 + 1) % 3] = xr.cmap[opaque(0) + (kWin / 8 + 1) * 64];
+        pp.cw[(kWin / 8 + 2) % 3] = xr.cmap[opaque(0) + (kWin / 8 + 2) * 64];
+      };
+      restart_classes();
+#pragma nounroll
+      for (;;) { // simulator.py:348-368
+        asm volatile("" : "+v"(xr.lp));
+        // the LDS reads of steps 63.. follow the tail pass of the previous sweep (row 63 reads
+        // the first tail row), so the read-ahead pipeline restarts here
+        prefetch<NR, P, kWin>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
+        prefetch<NR, P, kWin + 1>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
+        __builtin_amdgcn_sched_barrier(0);
+        roll_steps<NR, kWin, NR + kWin>(e, bk, Areg, pp, xr, dcur, dnext);
+        if (xr.edge) { // row 63 is still in sweep k: its new values for the tail scan
+#pragma unroll
+          for (int c = 0; c < NR; ++c) xr.seam_out[c + 63] = e[(c + 63) % NR];
+        }
+        restart_classes();
+        __builtin_amdgcn_wave_barrier();
+        double md = wave_max(fmax(dcur, tail_pass<NR>(a.T, lane, tab, tE, r63, At, tclsw)));
+        if (n_sweeps == 0) md = fmax(md, ring_d);
+        ++n_sweeps;
+        converged = md <= p.conv_threshold;
+        if (converged || n_sweeps >= p.iter_limit) {
+          asm volatile("" : "+v"(xr.lp));
+          roll_back<NR, 0>(e, bk, xr.lp); // undo the started sweep
+          break;
+        }
+        dcur = dnext;
+        dnext = 0.0;
+      }
+    } else
 #pragma nounroll
     for (int it = 0; it < p.iter_limit; ++it) { // simulator.py:348-368
       x.prog_base = it * 32; // the counter only grows within a building's step

@@ -359,6 +359,10 @@ class RegSweepModel:
     At = self.coef[tcls, 4] * tail + g[tcls] if self.T else None
     ring_d = max(abs(t_amb - ring.min()), abs(t_amb - ring.max())) if ring.size else 0.0
     n = 0
+    if schedule == "rolling":
+      assert self.mode == 3
+      n = self._fd_rolling(es[0], tail, As[0], At, tcls, ring_d, thr, iter_limit)
+      iter_limit = 0
     for it in range(iter_limit):
       if self.mode == 2:
         md = self._sweep_pair(es, As, schedule)
@@ -382,6 +386,61 @@ class RegSweepModel:
     out[ring_mask] = t_amb
     out[self.x0:self.x1 + 1, self.y0:self.y1 + 1] = self._store(es, tail)
     return out, n
+
+  def _fd_rolling(self, e, tail, A, At, tcls, ring_d, thr, iter_limit):
+    """Mode 3 with overlapped sweeps: period NR steps, lane l works on column (s - l) mod NR at
+    global step s, so lanes 0..j start sweep k+1 during steps j = 0..62 of the period while
+    lanes j+1..63 finish sweep k.  The stopping decision for sweep k falls after step 62 (and
+    the tail pass); the speculative updates of sweep k+1 are undone from per-step backups."""
+    NR = self.NR
+    lane = np.arange(64)
+
+    def step(D, first):
+      r, rm, rp = D % NR, (D - 1) % NR, (D + 1) % NR
+      col = (D - lane) if first else (D - lane) % NR
+      c = self._class(lane, col)
+      co = self.coef[c]
+      U = np.empty(64); U[1:] = e[:-1, rm]; U[0] = 0.0
+      Dn = np.empty(64); Dn[:-1] = e[1:, rp]
+      tc = col[63]
+      Dn[63] = tail[0, tc] if 0 <= tc < NR else 0.0
+      nv = co[:, 1] * Dn + A[:, r]
+      nv = co[:, 3] * e[:, rp] + nv
+      nv = co[:, 2] * e[:, rm] + nv
+      nv = co[:, 0] * U + nv
+      act = (lane <= D) if first else np.ones(64, bool)
+      sel = np.where(act, nv, e[:, r])
+      d = np.abs(sel - e[:, r])
+      old = e[:, r].copy()
+      e[:, r] = sel
+      return d, old
+
+    dcur = np.zeros(64)
+    for D in range(63):                       # ramp-up of sweep 0
+      d, _ = step(D, True)
+      dcur = np.maximum(dcur, d)
+    n = 0
+    while True:
+      for D in range(63, NR):                 # every lane inside sweep n
+        d, _ = step(D, False)
+        dcur = np.maximum(dcur, d)
+      dnext = np.zeros(64)
+      bk = []
+      for j in range(63):                     # lanes <= j: sweep n+1 (speculative); lanes > j: sweep n
+        d, old = step(NR + j, False)
+        bk.append(old)
+        dcur = np.maximum(dcur, np.where(lane > j, d, 0.0))
+        dnext = np.maximum(dnext, np.where(lane <= j, d, 0.0))
+      row63 = e[63, (np.arange(NR) + 63) % NR].copy()
+      md = max(float(dcur.max()), self._tail_pass(tail, At, tcls, row63))
+      if n == 0:
+        md = max(md, ring_d)
+      n += 1
+      if md <= thr or n >= iter_limit:
+        for j in range(63):
+          e[:, j] = np.where(lane <= j, bk[j], e[:, j])
+        return n
+      dcur = dnext
 
   def _tail_pass(self, tail, At, tcls, row63):
     """Rows 64.. by the recurrence x_c = bL x_{c-1} + q_c (scan order of operations: the q's are

@@ -57,6 +57,8 @@ def _r9_like(rooms, room_shape):
     ((2, 3), (9, 10), False, 1, "tight"),     # 23x36: one wavefront, 66 slots
     ((3, 3), (20, 30), False, 3, "tight"),    # R9, lanes = rows: 64 rows + 2 tail rows, 96 slots
     ((2, 3), (30, 30), False, 3, "tight"),    # one tail row
+    ((3, 3), (20, 30), False, 3, "rolling"),  # R9 with overlapped sweeps (speculative start + undo)
+    ((2, 3), (30, 30), False, 3, "rolling"),
     ((3, 3), (20, 30), True, 2, "tight"),     # R9, lanes = columns: two wavefronts, wave 1 as early as allowed
     ((3, 3), (20, 30), True, 2, "late"),      # ... and as late as possible: same grid
     ((2, 5), (30, 12), True, 2, "tight"),     # uneven split
