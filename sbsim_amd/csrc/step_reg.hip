@@ -339,50 +339,45 @@ __device__ __forceinline__ void affine_scan(double &a, double &q) {
 }
 
 constexpr int kTailMax = 2;
+// A lane owns two neighbouring columns of a tail row: NR <= 128 columns are one 64-lane scan.
+__device__ __forceinline__ int tail_col(int lane, int k) { return 2 * lane + k; }
 
 // One Gauss-Seidel pass over the tail rows; returns the lane's max |delta|.
 // tE: [T][NR+2] current values (column c at [1 + c]); r63: new values of row 63 by column.
-// A row is NR <= 128 columns = two 64-lane blocks whose scans are independent until the
-// carry (x of column 63) enters the second one, so both run interleaved.
+// The lane first composes the maps of its two columns (x_{2l+1} = bL1*(bL0*x + q0) + q1),
+// the scan runs over the 64 composed maps, and the even column follows from its left
+// neighbour's result.
 template <int NR>
 __device__ __forceinline__ double tail_pass(int T, int lane, const double *tab, double *tE, const double *r63,
                                             const double (&At)[kTailMax][2], unsigned tclsw) {
-  constexpr int kBlk = (NR + 63) / 64, kRow = NR + 2, kTS = table_stride(NR, kTail);
+  constexpr int kRow = NR + 2, kTS = table_stride(NR, kTail);
   static_assert(kTS == 32, "the tail-row class bytes are byte offsets");
+  static_assert(NR % 2 == 0 && NR <= 128, "two columns per lane");
+  const bool active = 2 * lane < NR;
+  const int c0 = active ? 2 * lane : NR - 2;
   double dmax = 0.0;
 #pragma unroll
   for (int t = 0; t < kTailMax; ++t) {
     if (t < T) {
       double *row = tE + t * kRow + 1;
-      double aa[kBlk], q[kBlk], old[kBlk];
-#pragma unroll
-      for (int blk = 0; blk < kBlk; ++blk) {
-        const int c = blk * 64 + lane;
-        const int cc = c < NR ? c : NR - 1;
-        const int cls8 = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
-        const double *bt = (const double *)((const char *)tab + cls8);
-        const double bU = bt[0], bD = bt[kTS], bL = bt[2 * kTS], bR = bt[3 * kTS];
-        const double U = t == 0 ? r63[cc] : row[cc - kRow];
-        const double Dn = t + 1 < T ? row[cc + kRow] : 0.0;
-        const double Rn = row[cc + 1];
-        old[blk] = row[cc];
-        q[blk] = fma(bU, U, fma(bR, Rn, fma(bD, Dn, At[t][blk])));
-        aa[blk] = bL;
-      }
-#pragma unroll
-      for (int blk = 0; blk < kBlk; ++blk) affine_scan(aa[blk], q[blk]);
+      const double *bt0 = (const double *)((const char *)tab + (int)((tclsw >> (8 * (t * 2))) & 0xffu));
+      const double *bt1 = (const double *)((const char *)tab + (int)((tclsw >> (8 * (t * 2 + 1))) & 0xffu));
+      const double bU0 = bt0[0], bD0 = bt0[kTS], bL0 = bt0[2 * kTS], bR0 = bt0[3 * kTS];
+      const double bU1 = bt1[0], bD1 = bt1[kTS], bL1 = bt1[2 * kTS], bR1 = bt1[3 * kTS];
+      const double old0 = row[c0], old1 = row[c0 + 1], R1 = row[c0 + 2];
+      const double U0 = t == 0 ? r63[c0] : row[c0 - kRow], U1 = t == 0 ? r63[c0 + 1] : row[c0 + 1 - kRow];
+      const double D0 = t + 1 < T ? row[c0 + kRow] : 0.0, D1 = t + 1 < T ? row[c0 + 1 + kRow] : 0.0;
+      const double q0 = fma(bU0, U0, fma(bR0, old1, fma(bD0, D0, At[t][0]))); // right neighbour: not yet updated
+      const double q1 = fma(bU1, U1, fma(bR1, R1, fma(bD1, D1, At[t][1])));
+      double a = bL1 * bL0, Q = fma(bL1, q0, q1);
+      affine_scan(a, Q); // Q: the odd column (the row starts from bL = 0: no carry-in)
+      const double xl = wave_shift1<0x138, false>(Q, 0.0); // column 2l - 1
+      const double x0 = fma(bL0, xl, q0);
       __builtin_amdgcn_wave_barrier(); // every read of the row's old values is done
-      double carry = 0.0;
-#pragma unroll
-      for (int blk = 0; blk < kBlk; ++blk) {
-        const int c = blk * 64 + lane;
-        const double xv = fma(aa[blk], carry, q[blk]);
-        if (c < NR) {
-          dmax = fmax(dmax, fabs(xv - old[blk]));
-          row[c] = xv;
-        }
-        carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xv), 63),
-                                 __builtin_amdgcn_readlane(__double2loint(xv), 63));
+      if (active) {
+        dmax = fmax(dmax, fmax(fabs(x0 - old0), fabs(Q - old1)));
+        row[c0] = x0;
+        row[c0 + 1] = Q;
       }
       __builtin_amdgcn_wave_barrier(); // the next row reads this one
     }
@@ -439,8 +434,8 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   unsigned tclsw = 0; // mode kTail: classes of the lane's tail cells, byte [t*2 + block]
   if (P == kTail)
     for (int t = 0; t < a.T; ++t)
-      for (int blk = 0; blk < (NR + 63) / 64; ++blk)
-        tclsw |= (unsigned)a.tcls[t * NR + min(blk * 64 + lane, NR - 1)] << (8 * (t * 2 + blk));
+      for (int k = 0; k < 2; ++k)
+        tclsw |= (unsigned)a.tcls[t * NR + min(tail_col(lane, k), NR - 1)] << (8 * (t * 2 + k));
   x.prog = (volatile int *)(xchg + 6);
   x.role = w; x.lag = a.lag; x.nch0 = a.nch[0]; x.prog_base = 0;
   const unsigned long long *amap = a.amapS + (size_t)w * kASlots * 64 + lane;
@@ -482,8 +477,8 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     if (P == kTail) {                                                                           \
       const double *tt_ = a.temp + (size_t)(bb) * a.state_doubles + NR * 64;                    \
       _Pragma("unroll") for (int t = 0; t < kTailMax; ++t)                                      \
-        _Pragma("unroll") for (int blk = 0; blk < (NR + 63) / 64; ++blk)                        \
-          if (t < a.T) nx_tail[t][blk] = tt_[t * NR + min(blk * 64 + lane, NR - 1)];            \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                           \
+          if (t < a.T) nx_tail[t][k] = tt_[t * NR + min(tail_col(lane, k), NR - 1)];            \
     }                                                                                           \
   } while (0)
   if ((int)blockIdx.x < a.B) {
@@ -526,8 +521,8 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
 #pragma unroll
         for (int t = 0; t < kTailMax; ++t)
 #pragma unroll
-          for (int blk = 0; blk < (NR + 63) / 64; ++blk)
-            if (t < a.T && blk * 64 + lane < NR) tE[t * (NR + 2) + 1 + blk * 64 + lane] = nx_tail[t][blk];
+          for (int k = 0; k < 2; ++k)
+            if (t < a.T && tail_col(lane, k) < NR) tE[t * (NR + 2) + 1 + tail_col(lane, k)] = nx_tail[t][k];
       }
     }
     if (P == kPair) __syncthreads(); else __builtin_amdgcn_wave_barrier();
@@ -539,11 +534,11 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
 #pragma unroll
       for (int t = 0; t < kTailMax; ++t)
 #pragma unroll
-        for (int blk = 0; blk < (NR + 63) / 64; ++blk)
+        for (int k = 0; k < 2; ++k)
           if (t < a.T) {
-            const int cls8 = (int)((tclsw >> (8 * (t * 2 + blk))) & 0xffu);
-            const double tp = tE[t * (NR + 2) + 1 + min(blk * 64 + lane, NR - 1)];
-            At[t][blk] = fma(*(const double *)((const char *)(tab + 4 * kTS) + cls8), tp,
+            const int cls8 = (int)((tclsw >> (8 * (t * 2 + k))) & 0xffu);
+            const double tp = tE[t * (NR + 2) + 1 + min(tail_col(lane, k), NR - 1)];
+            At[t][k] = fma(*(const double *)((const char *)(tab + 4 * kTS) + cls8), tp,
                              *(const double *)((const char *)gtab + cls8));
           }
     }
