@@ -202,6 +202,53 @@ def test_divergent_buildings_against_oracle():
     assert np.abs(grid[b] - twins[b].grid()).max() < T_TOL, b
 
 
+@pytest.mark.parametrize("limit", [1, 2, 5])
+def test_iteration_limit_ends_the_step(limit):
+  """simulator.py:348-368 with a limit that bites (the golden rollouts always converge): the
+  register kernel starts sweep k+1 before it knows that sweep k was the last one allowed and has
+  to undo it; sweep counts and grids against the oracle."""
+  _need_gpu()
+  import dataclasses
+  g = load("h2_sb1_r9_random.npz")
+  p = load("plan_r9_sb1.npz")
+  B, T = 6, 8
+  rs = np.random.RandomState(3)
+  init = np.clip(294.0 + rs.randn(B, 1, 1) + 0.3 * rs.randn(B, 68, 98), 285.0, 305.0)
+  acts = rs.uniform(-1, 1, size=(T, B, 2)).astype(np.float32)
+  cfg = dataclasses.replace(SimConfig.sb1(), iteration_limit=limit)
+  sim = BatchedSimulator(_plan(p), cfg, B, float(g["h_conv"]))
+  assert sim.launch_info["path"] == 1
+  sim.reset(temps=torch.tensor(init.reshape(B, -1), dtype=torch.float64, device="cuda"))
+  plan, prm = oracle_plan(p), oracle_params(g["params_json"], iter_limit=limit)
+  twins = [orc.OracleBuilding(plan, prm, 0.0, reset_temps=init[b].reshape(-1)) for b in range(B)]
+  obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  rng_w, rng_a = (310.0, 355.0), (285.0, 300.0)
+  hit = 0
+  for t in range(T):
+    sim.step(torch.tensor(acts[t], device="cuda"), _step_in(g, t + 100), obs, rew, info)
+    i = info.cpu().numpy().astype(np.float64)
+    for b in range(B):
+      a = acts[t, b]
+      native = [np.float32((float(a[0]) + 1.0) / 2.0 * (rng_w[1] - rng_w[0]) + rng_w[0]),
+                np.float32((float(a[1]) + 1.0) / 2.0 * (rng_a[1] - rng_a[0]) + rng_a[0])]
+      tt = t + 100
+      o = twins[b].step(
+          now_ts=300.0 * t, t_amb_now=float(g["t_amb_now"][tt]), h_conv=float(g["h_conv"]),
+          t_amb_next=float(g["t_amb_next"][tt]), comfort_now=bool(g["comfort_now"][tt]),
+          comfort_prev=g["comfort_prev"][tt] == 1, comfort_next=bool(g["comfort_next"][tt]),
+          occupancy=float(g["occupancy"][tt]), e_price=float(g["e_price"][tt]),
+          e_carbon=float(g["e_carbon"][tt]), g_price=float(g["g_price"][tt]),
+          g_carbon=float(g["g_carbon"][tt]), action=native, observe=True)
+      assert i[b, 4] == o["n_sweeps"] <= limit, (t, b, i[b, 4], o["n_sweeps"])
+      hit += int(o["n_sweeps"] == limit)
+  assert hit > 0
+  grid = sim.temps().cpu().numpy()
+  for b in range(B):
+    assert np.abs(grid[b] - twins[b].grid()).max() < T_TOL, b
+
+
 def test_per_building_weather_and_per_zone_occupancy():
   """The optional DEVICE inputs of sb_step_in: `t_amb_dev` [B][2] (every building its own
   ambient temperature now / next) and `occupancy_dev` [Z] (per-zone occupancy) -- BASELINE.json

@@ -98,3 +98,26 @@ def test_seam_lag_is_tight():
   m.lag -= 1
   with pytest.raises(AssertionError, match="before wave 0 published"):
     m.fd_timestep(prev, 280.0, np.zeros(cp.Z), 0.05, 2, schedule="tight")
+
+
+def test_overlapped_sweeps_stop_at_the_iteration_limit():
+  """The started sweep is undone when the limit, not convergence, ends the step."""
+  from tests.kernel_model import RegSweepModel
+  fp = _r9_like((3, 3), (20, 30))
+  dt, h = 300.0, 100.0
+  cp = fp.compile(dt, h)
+  m = RegSweepModel(cp)
+  rs = np.random.RandomState(11)
+  H, W = fp.shape
+  prev = np.clip(293.0 + 1.5 * rs.randn(H, W), 285.0, 300.0)
+  qz = rs.uniform(-400.0, 900.0, size=cp.Z)
+  q = np.zeros((H, W))
+  for z, cells in enumerate(fp.zone_cell_lists()):
+    q.reshape(-1)[cells] = qz[z] * fp.diffusers.reshape(-1)[cells]
+  plan = orc.OraclePlan(fp.conductivity, fp.density, fp.heat_capacity, fp.exterior_space,
+                        fp.zone_cell_lists(), fp.diffusers, fp.cv_size_cm, fp.floor_height_cm)
+  for limit in (1, 3):
+    ref, n_ref, _ = orc.fd_timestep(plan, prev, q, 279.5, h, dt, 1e-9, limit)
+    got, n_got = m.fd_timestep(prev, 279.5, qz, 1e-9, limit, schedule="rolling")
+    assert n_got == n_ref == limit
+    assert np.abs(got - ref).max() < 1e-10
