@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 3
+#define SB_ABI_VERSION 4
 #define SB_NUM_ACTIONS 2   /* boiler supply_water_setpoint, AHU supply_air_heating_temperature_setpoint */
 #define SB_NUM_AUX 7       /* hod cos/sin, dow cos/sin, comfort_now, comfort_soon, num_occupants */
 #define SB_INFO_STRIDE 8   /* floats per building in the optional info output */
@@ -124,6 +124,12 @@ typedef struct sb_step_in {
   int32_t has_action;      /* 0 = thermostat-only step (bare Simulator.step_sim) */
   double occupancy;        /* average_zone_occupancy over [t+dt, t+2dt], all zones */
   const double *occupancy_dev; /* optional DEVICE [Z] per-zone occupancy; overrides */
+  /* optional per-building occupancy (sb_occupancy_peek): overrides both of the above */
+  const float *occupancy_bz_dev;  /* DEVICE [B][Z] occupants at work in the reward interval */
+  const float *num_occupants_dev; /* DEVICE [B] SimulatorBuilding.num_occupants at t+dt: the device
+                                   * writes aux feature 6 = (n - occupancy_norm) / (occupancy_norm + 1)
+                                   * (environment.py:951-955) instead of aux[6] */
+  double occupancy_norm;
   double e_price, e_carbon;    /* electricity USD/W/s, kg/W/s at reward start_time.hour */
   double g_price, g_carbon;    /* natural gas USD/J, kg/J at reward start_time.month */
   float aux[SB_NUM_AUX];       /* auxiliary observation features at t+dt, already fp32 */
@@ -159,6 +165,9 @@ int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *s
  * t_amb_dev: optional DEVICE [B] per-building ambient temperature (overrides t_amb). */
 int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
                float *obs_dev, void *stream);
+/* ... with per-building num_occupants (DEVICE [B], see sb_step_in.num_occupants_dev) */
+int sb_observe_occupancy(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
+                         const float *num_occupants_dev, double occupancy_norm, float *obs_dev, void *stream);
 
 /* One Environment._step for every building.  actions_dev [B][2] fp32 in [-1,1] (or NULL
  * when in->has_action == 0); obs_dev [B][O] fp32; reward_dev [B] fp32; info_dev optional
@@ -177,6 +186,29 @@ int sb_step(sb_handle *h, const float *actions_dev, const sb_step_in *in, float 
 #define SB_PHASE_POST 4
 int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in, float *obs_dev,
                    float *reward_dev, float *info_dev, void *stream, int32_t phases);
+
+/* SURVEY.md 8(f) rank 2 -- RandomizedArrivalDepartureOccupancy
+ * (simulator/randomized_arrival_departure_occupancy.py:41-218), one independent instance per
+ * building, on the device.  Every occupant is the reference's two-state machine (AWAY/WORK,
+ * one Bernoulli trial per query inside the arrival / departure window, nobody on non-working
+ * days); the trials come from Philox4x32-10 keyed by `seed` with counter (global building
+ * index, zone, query number), so results do not depend on how a batch is sharded -- and are
+ * statistically, not bitwise, those of np.random.RandomState.  The calendar stays on the host:
+ * the caller passes the local hour and whether the local day is a working day. */
+typedef struct sb_occupancy_config {
+  int32_t zone_assignment; /* occupants per zone, 1..32 */
+  int32_t earliest_arrival_hour, latest_arrival_hour, earliest_departure_hour, latest_departure_hour;
+  double time_step_sec;
+  uint64_t seed;
+  int64_t first_building; /* global index of this handle's building 0 */
+} sb_occupancy_config;
+/* Creates (or re-creates) the handle's occupants, all AWAY, query counter 0. */
+int sb_occupancy_attach(sb_handle *h, const sb_occupancy_config *cfg);
+/* One average_zone_occupancy(zone, start_time, .) for every zone of every building: advances
+ * every occupant once and writes the occupants at work -- count_dev [B][Z] fp32 and/or
+ * total_dev [B] fp32 (either may be NULL). */
+int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, float *count_dev,
+                      float *total_dev, void *stream);
 
 /* Parity taps (all DEVICE outputs, float64). */
 int sb_get_temps(sb_handle *h, double *out_dev /* [B][H*W] */, void *stream);

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("SBSIM_LIB") or os.path.join(_HERE, "libsbsim_amd.so")
 
 SB_NUM_ACTIONS = 2
 SB_NUM_AUX = 7
-SB_ABI_VERSION = 3   # include/sbsim_amd.h
+SB_ABI_VERSION = 4   # include/sbsim_amd.h
 SB_INFO_STRIDE = 8
 SB_NUM_SCALARS = 16
 
@@ -63,9 +63,17 @@ class StepIn(C.Structure):
               ("comfort_now", C.c_int32), ("comfort_prev", C.c_int32),
               ("comfort_next", C.c_int32), ("has_action", C.c_int32),
               ("occupancy", C.c_double), ("occupancy_dev", C.c_void_p),
+              ("occupancy_bz_dev", C.c_void_p), ("num_occupants_dev", C.c_void_p), ("occupancy_norm", C.c_double),
               ("e_price", C.c_double), ("e_carbon", C.c_double),
               ("g_price", C.c_double), ("g_carbon", C.c_double),
               ("aux", C.c_float * SB_NUM_AUX)]
+
+
+class OccupancyConfig(C.Structure):
+  _fields_ = [("zone_assignment", C.c_int32), ("earliest_arrival_hour", C.c_int32),
+              ("latest_arrival_hour", C.c_int32), ("earliest_departure_hour", C.c_int32),
+              ("latest_departure_hour", C.c_int32), ("time_step_sec", C.c_double),
+              ("seed", C.c_uint64), ("first_building", C.c_int64)]
 
 
 class LaunchInfo(C.Structure):
@@ -77,7 +85,7 @@ class LaunchInfo(C.Structure):
 
 
 EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",
-           "sb_reset", "sb_observe", "sb_step", "sb_step_phases", "sb_get_temps", "sb_get_zone_temps",
+           "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_step", "sb_step_phases", "sb_get_temps", "sb_get_zone_temps",
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles")
 
 _lib = None
@@ -108,6 +116,9 @@ def load():
   L.sb_get_launch_info.argtypes = [vp, C.POINTER(LaunchInfo)]
   L.sb_reset.argtypes = [vp, C.c_double, vp, vp]
   L.sb_observe.argtypes = [vp, C.POINTER(C.c_float), C.c_double, vp, vp, vp]
+  L.sb_observe_occupancy.argtypes = [vp, C.POINTER(C.c_float), C.c_double, vp, vp, C.c_double, vp, vp]
+  L.sb_occupancy_attach.argtypes = [vp, C.POINTER(OccupancyConfig)]
+  L.sb_occupancy_peek.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
   L.sb_step.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp]
   L.sb_step_phases.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp, C.c_int32]
   for name in ("sb_get_temps", "sb_get_zone_temps", "sb_get_scalars", "sb_get_modes",

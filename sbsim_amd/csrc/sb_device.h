@@ -216,7 +216,7 @@ __device__ __forceinline__ void put_obs(const Dev &a, float *row, int src, doubl
 // (kNScalOut doubles).  Device columns in sorted (device, field) order (air_handler.py:66-95 /
 // boiler.py:69-79).
 __device__ inline void write_obs(const Dev &a, int b, float *obs, const float *aux, double t_amb_obs,
-                                 const double *S) {
+                                 const double *S, const float *num_occupants = nullptr, double occ_norm = 0.0) {
   float *row = obs + (size_t)b * a.O;
   for (int k = 0; k < a.n_hist; ++k)
     for (int j = a.hist_off[k]; j < a.hist_off[k + 1]; ++j) row[a.hist_col[k] + j - a.hist_off[k]] = 0.0f;
@@ -257,6 +257,8 @@ __device__ inline void write_obs(const Dev &a, int b, float *obs, const float *a
       for (int j = 0; j < n; ++j) h[j] = (float)((double)h[j] / tot);
     }
   for (int i = 0; i < SB_NUM_AUX; ++i) row[a.col_aux + i] = aux[i];
+  if (num_occupants) // environment.py:951-955 with the building's own int(num_occupants)
+    row[a.col_aux + SB_NUM_AUX - 1] = (float)(((double)(int)num_occupants[b] - occ_norm) / (occ_norm + 1.0));
 }
 
 // ---------------------------------------------------------------- the step around the sweep
@@ -373,7 +375,9 @@ __device__ inline void post_building(const Dev &a, const StepArgs &s, int b) {
     const double tzp = a.zsum[zb + z] / (double)(a.zone_off[z + 1] - a.zone_off[z]);
     a.zmean[zb + z] = tzp;
     const double t = (double)(float)tzp;
-    const double occ = (double)(float)(in.occupancy_dev ? in.occupancy_dev[z] : in.occupancy);
+    const double occ = in.occupancy_bz_dev
+                           ? (double)in.occupancy_bz_dev[zb + z]
+                           : (double)(float)(in.occupancy_dev ? in.occupancy_dev[z] : in.occupancy);
     double prod; // base_setpoint_energy_carbon_reward.py:78-123
     if (t < hsp2) prod = p.max_prod / (1.0 + exp(-p.prod_stiff * (t - (hsp2 - p.prod_delta))));
     else if (t > csp2)
@@ -427,7 +431,7 @@ __device__ inline void post_building(const Dev &a, const StepArgs &s, int b) {
     I[0] = blower; I[1] = ac; I[2] = gas; I[3] = pump;
     I[4] = (float)n_sweeps; I[5] = (float)converged; I[6] = (float)v.t_sa; I[7] = (float)reward;
   }
-  if (s.obs) write_obs(a, b, s.obs, in.aux, v.t_next, S);
+  if (s.obs) write_obs(a, b, s.obs, in.aux, v.t_next, S, in.num_occupants_dev, in.occupancy_norm);
 }
 
 } // namespace sb

@@ -103,10 +103,67 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps) {
 }
 
 __global__ void k_observe(Dev a, float *obs, float aux0, float aux1, float aux2, float aux3,
-                          float aux4, float aux5, float aux6, double t_amb, const double *t_amb_b) {
+                          float aux4, float aux5, float aux6, double t_amb, const double *t_amb_b,
+                          const float *num_occupants, double occ_norm) {
   const float aux[SB_NUM_AUX] = {aux0, aux1, aux2, aux3, aux4, aux5, aux6};
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
-    write_obs(a, b, obs, aux, t_amb_b ? t_amb_b[b] : t_amb, a.scal + (size_t)b * kNScal);
+    write_obs(a, b, obs, aux, t_amb_b ? t_amb_b[b] : t_amb, a.scal + (size_t)b * kNScal, num_occupants, occ_norm);
+}
+
+// ---------------------------------------------------------------- randomized occupancy
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): ten
+// rounds of two 32x32 -> 64 multiplies on a 128-bit counter under a 64-bit key.
+__device__ inline void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+struct OccArgs {
+  uint32_t *state; // [B][Z]: bit i = occupant i of the zone is at WORK
+  int B, Z, n_occ, hour, workday, e_arr, l_arr, e_dep;
+  double p_arr, p_dep;
+  uint64_t seed;
+  long long first_building;
+  uint32_t query;
+  float *count, *total;
+};
+
+// ZoneOccupant.peek (randomized_arrival_departure_occupancy.py:138-160) for every occupant of
+// every zone of one building per thread.  Uniform of occupant i: word i & 3 of the Philox block
+// with counter (building lo, building hi, zone, query * 8 + (i >> 2)), u = (x >> 8) / 2^24.
+__global__ void k_occupancy(OccArgs o) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < o.B; b += gridDim.x * blockDim.x) {
+    const unsigned long long gb = (unsigned long long)(o.first_building + b);
+    float tot = 0.0f;
+    for (int z = 0; z < o.Z; ++z) {
+      uint32_t st = o.state[(size_t)b * o.Z + z];
+      if (!o.workday) st = 0;
+      else {
+        const bool arr_open = !(o.hour < o.e_arr || o.hour > o.l_arr), dep_open = !(o.hour < o.e_dep);
+        if (arr_open || dep_open)
+          for (int blk = 0; blk * 4 < o.n_occ; ++blk) {
+            uint32_t c[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)z, o.query * 8u + (uint32_t)blk};
+            philox4x32_10(c, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
+            for (int k = 0; k < 4 && blk * 4 + k < o.n_occ; ++k) {
+              const int i = blk * 4 + k;
+              const double u = (double)(c[k] >> 8) * (1.0 / 16777216.0);
+              const bool at_work = (st >> i) & 1u;
+              if (!at_work && arr_open && u < o.p_arr) st |= 1u << i;
+              else if (at_work && dep_open && u < o.p_dep) st &= ~(1u << i);
+            }
+          }
+      }
+      o.state[(size_t)b * o.Z + z] = st;
+      const float n = (float)__popc(st);
+      if (o.count) o.count[(size_t)b * o.Z + z] = n;
+      tot += n;
+    }
+    if (o.total) o.total[b] = tot;
+  }
 }
 
 // building.temp in the caller's row-major layout, whichever state layout the handle uses.
@@ -461,6 +518,10 @@ struct sb_handle {
   DevBuf<int4> sched;
   DevBuf<unsigned long long> smask, cmapS, amapS, zmapS;
   DevBuf<long long> dbg;
+  DevBuf<uint32_t> occ_state; // sb_occupancy_attach
+  sb_occupancy_config occ{};
+  uint32_t occ_queries = 0;
+  bool occ_attached = false;
 };
 
 namespace {
@@ -726,13 +787,63 @@ int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *s
   return SB_OK;
 }
 
-int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
-               float *obs_dev, void *stream) {
+int sb_observe_occupancy(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
+                         const float *num_occupants_dev, double occupancy_norm, float *obs_dev, void *stream) {
   if (!h || !aux || !obs_dev) return fail(SB_ERR_INVALID, "sb_observe: null argument");
   SB_HIP(hipSetDevice(h->device));
   const int blocks = std::max(1, std::min((h->d.B + 63) / 64, 4096));
   hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->d, obs_dev, aux[0],
-                     aux[1], aux[2], aux[3], aux[4], aux[5], aux[6], t_amb, t_amb_dev);
+                     aux[1], aux[2], aux[3], aux[4], aux[5], aux[6], t_amb, t_amb_dev, num_occupants_dev,
+                     occupancy_norm);
+  SB_HIP(hipGetLastError());
+  return SB_OK;
+}
+
+int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
+               float *obs_dev, void *stream) {
+  return sb_observe_occupancy(h, aux, t_amb, t_amb_dev, nullptr, 0.0, obs_dev, stream);
+}
+
+int sb_occupancy_attach(sb_handle *h, const sb_occupancy_config *cfg) {
+  if (!h || !cfg) return fail(SB_ERR_INVALID, "sb_occupancy_attach: null argument");
+  if (cfg->zone_assignment < 1 || cfg->zone_assignment > 32)
+    return fail(SB_ERR_INVALID, "sb_occupancy_attach: zone_assignment must be 1..32 (one state word per zone)");
+  if (!(cfg->earliest_arrival_hour < cfg->latest_arrival_hour &&
+        cfg->latest_arrival_hour < cfg->earliest_departure_hour &&
+        cfg->earliest_departure_hour < cfg->latest_departure_hour))
+    return fail(SB_ERR_INVALID, "sb_occupancy_attach: hours must be strictly increasing "
+                                "(randomized_arrival_departure_occupancy.py:68-73)");
+  if (!(cfg->time_step_sec > 0) || cfg->first_building < 0)
+    return fail(SB_ERR_INVALID, "sb_occupancy_attach: time_step_sec must be positive, first_building >= 0");
+  SB_HIP(hipSetDevice(h->device));
+  if (!h->occ_state.p) {
+    const int rc = alloc_zero(h->occ_state, (size_t)h->d.B * h->d.Z);
+    if (rc != SB_OK) return rc;
+  } else SB_HIP(hipMemset(h->occ_state.p, 0, (size_t)h->d.B * h->d.Z * sizeof(uint32_t)));
+  h->occ = *cfg;
+  h->occ_queries = 0;
+  h->occ_attached = true;
+  return SB_OK;
+}
+
+int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, float *count_dev,
+                      float *total_dev, void *stream) {
+  if (!h) return fail(SB_ERR_INVALID, "sb_occupancy_peek: null handle");
+  if (!h->occ_attached) return fail(SB_ERR_INVALID, "sb_occupancy_peek: sb_occupancy_attach first");
+  if (local_hour < 0 || local_hour > 23) return fail(SB_ERR_INVALID, "sb_occupancy_peek: hour must be 0..23");
+  SB_HIP(hipSetDevice(h->device));
+  const sb_occupancy_config &c = h->occ;
+  OccArgs o;
+  o.state = h->occ_state.p; o.B = h->d.B; o.Z = h->d.Z; o.n_occ = c.zone_assignment;
+  o.hour = local_hour; o.workday = is_work_day != 0;
+  o.e_arr = c.earliest_arrival_hour; o.l_arr = c.latest_arrival_hour; o.e_dep = c.earliest_departure_hour;
+  // _get_event_probability (:100-112): 1 / (half the window in time steps)
+  o.p_arr = 1.0 / ((double)(c.latest_arrival_hour - c.earliest_arrival_hour) * 3600.0 / c.time_step_sec / 2.0);
+  o.p_dep = 1.0 / ((double)(c.latest_departure_hour - c.earliest_departure_hour) * 3600.0 / c.time_step_sec / 2.0);
+  o.seed = c.seed; o.first_building = c.first_building; o.query = h->occ_queries++;
+  o.count = count_dev; o.total = total_dev;
+  const int blocks = std::max(1, std::min((o.B + 63) / 64, 4096));
+  hipLaunchKernelGGL(k_occupancy, dim3(blocks), dim3(64), 0, (hipStream_t)stream, o);
   SB_HIP(hipGetLastError());
   return SB_OK;
 }

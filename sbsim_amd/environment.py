@@ -246,6 +246,7 @@ class BatchedSimulator:
       raise ValueError("orientation must be 'auto', 'rows' or 'columns'")
     self.Z, self.H, self.W = plan.n_zones, H0, W0
     zone_names = list(zone_names or plan.zone_names or [f"room_{i + 1}" for i in range(self.Z)])
+    self.zone_names = zone_names
     (source_names, col_ahu, col_blr, col_zone, n_src) = observation_field_names(
         zone_names, config.ahu_has_weather_sensor)
     aux_names, source_names = source_names[n_src:], source_names[:n_src]
@@ -344,8 +345,27 @@ class BatchedSimulator:
     t0 = self.config.initial_temp if initial_temp is None else float(initial_temp)
     _ffi.check(self._lib.sb_reset(self._h, t0, ptr, self._stream()), "sb_reset")
 
-  def observe(self, aux: Sequence[float], t_amb, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """t_amb: one ambient temperature, or a float64 [B] device tensor (per-building weather)."""
+  def occupancy_attach(self, zone_assignment: int, hours: Sequence[int], time_step_sec: float, seed: int,
+                       first_building: int = 0) -> None:
+    """sb_occupancy_attach: one RandomizedArrivalDepartureOccupancy per building on the device."""
+    cfg = _ffi.OccupancyConfig(int(zone_assignment), int(hours[0]), int(hours[1]), int(hours[2]), int(hours[3]),
+                               float(time_step_sec), int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_building))
+    _ffi.check(self._lib.sb_occupancy_attach(self._h, C.byref(cfg)), "sb_occupancy_attach")
+
+  def occupancy_peek(self, local_hour: int, is_work_day: bool, count: Optional[torch.Tensor] = None,
+                     total: Optional[torch.Tensor] = None) -> None:
+    """sb_occupancy_peek: advances every occupant once; count [B, Z] / total [B] float32."""
+    for t, shape in ((count, (self.B, self.Z)), (total, (self.B,))):
+      if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous()):
+        raise ValueError(f"occupancy output must be a contiguous float32 {shape} tensor")
+    _ffi.check(self._lib.sb_occupancy_peek(
+        self._h, int(local_hour), int(bool(is_work_day)), C.c_void_p(count.data_ptr()) if count is not None else None,
+        C.c_void_p(total.data_ptr()) if total is not None else None, self._stream()), "sb_occupancy_peek")
+
+  def observe(self, aux: Sequence[float], t_amb, out: Optional[torch.Tensor] = None,
+              num_occupants: Optional[torch.Tensor] = None, occupancy_norm: float = 0.0) -> torch.Tensor:
+    """t_amb: one ambient temperature, or a float64 [B] device tensor (per-building weather).
+    num_occupants: optional float32 [B] device tensor (per-building occupancy feature)."""
     out = out if out is not None else torch.empty((self.B, self.O), dtype=torch.float32, device=self.tdev)
     a = (C.c_float * _ffi.SB_NUM_AUX)(*[float(x) for x in aux])
     per_b = None
@@ -353,8 +373,9 @@ class BatchedSimulator:
       if t_amb.dtype != torch.float64 or tuple(t_amb.shape) != (self.B,):
         raise ValueError("per-building t_amb must be a float64 [B] tensor")
       per_b, t_amb = C.c_void_p(t_amb.contiguous().data_ptr()), 0.0
-    _ffi.check(self._lib.sb_observe(self._h, a, float(t_amb), per_b, C.c_void_p(out.data_ptr()),
-                                    self._stream()), "sb_observe")
+    _ffi.check(self._lib.sb_observe_occupancy(
+        self._h, a, float(t_amb), per_b, C.c_void_p(num_occupants.data_ptr()) if num_occupants is not None else None,
+        float(occupancy_norm), C.c_void_p(out.data_ptr()), self._stream()), "sb_observe")
     return out
 
   def step(self, actions: Optional[torch.Tensor], step_in: _ffi.StepIn, obs: torch.Tensor,
@@ -433,6 +454,12 @@ class BatchedEnvironment:
         raise ValueError("BatchedSinusoidWeather needs one (low, high) pair per building")
       self._weather_lohi = torch.tensor(np.stack([self.weather.low, self.weather.high], axis=1),
                                         dtype=torch.float64, device=self.sim.tdev).contiguous()
+    self._occ_count = self._occ_total = None
+    if isinstance(self.occupancy, host_inputs.BatchedRandomizedArrivalDepartureOccupancy):
+      o = self.occupancy   # per-building occupants live on the device
+      self.sim.occupancy_attach(o.zone_assignment, o.hours, o.time_step_sec, o.seed or 0, o.first_building)
+      self._occ_count = torch.zeros((self.batch_size, self.sim.Z), dtype=torch.float32, device=self.sim.tdev)
+      self._occ_total = torch.zeros((self.batch_size,), dtype=torch.float32, device=self.sim.tdev)
     self._step_interval = dt.timedelta(seconds=self.config.time_step_sec)
     # environment.py:427-435
     self._num_timesteps_in_episode = int(dt.timedelta(days=num_days_in_episode) / self._step_interval)
@@ -482,8 +509,12 @@ class BatchedEnvironment:
     hod = host_inputs.get_radian_time(ts, hour_of_day=True)
     dow = host_inputs.get_radian_time(ts, hour_of_day=False)
     n_occ = 0.0   # simulator_building.py:305-315
-    for _ in range(self.sim.Z):
-      n_occ += self.occupancy.average_zone_occupancy("", ts - dt.timedelta(minutes=5), ts)
+    if self._occ_total is not None:   # per building, on the device: overrides aux[6]
+      t5 = ts - dt.timedelta(minutes=5)
+      self.sim.occupancy_peek(self.occupancy.local(t5).hour, self.occupancy.is_work_day(t5), None, self._occ_total)
+    else:
+      for z in range(self.sim.Z):
+        n_occ += self.occupancy.average_zone_occupancy(self.sim.zone_names[z], ts - dt.timedelta(minutes=5), ts)
     n_occ = int(n_occ)
     return [np.float32(np.cos(hod)), np.float32(np.sin(hod)), np.float32(np.cos(dow)),
             np.float32(np.sin(dow)), np.float32(self.schedule.is_comfort_mode(ts)),
@@ -504,12 +535,26 @@ class BatchedEnvironment:
                        else int(self.schedule.is_comfort_mode(self._prev_thermostat_ts)))
     si.comfort_next = int(self.schedule.is_comfort_mode(nxt))
     si.has_action = int(has_action)
-    si.occupancy = self.occupancy.average_zone_occupancy("", nxt, nxt + self._step_interval)
+    # the reference asks the occupancy model in this order (environment.py:1310-1330):
+    # _get_observation (num_occupants), then _get_reward (reward_info) -- it matters for the
+    # randomized model, whose every query advances the occupants
+    for i, v in enumerate(self._aux(nxt)):
+      si.aux[i] = float(v)
+    if self._occ_count is not None:
+      self.sim.occupancy_peek(self.occupancy.local(nxt).hour, self.occupancy.is_work_day(nxt), self._occ_count, None)
+      si.occupancy_bz_dev = self._occ_count.data_ptr()
+      si.num_occupants_dev = self._occ_total.data_ptr()
+      si.occupancy_norm = self._occ_norm
+    elif isinstance(self.occupancy, host_inputs.RandomizedArrivalDepartureOccupancy):
+      occ = [self.occupancy.average_zone_occupancy(self.sim.zone_names[z], nxt, nxt + self._step_interval)
+             for z in range(self.sim.Z)]   # one shared instance: per-zone values, same for every building
+      self._occ_zone = torch.tensor(occ, dtype=torch.float64, device=self.sim.tdev)
+      si.occupancy_dev = self._occ_zone.data_ptr()
+    else:
+      si.occupancy = self.occupancy.average_zone_occupancy("", nxt, nxt + self._step_interval)
     start_utc = host_inputs.reward_start_time_utc(nxt)
     si.e_price, si.e_carbon = self.electricity.rates(start_utc)
     si.g_price, si.g_carbon = self.gas.rates(start_utc)
-    for i, v in enumerate(self._aux(nxt)):
-      si.aux[i] = float(v)
     return si
 
   # ---- PyEnvironment API ----
@@ -525,7 +570,7 @@ class BatchedEnvironment:
       t_amb = torch.tensor(self.weather.temps(self._now), dtype=torch.float64, device=self.sim.tdev)
     else:
       t_amb = self.weather.get_current_temp(self._now)
-    self.sim.observe(self._aux(self._now), t_amb, self._obs)
+    self.sim.observe(self._aux(self._now), t_amb, self._obs, self._occ_total, self._occ_norm)
     first = torch.full((self.batch_size,), STEP_FIRST, dtype=torch.int32, device=self.sim.tdev)
     return TimeStep(first, self._zero, torch.ones_like(self._discount), self._obs)
 

@@ -302,6 +302,94 @@ class StepFunctionOccupancy:
     return (work * self._work_occupancy + nonwork * self._nonwork_occupancy) / (work + nonwork)
 
 
+class RandomizedArrivalDepartureOccupancy:
+  """Occupants that arrive and leave at random times of a working day
+  (simulator/randomized_arrival_departure_occupancy.py:41-218).  Host mirror: the same
+  ``np.random.RandomState(seed)`` stream consumed in the same order, so one instance
+  reproduces the reference call for call (tests/golden/occupancy_randomized.npz).  Every
+  ``average_zone_occupancy`` call ADVANCES each occupant of the zone (one Bernoulli trial inside
+  the arrival / departure window), exactly as in the reference -- the result depends on how
+  often it is asked, not only on the time."""
+
+  AWAY, WORK = 1, 2
+
+  def __init__(self, zone_assignment: int, earliest_expected_arrival_hour: int,
+               latest_expected_arrival_hour: int, earliest_expected_departure_hour: int,
+               latest_expected_departure_hour: int, time_step_sec: int, seed: Optional[int] = 17321,
+               time_zone="UTC", holiday_calendar: Optional[Iterable[dt.date]] = "us"):
+    assert (earliest_expected_arrival_hour < latest_expected_arrival_hour
+            < earliest_expected_departure_hour < latest_expected_departure_hour)   # :68-73
+    self.zone_assignment = int(zone_assignment)
+    self.hours = (int(earliest_expected_arrival_hour), int(latest_expected_arrival_hour),
+                  int(earliest_expected_departure_hour), int(latest_expected_departure_hour))
+    self.time_step_sec = float(time_step_sec)
+    self.seed = seed
+    self.p_arrival = self.event_probability(self.hours[0], self.hours[1], self.time_step_sec)
+    self.p_departure = self.event_probability(self.hours[2], self.hours[3], self.time_step_sec)
+    self._random_state = np.random.RandomState(seed)
+    self._tz = _tz(time_zone)
+    self._holiday_calendar = holiday_calendar
+    self._zone_occupants: Dict[str, list] = {}
+
+  @staticmethod
+  def event_probability(start_hour: int, end_hour: int, time_step_sec: float) -> float:
+    """:100-112: geometric distribution whose mean is half the window."""
+    n_halfway = (end_hour - start_hour) * 3600.0 / time_step_sec / 2.0
+    return 1.0 / n_halfway
+
+  def local(self, ts) -> dt.datetime:
+    ts = as_datetime(ts)
+    return ts if ts.tzinfo is None else ts.astimezone(self._tz)   # :93-98
+
+  def is_work_day(self, ts) -> bool:
+    loc = self.local(ts)
+    return is_work_day(dt.datetime(loc.year, loc.month, loc.day), self._holiday_calendar)   # :141-150
+
+  def _peek(self, state: int, ts) -> int:
+    """ZoneOccupant.peek (:138-160)."""
+    hour = self.local(ts).hour
+    e_arr, l_arr, e_dep, _ = self.hours
+    if not self.is_work_day(ts):
+      return self.AWAY
+    if state == self.AWAY:
+      if hour < e_arr or hour > l_arr:
+        return state
+      return self.WORK if self._random_state.rand() < self.p_arrival else state
+    if hour < e_dep:
+      return state
+    return self.AWAY if self._random_state.rand() < self.p_departure else state
+
+  def average_zone_occupancy(self, zone_id, start_time, end_time) -> float:
+    """:183-218: the number of occupants at work at ``start_time``."""
+    occ = self._zone_occupants.setdefault(zone_id, [self.AWAY] * self.zone_assignment)
+    n = 0.0
+    for i in range(len(occ)):
+      occ[i] = self._peek(occ[i], start_time)
+      if occ[i] == self.WORK:
+        n += 1.0
+    return n
+
+
+class BatchedRandomizedArrivalDepartureOccupancy(RandomizedArrivalDepartureOccupancy):
+  """One independent ``RandomizedArrivalDepartureOccupancy`` per building, generated on the
+  device (``sb_occupancy_attach`` / ``sb_occupancy_peek``): the per-occupant state machine is the
+  reference's, the Bernoulli trials come from a counter-based generator (Philox4x32-10 keyed by
+  seed, counter = global building index, zone, query number), so the streams cannot be those of
+  ``np.random.RandomState`` -- statistically equivalent, not bitwise --
+  but they do not depend on how the batch is sharded over GPUs.  ``BatchedEnvironment`` asks
+  twice per step like the reference's environment: the reward's query, then ``num_occupants``'
+  query five minutes earlier.  ``first_building``: global index of the batch's building 0."""
+
+  def __init__(self, *args, first_building: int = 0, **kwargs):
+    super().__init__(*args, **kwargs)
+    if not 1 <= self.zone_assignment <= 32:
+      raise ValueError("the device generator keeps a zone's occupants in one 32-bit word")
+    self.first_building = int(first_building)
+
+  def average_zone_occupancy(self, zone_id, start_time, end_time) -> float:
+    raise TypeError("per-building occupancy lives on the device; use BatchedEnvironment")
+
+
 # --------------------------------------------------------------------------- tariffs
 # Units: kg carbon / MWh (reward/electricity_energy_cost.py:39-64).
 CARBON_EMISSION_BY_HOUR = (
