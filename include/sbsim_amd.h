@@ -54,7 +54,8 @@ typedef enum sb_status {
   SB_ERR_INVALID = -1,    /* bad argument (reference: ValueError) */
   SB_ERR_NO_DEVICE = -2,  /* no HIP device / wrong architecture */
   SB_ERR_HIP = -3,        /* HIP runtime error, see sb_last_error() */
-  SB_ERR_TOO_LARGE = -4   /* one building does not fit the 160 KiB LDS of a CU */
+  SB_ERR_TOO_LARGE = -4,  /* one building does not fit the 160 KiB LDS of a CU */
+  SB_ERR_UNSUPPORTED = -5 /* a reference option this library does not implement */
 } sb_status;
 
 typedef struct sb_handle sb_handle;
@@ -209,6 +210,21 @@ int sb_occupancy_attach(sb_handle *h, const sb_occupancy_config *cfg);
  * total_dev [B] fp32 (either may be NULL). */
 int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, float *count_dev,
                       float *total_dev, void *stream);
+
+/* SURVEY.md 8(f) rank 3 -- StochasticConvectionSimulator(p, distance, seed)
+ * (simulator/stochastic_convection_simulator.py:62-145; SB1: p = 1, distance = 5,
+ * sim_config.gin:36-39): after every FD update the air cells of each room are shuffled by
+ * random local swaps applied in random order (simulator_flexible_floor_plan.py:156).  The
+ * reference draws from Python's global `random`; here the draws are Philox4x32-10 keyed by
+ * `seed` with counter (global building index, call number, grid cell): the same random process
+ * (statistically equivalent, sharding-independent), not the same stream.  p == 0 or
+ * distance == 0 detaches (the reference returns early); distance == -1 (whole-room shuffle)
+ * is SB_ERR_UNSUPPORTED.  sb_step then runs the shuffle between the sweep and the reward.
+ * transposed: the plan given to sb_create is the transpose of the caller's floor plan (the host
+ * picks the cheaper orientation, sb_plan_info); cells are then numbered -- and candidates
+ * ordered -- as in the caller's [H, W] grid, so the shuffle does not depend on the orientation. */
+int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed, int64_t first_building,
+                         int32_t transposed);
 
 /* Parity taps (all DEVICE outputs, float64). */
 int sb_get_temps(sb_handle *h, double *out_dev /* [B][H*W] */, void *stream);

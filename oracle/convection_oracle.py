@@ -1,0 +1,76 @@
+"""CPU restatement of the device convection shuffle (TEST INFRASTRUCTURE: only tests/ may import
+this).
+
+Checker for `k_convect` (sbsim_amd/csrc/sbsim_hip.hip).  The random PROCESS is
+`StochasticConvectionSimulator._shuffle_max_dist` of the reference
+(simulator/stochastic_convection_simulator.py:101-145): every cell of a room starts a swap with
+probability p, its partner is uniform over the room's cells inside the offset window
+(:125-131: dx, dy in [-distance, distance), dx^2 + dy^2 <= distance), the swaps run one after
+the other in uniformly random order (:137-145).  Here the swaps are really applied one after
+the other (the device follows every value through the sequence instead); the draws are the
+device's: Philox4x32-10, key = seed, counter = (global building lo, hi, call number, grid cell),
+word 0 -> inclusion (u = (x >> 8) / 2**24, included unless u > p), word 1 -> partner
+((x * count) >> 32 among the valid offsets in (dx, dy) raster order), word 2 -> order (swaps by
+increasing (x, cell's index in the room)).  The reference draws from Python's global `random`,
+which no counter-based generator reproduces: what is pinned against the reference is the
+displacement statistics (tests/golden/convection_stats.npz)."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle.occupancy_oracle import philox4x32_10
+
+
+def offsets(distance: int):
+  return [(dx, dy) for dx in range(-distance, distance) for dy in range(-distance, distance)
+          if dx * dx + dy * dy <= distance]
+
+
+class ConvectionOracle:
+
+  def __init__(self, zone_cell_lists, H: int, W: int, p: float, distance: int, seed: int, first_building: int = 0):
+    self.zones = [np.asarray(c, dtype=np.int64) for c in zone_cell_lists]
+    self.H, self.W, self.p, self.seed, self.first = H, W, float(p), int(seed), int(first_building)
+    self.off = offsets(distance)
+    self.room = np.full(H * W, -1, dtype=np.int64)
+    self.local = np.full(H * W, -1, dtype=np.int64)
+    for z, cells in enumerate(self.zones):
+      self.room[cells] = z
+      self.local[cells] = np.arange(len(cells))
+    self.call = 0
+
+  def swaps(self, b: int, z: int, call: int):
+    """The room's swap sequence [(cell index, partner index)] in application order."""
+    cells = self.zones[z]
+    gb = self.first + b
+    n = len(cells)
+    w = philox4x32_10(np.full(n, gb & 0xFFFFFFFF), np.full(n, gb >> 32), np.full(n, call), cells,
+                      self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
+    u = (w[0] >> np.uint64(8)).astype(np.float64) / 16777216.0
+    seq = []
+    for i in range(n):
+      if u[i] > self.p:
+        continue
+      x, y = divmod(int(cells[i]), self.W)
+      cand = []
+      for dx, dy in self.off:
+        xx, yy = x + dx, y + dy
+        if 0 <= xx < self.H and 0 <= yy < self.W and self.room[xx * self.W + yy] == z:
+          cand.append(int(self.local[xx * self.W + yy]))
+      other = cand[(int(w[1][i]) * len(cand)) >> 32]
+      if other != i:
+        seq.append((int(w[2][i]), i, other))
+    seq.sort()
+    return [(i, o) for _, i, o in seq]
+
+  def apply(self, grids: np.ndarray) -> None:
+    """grids [B, H, W] float64, shuffled in place (one call of apply_convection per building)."""
+    B = grids.shape[0]
+    flat = grids.reshape(B, -1)
+    for b in range(B):
+      for z, cells in enumerate(self.zones):
+        v = flat[b, cells].copy()
+        for i, o in self.swaps(b, z, self.call):
+          v[i], v[o] = v[o], v[i]
+        flat[b, cells] = v
+    self.call += 1

@@ -1,0 +1,65 @@
+"""Displacement statistics of the reference's stochastic convection.
+
+TEST INFRASTRUCTURE -- runs only in the build container: imports the REFERENCE
+(`/root/reference`, through oracle/refshim) and runs its own
+`StochasticConvectionSimulator.apply_convection` (stochastic_convection_simulator.py:62-145) on a
+16 x 20 grid with one 14 x 18 room whose temperatures are the cells' own indices, many times.
+Recorded per (p, distance): the probability that a value starting at least 4 cells away from the
+walls ends at offset (dx, dy), dx, dy in -8..8; the fraction of ALL room values that do not move;
+the mean squared displacement of all room values.  Output: tests/golden/convection_stats.npz.
+
+    python -m oracle.gen_golden_convection
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from oracle import refshim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+H, W = 16, 20
+CASES = [(1.0, 5), (0.5, 5), (1.0, 2)]
+TRIALS = 400
+
+
+def main() -> None:
+  refshim.install()
+  scs = refshim.ref("simulator.stochastic_convection_simulator")
+  room = [(x, y) for x in range(1, H - 1) for y in range(1, W - 1)]
+  wall = [(x, y) for x in range(H) for y in range(W) if (x, y) not in set(room)]
+  room_dict = {"exterior_space": [], "interior_wall": wall, "room_1": room}
+  out = {"H": np.array(H), "W": np.array(W), "trials": np.array(TRIALS),
+         "cases": np.array(CASES, dtype=np.float64)}
+  ids = np.arange(H * W, dtype=np.float64).reshape(H, W)
+  for ci, (p, dist) in enumerate(CASES):
+    sim = scs.StochasticConvectionSimulator(p=p, distance=dist, seed=1234 + ci)
+    hist = np.zeros((17, 17))
+    n_inner = 0
+    fixed = 0
+    msd = 0.0
+    for _ in range(TRIALS):
+      temp = ids.copy()
+      sim.apply_convection(room_dict, temp)
+      assert np.array_equal(np.sort(temp.reshape(-1)), ids.reshape(-1))
+      for x in range(1, H - 1):
+        for y in range(1, W - 1):
+          src = int(temp[x, y])
+          sx, sy = divmod(src, W)
+          dx, dy = x - sx, y - sy
+          fixed += int(dx == 0 and dy == 0)
+          msd += dx * dx + dy * dy
+          if 5 <= sx <= H - 6 and 5 <= sy <= W - 6:
+            hist[dx + 8, dy + 8] += 1
+            n_inner += 1
+    out[f"hist_{ci}"] = hist / n_inner
+    out[f"fixed_{ci}"] = np.array(fixed / (TRIALS * len(room)))
+    out[f"msd_{ci}"] = np.array(msd / (TRIALS * len(room)))
+    print(p, dist, "fixed", out[f"fixed_{ci}"], "msd", out[f"msd_{ci}"], "inner samples", n_inner)
+  np.savez_compressed(os.path.join(GOLD, "convection_stats.npz"), **out)
+
+
+if __name__ == "__main__":
+  main()

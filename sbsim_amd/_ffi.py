@@ -85,7 +85,7 @@ class LaunchInfo(C.Structure):
 
 
 EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",
-           "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_step", "sb_step_phases", "sb_get_temps", "sb_get_zone_temps",
+           "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_convection_attach", "sb_step", "sb_step_phases", "sb_get_temps", "sb_get_zone_temps",
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles")
 
 _lib = None
@@ -119,6 +119,7 @@ def load():
   L.sb_observe_occupancy.argtypes = [vp, C.POINTER(C.c_float), C.c_double, vp, vp, C.c_double, vp, vp]
   L.sb_occupancy_attach.argtypes = [vp, C.POINTER(OccupancyConfig)]
   L.sb_occupancy_peek.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
+  L.sb_convection_attach.argtypes = [vp, C.c_double, C.c_int32, C.c_uint64, C.c_int64, C.c_int32]
   L.sb_step.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp]
   L.sb_step_phases.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp, C.c_int32]
   for name in ("sb_get_temps", "sb_get_zone_temps", "sb_get_scalars", "sb_get_modes",

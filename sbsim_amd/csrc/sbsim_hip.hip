@@ -166,6 +166,110 @@ __global__ void k_occupancy(OccArgs o) {
   }
 }
 
+// ---------------------------------------------------------------- stochastic convection
+// StochasticConvectionSimulator._shuffle_max_dist (stochastic_convection_simulator.py:101-145),
+// one workgroup per building, room by room.  Every air cell of a room is, with probability p,
+// the first half of a swap whose second half is drawn uniformly from the room's cells within
+// the offset table (dx^2 + dy^2 <= distance inside the [-distance, distance) window, :125-131);
+// the swaps are applied one after the other in a uniformly random order (:137).  Random order:
+// swap i gets the time stamp T_i = (32 random bits, i) and swaps run by increasing T.  Instead of
+// replaying the sequence, every VALUE is followed through it: at cell c after time t the next
+// swap touching c is the earliest of c's own swap and the swaps that chose c (a linked list per
+// cell, built with LDS atomics); the value moves to that swap's other cell.  All values move
+// in parallel, reads before writes.  Randomness: Philox4x32-10, key = seed, counter = (global
+// building lo, hi, call number, grid cell): word 0 -> inclusion, 1 -> choice, 2 -> time stamp.
+struct ConvCell {
+  int g0;                  // the cell's index in the caller's [H, W] grid: Philox counter, tie-break
+  int gh;                  // ... in the handle's grid (which may be the transposed plan)
+  int sidx;                // index into the building's state
+  int pad;
+  unsigned long long mask; // bit k: offset k of the table leads to a cell of the same room
+};
+
+struct ConvArgs {
+  double *temp;
+  size_t stride; // doubles per building
+  const int *zone_off, *local, *off;
+  const ConvCell *cells; // every zone's cells, within a zone by increasing state index: lanes that
+                         // read / write neighbouring cells of the list touch neighbouring memory
+  int B, Z, W, n_off, max_room;
+  double p;
+  uint64_t seed;
+  long long first_building;
+  uint32_t call;
+};
+
+constexpr int kConvMaxThreads = 512, kConvMaxPerLane = 8; // rooms up to 4,096 cells
+
+// Q: cells per lane; the workgroup has ceil(largest room / Q) lanes rounded up to a wavefront
+template <int Q>
+__global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
+  const int kConvThreads = blockDim.x;
+  extern __shared__ unsigned long long conv_lds[];
+  unsigned long long *T = conv_lds;            // [max_room] time stamp of the cell's own swap
+  double *vout = (double *)(T + o.max_room);   // [max_room] the value that ends in this cell
+  int *part = (int *)(vout + o.max_room);      // [max_room] other cell of the cell's own swap (itself: none)
+  int *head = part + o.max_room;               // [max_room] first swap that chose this cell
+  int *nxt = head + o.max_room;                // [max_room] next swap that chose the same cell
+  const int tid = threadIdx.x;
+  for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
+    double *st = o.temp + (size_t)b * o.stride;
+    const unsigned long long gb = (unsigned long long)(o.first_building + b);
+    for (int z = 0; z < o.Z; ++z) {
+      const int c0 = o.zone_off[z], n = o.zone_off[z + 1] - c0;
+      for (int i = tid; i < n; i += kConvThreads) head[i] = -1;
+      __syncthreads();
+      double val[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int i = tid + q * kConvThreads;
+        if (i < n) {
+          const ConvCell cc = o.cells[c0 + i];
+          val[q] = st[cc.sidx];
+          uint32_t c[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc.g0};
+          philox4x32_10(c, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
+          const double u = (double)(c[0] >> 8) * (1.0 / 16777216.0);
+          int other = i;
+          if (!(u > o.p)) { // :119
+            const int cnt = __popcll(cc.mask);
+            int pick = (int)(((unsigned long long)c[1] * (unsigned long long)cnt) >> 32); // uniform in [0, cnt)
+            unsigned long long m = cc.mask;
+            for (; pick > 0; --pick) m &= m - 1; // drop the lowest set bits
+            const int k = __ffsll((long long)m) - 1;
+            other = o.local[cc.gh + o.off[k]]; // off[k]: offset k as a step in the handle's grid
+          }
+          part[i] = other;
+          T[i] = (((unsigned long long)c[2] << 20) | (unsigned long long)cc.g0) + 1ull; // ties: raster order of the caller's grid
+          if (other != i) nxt[i] = atomicExch(&head[other], i);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int i = tid + q * kConvThreads;
+        if (i < n) {
+          int pos = i;
+          unsigned long long t = 0;
+          for (;;) {
+            unsigned long long best = ~0ull;
+            int to = -1;
+            if (part[pos] != pos && T[pos] > t) { best = T[pos]; to = part[pos]; }
+            for (int j = head[pos]; j >= 0; j = nxt[j])
+              if (T[j] > t && T[j] < best) { best = T[j]; to = j; }
+            if (to < 0) break;
+            t = best;
+            pos = to;
+          }
+          vout[pos] = val[q];
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < n; i += kConvThreads) st[o.cells[c0 + i].sidx] = vout[i];
+      __syncthreads();
+    }
+  }
+}
+
 // building.temp in the caller's row-major layout, whichever state layout the handle uses.
 __global__ void k_copy_temps(Dev a, double *out) {
   size_t n = (size_t)a.B * a.N;
@@ -518,6 +622,17 @@ struct sb_handle {
   DevBuf<int4> sched;
   DevBuf<unsigned long long> smask, cmapS, amapS, zmapS;
   DevBuf<long long> dbg;
+  // host copies for the optional generators
+  std::vector<int> h_zone_off, h_zone_cells, h_state_index; // state index of every grid cell (< 0: exterior ring)
+  // sb_convection_attach
+  DevBuf<int> conv_local, conv_off; // per grid cell: index in its room's list; the offset table as linear steps
+  DevBuf<ConvCell> conv_cells;
+  double conv_p = 0.0;
+  int conv_n_off = 0, conv_max_room = 0;
+  uint64_t conv_seed = 0;
+  long long conv_first = 0;
+  uint32_t conv_calls = 0;
+  bool conv_attached = false;
   DevBuf<uint32_t> occ_state; // sb_occupancy_attach
   sb_occupancy_config occ{};
   uint32_t occ_queries = 0;
@@ -607,6 +722,10 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   }
   SB_TRY(upload(h->czone, plan->class_zone, (size_t)d.ncls));
   SB_TRY(upload(h->zone_off, plan->zone_off, (size_t)d.Z + 1));
+  h->h_zone_off.assign(plan->zone_off, plan->zone_off + d.Z + 1);
+  h->h_zone_cells.assign(plan->zone_cells, plan->zone_cells + plan->zone_off[plan->Z]);
+  h->h_state_index.resize((size_t)d.N);
+  for (int g = 0; g < d.N; ++g) h->h_state_index[g] = d.reg ? r.cell_state[g] : kPad + g;
   if (d.reg) {
     d.pitch = d.W; d.NL = d.N; d.ts = r.ts;
     d.NR = r.NR; d.P = r.P; d.RS = r.RS; d.Ws = r.Ws; d.n_ring = r.n_ring;
@@ -848,6 +967,101 @@ int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, flo
   return SB_OK;
 }
 
+int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed, int64_t first_building,
+                         int32_t transposed) {
+  if (!h) return fail(SB_ERR_INVALID, "sb_convection_attach: null handle");
+  if (!(p >= 0.0 && p <= 1.0)) return fail(SB_ERR_INVALID, "sb_convection_attach: p must be in [0, 1]");
+  if (first_building < 0) return fail(SB_ERR_INVALID, "sb_convection_attach: first_building must be >= 0");
+  if (p == 0.0 || distance == 0) { h->conv_attached = false; return SB_OK; } // stochastic_convection_simulator.py:70-71
+  if (distance < 0 || distance > 64)
+    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: distance must be 1..64 (distance = -1, the whole-room "
+                                    "shuffle of stochastic_convection_simulator.py:80-99, is not implemented)");
+  SB_HIP(hipSetDevice(h->device));
+  const Dev &d = h->d;
+  // :125-131: window [-distance, distance) in both directions, squared distance <= distance
+  // (in the order of the caller's grid: the handle may hold the transposed floor plan)
+  if (d.N >= (1 << 20)) return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: more than 2^20 grid cells");
+  std::vector<int> odx, ody, offd; // offsets in the handle's coordinates, linear steps
+  for (int dx = -distance; dx < distance; ++dx)
+    for (int dy = -distance; dy < distance; ++dy)
+      if (dx * dx + dy * dy <= distance) {
+        odx.push_back(transposed ? dy : dx);
+        ody.push_back(transposed ? dx : dy);
+        offd.push_back(odx.back() * d.W + ody.back());
+      }
+  if (offd.size() > 64)
+    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: more than 64 candidate offsets (distance <= 17)");
+  std::vector<int> room((size_t)d.N, -1), local((size_t)d.N, -1);
+  for (int z = 0; z < d.Z; ++z)
+    for (int i = h->h_zone_off[z]; i < h->h_zone_off[z + 1]; ++i) room[h->h_zone_cells[i]] = z;
+  std::vector<ConvCell> cells(h->h_zone_cells.size());
+  int max_room = 1;
+  for (int z = 0; z < d.Z; ++z) {
+    const int c0 = h->h_zone_off[z], n = h->h_zone_off[z + 1] - c0;
+    max_room = std::max(max_room, n);
+    std::vector<int> order(h->h_zone_cells.begin() + c0, h->h_zone_cells.begin() + c0 + n);
+    for (int g : order)
+      if (h->h_state_index[g] < 0) return fail(SB_ERR_INVALID, "sb_convection_attach: a zone cell lies in the exterior ring");
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return h->h_state_index[a] < h->h_state_index[b]; });
+    for (int i = 0; i < n; ++i) {
+      const int g = order[i], x = g / d.W, y = g % d.W;
+      local[g] = i;
+      ConvCell &c = cells[(size_t)c0 + i];
+      c.gh = g; c.g0 = transposed ? y * d.H + x : g; c.sidx = h->h_state_index[g]; c.pad = 0; c.mask = 0;
+      for (size_t k = 0; k < offd.size(); ++k) {
+        const int xx = x + odx[k], yy = y + ody[k];
+        if (xx >= 0 && xx < d.H && yy >= 0 && yy < d.W && room[xx * d.W + yy] == z) c.mask |= 1ull << k;
+      }
+    }
+  }
+  if (max_room > kConvMaxThreads * kConvMaxPerLane)
+    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: a room has more than 2048 cells");
+  for (DevBuf<int> *buf : {&h->conv_local, &h->conv_off}) {
+    if (buf->p) (void)hipFree(buf->p); // attached before: replace
+    buf->p = nullptr;
+  }
+  if (h->conv_cells.p) { (void)hipFree(h->conv_cells.p); h->conv_cells.p = nullptr; }
+  int rc;
+  if ((rc = upload(h->conv_local, local.data(), local.size())) != SB_OK) return rc;
+  if ((rc = upload(h->conv_off, offd.data(), offd.size())) != SB_OK) return rc;
+  if ((rc = upload(h->conv_cells, cells.data(), cells.size())) != SB_OK) return rc;
+  h->conv_p = p; h->conv_n_off = (int)offd.size(); h->conv_max_room = max_room;
+  h->conv_seed = seed; h->conv_first = first_building; h->conv_calls = 0;
+  h->conv_attached = true;
+  return SB_OK;
+}
+
+namespace {
+int launch_convection(sb_handle *h, hipStream_t stream) {
+  const Dev &d = h->d;
+  ConvArgs o;
+  o.temp = d.temp; o.stride = d.reg ? (size_t)d.state_doubles : (size_t)d.Np;
+  o.zone_off = h->zone_off.p; o.local = h->conv_local.p; o.off = h->conv_off.p; o.cells = h->conv_cells.p;
+  o.B = d.B; o.Z = d.Z; o.W = d.W; o.n_off = h->conv_n_off; o.max_room = h->conv_max_room;
+  o.p = h->conv_p; o.seed = h->conv_seed; o.first_building = h->conv_first; o.call = h->conv_calls++;
+  const size_t lds = (size_t)o.max_room * (8 + 8 + 3 * 4);
+  // workgroups of about 256 lanes measured best on R9's 600-cell rooms (5.4 ms per launch for 65,536
+  // buildings; 320 lanes x 2 cells: 7.4 ms); every resident workgroup gets the same number of buildings
+  int q = std::max(1, (o.max_room + 255) / 256);
+  if (q > kConvMaxPerLane) q = kConvMaxPerLane;
+  const int threads = ((o.max_room + q - 1) / q + 63) / 64 * 64;
+  const int per_cu = std::max(1, std::min(std::min(8, 2048 / threads), (int)(kLdsCap / ((lds + 1279) / 1280 * 1280))));
+  const int blocks = std::max(1, std::min(d.B, h->cus * per_cu));
+  switch (q) {
+    case 1: hipLaunchKernelGGL(k_convect<1>, dim3(blocks), dim3(threads), lds, stream, o); break;
+    case 2: hipLaunchKernelGGL(k_convect<2>, dim3(blocks), dim3(threads), lds, stream, o); break;
+    case 3: hipLaunchKernelGGL(k_convect<3>, dim3(blocks), dim3(threads), lds, stream, o); break;
+    case 4: hipLaunchKernelGGL(k_convect<4>, dim3(blocks), dim3(threads), lds, stream, o); break;
+    case 5: hipLaunchKernelGGL(k_convect<5>, dim3(blocks), dim3(threads), lds, stream, o); break;
+    case 6: hipLaunchKernelGGL(k_convect<6>, dim3(blocks), dim3(threads), lds, stream, o); break;
+    case 7: hipLaunchKernelGGL(k_convect<7>, dim3(blocks), dim3(threads), lds, stream, o); break;
+    default: hipLaunchKernelGGL(k_convect<8>, dim3(blocks), dim3(threads), lds, stream, o); break;
+  }
+  SB_HIP(hipGetLastError());
+  return SB_OK;
+}
+} // namespace
+
 int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in, float *obs_dev,
                    float *reward_dev, float *info_dev, void *stream, int32_t phases) {
   if (!h || !in || !reward_dev) return fail(SB_ERR_INVALID, "sb_step: null argument");
@@ -870,6 +1084,10 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
       return fail(SB_ERR_HIP, std::string("sweep kernel launch: ") + hipGetErrorString((hipError_t)e));
   }
   if (phases & SB_PHASE_POST) {
+    if (h->conv_attached) { // simulator_flexible_floor_plan.py:156: after the FD update; the zone sums of
+      const int rc = launch_convection(h, (hipStream_t)stream); // k_post do not change (values move inside rooms)
+      if (rc != SB_OK) return rc;
+    }
     hipLaunchKernelGGL(k_post, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s);
     SB_HIP(hipGetLastError());
   }

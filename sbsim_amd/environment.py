@@ -352,6 +352,12 @@ class BatchedSimulator:
                                float(time_step_sec), int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_building))
     _ffi.check(self._lib.sb_occupancy_attach(self._h, C.byref(cfg)), "sb_occupancy_attach")
 
+  def convection_attach(self, p: float, distance: int, seed: int, first_building: int = 0) -> None:
+    """sb_convection_attach: StochasticConvectionSimulator(p, distance, seed) after every FD update
+    (stochastic_convection_simulator.py:62-145), counter-based draws per building."""
+    _ffi.check(self._lib.sb_convection_attach(self._h, float(p), int(distance), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                              int(first_building), int(self.transposed)), "sb_convection_attach")
+
   def occupancy_peek(self, local_hour: int, is_work_day: bool, count: Optional[torch.Tensor] = None,
                      total: Optional[torch.Tensor] = None) -> None:
     """sb_occupancy_peek: advances every occupant once; count [B, Z] / total [B] float32."""
@@ -428,7 +434,7 @@ class BatchedEnvironment:
                occupancy_normalization_constant: float = 0.0, holiday_calendar="us",
                electricity_energy_cost=None, natural_gas_energy_cost=None, collect_info: bool = False,
                observation_histogram_parameters: Optional[Sequence[Tuple[str, Sequence[float]]]] = None,
-               normalize_reduce: bool = False):
+               normalize_reduce: bool = False, convection_simulator=None):
     if discount_factor <= 0 or discount_factor > 1:
       raise ValueError("Discount factor must be in (0,1]")   # environment.py:454-455
     self.config = config or SimConfig.sb1()
@@ -454,6 +460,9 @@ class BatchedEnvironment:
         raise ValueError("BatchedSinusoidWeather needs one (low, high) pair per building")
       self._weather_lohi = torch.tensor(np.stack([self.weather.low, self.weather.high], axis=1),
                                         dtype=torch.float64, device=self.sim.tdev).contiguous()
+    if convection_simulator is not None:   # simulator_flexible_floor_plan.py:71,156
+      c = convection_simulator
+      self.sim.convection_attach(c.p, c.distance, c.seed or 0, getattr(c, "first_building", 0))
     self._occ_count = self._occ_total = None
     if isinstance(self.occupancy, host_inputs.BatchedRandomizedArrivalDepartureOccupancy):
       o = self.occupancy   # per-building occupants live on the device

@@ -390,6 +390,18 @@ class BatchedRandomizedArrivalDepartureOccupancy(RandomizedArrivalDepartureOccup
     raise TypeError("per-building occupancy lives on the device; use BatchedEnvironment")
 
 
+class StochasticConvectionSimulator:
+  """Parameters of the reference's StochasticConvectionSimulator(p, distance, seed)
+  (simulator/stochastic_convection_simulator.py:35-60; SB1: p = 1, distance = 5,
+  sim_config.gin:36-39).  The shuffle itself runs on the device after every FD update
+  (``sb_convection_attach``, ``BatchedEnvironment(convection_simulator=...)``): the reference's
+  random process with counter-based draws per building -- statistically equivalent to the
+  reference (which uses Python's global ``random``), independent of batch sharding."""
+
+  def __init__(self, p: float, distance: int, seed: Optional[int], first_building: int = 0):
+    self.p, self.distance, self.seed, self.first_building = float(p), int(distance), seed, int(first_building)
+
+
 # --------------------------------------------------------------------------- tariffs
 # Units: kg carbon / MWh (reward/electricity_energy_cost.py:39-64).
 CARBON_EMISSION_BY_HOUR = (

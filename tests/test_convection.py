@@ -1,0 +1,155 @@
+"""Stochastic convection shuffle: the device kernel's CPU restatement
+against the reference's displacement statistics, and the device against the restatement."""
+import numpy as np
+import pytest
+
+from oracle.convection_oracle import ConvectionOracle, offsets
+from tests.golden_util import load
+
+
+def _stats(grids, H, W):
+  B = grids.shape[0]
+  src = grids.astype(np.int64)
+  sx, sy = np.divmod(src, W)
+  x, y = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+  dx, dy = x[None] - sx, y[None] - sy
+  room = np.zeros((H, W), bool)
+  room[1:H - 1, 1:W - 1] = True
+  inner = room[None] & (sx >= 5) & (sx <= H - 6) & (sy >= 5) & (sy <= W - 6)
+  hist = np.zeros((17, 17))
+  np.add.at(hist, (dx[inner] + 8, dy[inner] + 8), 1)
+  n_room = B * room.sum()
+  fixed = ((dx == 0) & (dy == 0) & room[None]).sum() / n_room
+  msd = ((dx * dx + dy * dy) * room[None]).sum() / n_room
+  return hist / inner.sum(), fixed, msd
+
+
+def test_offset_window_is_the_reference_one():
+  """stochastic_convection_simulator.py:125-131 with distance = 5: squared distance <= 5."""
+  off = offsets(5)
+  assert len(off) == 21 and (0, 0) in off and (2, 1) in off and (-1, -2) in off and (2, 2) not in off
+  assert off == sorted(off)                       # (dx, dy) raster order = the reference's loop order
+  assert len(offsets(2)) == 9 and offsets(1) == [(-1, 0), (0, -1), (0, 0)]    # the window is half-open: [-d, d)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_restatement_matches_reference_displacement_statistics(case):
+  """24,000 tracked values on each side.  Bin probabilities <= 0.25 -> sigma of a difference
+  <= sqrt(2 * 0.25 * 0.75 / 24000) = 0.004; 0.02 is five sigma."""
+  g = load("convection_stats.npz")
+  H, W = int(g["H"]), int(g["W"])
+  p, dist = float(g["cases"][case][0]), int(g["cases"][case][1])
+  room = [x * W + y for x in range(1, H - 1) for y in range(1, W - 1)]
+  B = 400
+  m = ConvectionOracle([room], H, W, p, dist, seed=77 + case)
+  grids = np.tile(np.arange(H * W, dtype=np.float64).reshape(1, H, W), (B, 1, 1))
+  m.apply(grids)
+  assert np.array_equal(np.sort(grids.reshape(B, -1), axis=1), np.tile(np.arange(H * W), (B, 1)))   # permutations
+  assert np.array_equal(grids[:, 0, :], np.tile(np.arange(W), (B, 1)))                              # walls stay
+  hist, fixed, msd = _stats(grids, H, W)
+  assert np.abs(hist - g[f"hist_{case}"]).max() < 0.02
+  assert abs(fixed - float(g[f"fixed_{case}"])) < 0.01
+  assert abs(msd - float(g[f"msd_{case}"])) < 0.03 * float(g[f"msd_{case}"])
+
+
+def test_restatement_does_not_depend_on_sharding_and_calls_differ():
+  H, W = 10, 12
+  rooms = [[x * W + y for x in range(1, 5) for y in range(1, 11)], [x * W + y for x in range(6, 9) for y in range(1, 11)]]
+  base = np.arange(H * W, dtype=np.float64).reshape(1, H, W)
+  whole = ConvectionOracle(rooms, H, W, 1.0, 5, seed=3)
+  a = np.tile(base, (6, 1, 1)); whole.apply(a)
+  parts = []
+  for f in (0, 3):
+    m = ConvectionOracle(rooms, H, W, 1.0, 5, seed=3, first_building=f)
+    gpart = np.tile(base, (3, 1, 1)); m.apply(gpart); parts.append(gpart)
+  assert np.array_equal(a, np.concatenate(parts))
+  assert not np.array_equal(a[0], a[1])
+  b = np.tile(base, (6, 1, 1)); whole.apply(b)        # second call: other draws
+  assert not np.array_equal(a, b)
+  for z, cells in enumerate(rooms):                   # values never leave their room
+    assert np.array_equal(np.sort(a[:, :, :].reshape(6, -1)[:, cells], axis=1), np.tile(np.sort(cells), (6, 1)))
+
+
+# ------------------------------------------------------------------------------------- GPU
+def _need_gpu():
+  import torch
+  if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["reg", "lds"])
+def test_device_shuffle_equals_its_restatement_inside_a_rollout(kernel, monkeypatch):
+  """R9, SB1 physics, convection p = 1 / distance = 5 (sim_config.gin:36-39) after every FD
+  update: sweep counts, zone temperatures and the final grid against oracle twins whose grids
+  get the restatement's shuffle after every step."""
+  _need_gpu()
+  import torch
+  from oracle import oracle as orc
+  from sbsim_amd import _ffi
+  from sbsim_amd.environment import BatchedSimulator, SimConfig
+  from tests.golden_util import oracle_params, oracle_plan
+  from tests.test_gpu_parity import T_TOL, _plan, _step_in
+  if kernel == "lds":
+    monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
+  g = load("h2_sb1_r9_random.npz")
+  p = load("plan_r9_sb1.npz")
+  B, T, first = 4, 10, 1000
+  rs = np.random.RandomState(5)
+  init = np.clip(294.0 + rs.randn(B, 1, 1) + 0.8 * rs.randn(B, 68, 98), 285.0, 305.0)
+  acts = rs.uniform(-1, 1, size=(T, B, 2)).astype(np.float32)
+  fp = _plan(p)
+  sim = BatchedSimulator(fp, SimConfig.sb1(), B, float(g["h_conv"]))
+  assert sim.launch_info["path"] == (1 if kernel == "reg" else 0)
+  sim.convection_attach(1.0, 5, seed=4242, first_building=first)
+  sim.reset(temps=torch.tensor(init.reshape(B, -1), dtype=torch.float64, device="cuda"))
+  conv = ConvectionOracle(fp.zone_cell_lists(), 68, 98, 1.0, 5, seed=4242, first_building=first)
+  plan, prm = oracle_plan(p), oracle_params(g["params_json"])
+  twins = [orc.OracleBuilding(plan, prm, 0.0, reset_temps=init[b].reshape(-1)) for b in range(B)]
+  obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  for t in range(T):
+    sim.step(torch.tensor(acts[t], device="cuda"), _step_in(g, t + 100), obs, rew, info)
+    i = info.cpu().numpy().astype(np.float64)
+    zt = sim.zone_temps().cpu().numpy()
+    for b in range(B):
+      a = acts[t, b]
+      native = [np.float32((float(a[0]) + 1.0) / 2.0 * 45.0 + 310.0), np.float32((float(a[1]) + 1.0) / 2.0 * 15.0 + 285.0)]
+      tt = t + 100
+      o = twins[b].step(
+          now_ts=300.0 * t, t_amb_now=float(g["t_amb_now"][tt]), h_conv=float(g["h_conv"]),
+          t_amb_next=float(g["t_amb_next"][tt]), comfort_now=bool(g["comfort_now"][tt]),
+          comfort_prev=g["comfort_prev"][tt] == 1, comfort_next=bool(g["comfort_next"][tt]),
+          occupancy=float(g["occupancy"][tt]), e_price=float(g["e_price"][tt]),
+          e_carbon=float(g["e_carbon"][tt]), g_price=float(g["g_price"][tt]),
+          g_carbon=float(g["g_carbon"][tt]), action=native, observe=True)
+      assert i[b, 4] == o["n_sweeps"], (t, b, i[b, 4], o["n_sweeps"])
+      assert np.abs(zt[b] - o["zone_temp_post"]).max() < T_TOL, (t, b)
+    grids = np.stack([tw.grid() for tw in twins])
+    before = grids.copy()
+    conv.apply(grids)                                   # apply_convection after the FD update
+    assert not np.array_equal(before, grids)
+    for b in range(B):
+      twins[b].temp[:] = grids[b].reshape(-1)
+    dev = sim.temps().cpu().numpy()
+    for b in range(B):
+      assert np.abs(dev[b] - grids[b]).max() < T_TOL, (t, b)
+  sim.close()
+
+
+@pytest.mark.gpu
+def test_convection_attach_argument_checks():
+  _need_gpu()
+  from sbsim_amd import _ffi
+  from sbsim_amd.environment import BatchedSimulator, SimConfig
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  fp = FloorPlan.from_file_input(rectangular_floor_plan((2, 2), (5, 9)), Materials.sb1(), 10.0, 300.0)
+  sim = BatchedSimulator(fp, SimConfig.sb1(), 3, 100.0)
+  sim.convection_attach(0.0, 5, seed=1)       # p == 0: the reference returns early -> detached
+  sim.convection_attach(1.0, 0, seed=1)
+  with pytest.raises(_ffi.SbsimError, match="whole-room"):
+    sim.convection_attach(1.0, -1, seed=1)
+  with pytest.raises(_ffi.SbsimError, match=r"p must be in \[0, 1\]"):
+    sim.convection_attach(1.5, 5, seed=1)
+  sim.close()
