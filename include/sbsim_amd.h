@@ -119,6 +119,15 @@ typedef struct sb_step_in {
    * overrides t_amb_now/next and t_amb_dev */
   const double *weather_lohi_dev; /* DEVICE [B][2] (low, high) in force at this step */
   double weather_f_now, weather_f_next;
+  /* optional per-building replay weather on the device (weather_controller.py:166-218): building
+   * b sees the trace shifted by weather_offset_dev[b] seconds, T_b = to_kelvin(np.interp(t +
+   * offset_b, times, temps_F)) -- np.interp's own arithmetic (clamped at the ends: the host
+   * checks the range, where the reference raises).  Overrides everything above. */
+  const double *weather_times_dev;  /* DEVICE [weather_n] ascending, seconds */
+  const double *weather_tempf_dev;  /* DEVICE [weather_n] degrees Fahrenheit */
+  const double *weather_offset_dev; /* DEVICE [B] seconds, or NULL (no shift) */
+  int32_t weather_n;
+  double weather_t_now, weather_t_next; /* query times t and t+dt, seconds on the trace's clock */
   int32_t comfort_now;     /* schedule.is_comfort_mode(t) */
   int32_t comfort_prev;    /* is_comfort_mode(previous thermostat timestamp); -1 = none */
   int32_t comfort_next;    /* is_comfort_mode(t+dt): setpoint window seen by the reward */

@@ -60,6 +60,8 @@ class ObsLayout(C.Structure):
 class StepIn(C.Structure):
   _fields_ = [("t_amb_now", C.c_double), ("t_amb_next", C.c_double), ("t_amb_dev", C.c_void_p),
               ("weather_lohi_dev", C.c_void_p), ("weather_f_now", C.c_double), ("weather_f_next", C.c_double),
+              ("weather_times_dev", C.c_void_p), ("weather_tempf_dev", C.c_void_p), ("weather_offset_dev", C.c_void_p),
+              ("weather_n", C.c_int32), ("weather_t_now", C.c_double), ("weather_t_next", C.c_double),
               ("comfort_now", C.c_int32), ("comfort_prev", C.c_int32),
               ("comfort_next", C.c_int32), ("has_action", C.c_int32),
               ("occupancy", C.c_double), ("occupancy_dev", C.c_void_p),

@@ -277,13 +277,39 @@ struct Bld {
 // per-building table g[class] = gc*T_amb + sc*q_zone (q of the PREVIOUS step feeds this sweep),
 // VAV outputs from the PRE-update zone temperatures (simulator.py:433-448), demand accumulation
 // in the reference's zone order, boiler tank lag (boiler.py:158-217).
+// np.interp(x, xp, fp) for one x (numpy's arr_interp: value at a knot is the knot's, otherwise
+// slope * (x - xp[j]) + fp[j] with the slope of the bracketing interval), then
+// conversion_utils.fahrenheit_to_kelvin (conversion_utils.py:155-171).
+__device__ inline double replay_weather_kelvin(const double *xp, const double *fp, int n, double x) {
+  double f;
+  if (x <= xp[0]) f = fp[0];
+  else if (x >= xp[n - 1]) f = fp[n - 1];
+  else {
+    int lo = 0, hi = n - 1; // xp[lo] <= x < xp[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    if (x == xp[lo]) f = fp[lo];
+    else {
+      const double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
+      f = __dadd_rn(__dmul_rn(slope, x - xp[lo]), fp[lo]);
+    }
+  }
+  return __dadd_rn(__dmul_rn(f - 32.0, 5.0) / 9.0, 273.15);
+}
+
 __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   const sb_params &p = a.p;
   const sb_step_in &in = s.in;
   const double *S = a.scal + (size_t)b * kNScal;
   const size_t zb = (size_t)b * a.Z;
   Bld v;
-  if (in.weather_lohi_dev) { // weather_controller.py:119-121, per building; no fma: the reference's two roundings
+  if (in.weather_times_dev) {
+    const double off = in.weather_offset_dev ? in.weather_offset_dev[b] : 0.0;
+    v.t_now = replay_weather_kelvin(in.weather_times_dev, in.weather_tempf_dev, in.weather_n, in.weather_t_now + off);
+    v.t_next = replay_weather_kelvin(in.weather_times_dev, in.weather_tempf_dev, in.weather_n, in.weather_t_next + off);
+  } else if (in.weather_lohi_dev) { // weather_controller.py:119-121, per building; no fma: the reference's two roundings
     const double lo = in.weather_lohi_dev[2 * b], hi = in.weather_lohi_dev[2 * b + 1];
     v.t_now = __dadd_rn(__dmul_rn(in.weather_f_now, hi - lo), lo);
     v.t_next = __dadd_rn(__dmul_rn(in.weather_f_next, hi - lo), lo);

@@ -454,7 +454,12 @@ class BatchedEnvironment:
                                 histogram_parameters=observation_histogram_parameters,
                                 normalize_reduce=normalize_reduce)
     self.batch_size = self.sim.B
-    self._weather_lohi = None
+    self._weather_lohi = self._weather_replay = None
+    if isinstance(self.weather, host_inputs.BatchedReplayWeather):
+      if self.weather.offsets_sec.shape[0] != self.batch_size:
+        raise ValueError("BatchedReplayWeather needs one offset per building")
+      td = lambda a: torch.tensor(a, dtype=torch.float64, device=self.sim.tdev).contiguous()
+      self._weather_replay = (td(self.weather.times), td(self.weather.temps_f), td(self.weather.offsets_sec))
     if isinstance(self.weather, host_inputs.BatchedSinusoidWeather):
       if self.weather.low.shape[0] != self.batch_size:
         raise ValueError("BatchedSinusoidWeather needs one (low, high) pair per building")
@@ -533,7 +538,12 @@ class BatchedEnvironment:
   def make_step_in(self, ts: dt.datetime, has_action: bool = True) -> _ffi.StepIn:
     nxt = ts + self._step_interval
     si = _ffi.StepIn()
-    if isinstance(self.weather, host_inputs.BatchedSinusoidWeather):   # per-building weather, on the device
+    if self._weather_replay is not None:   # per-building replay weather, interpolated on the device
+      tt, tf, off = self._weather_replay
+      si.weather_times_dev, si.weather_tempf_dev, si.weather_offset_dev = tt.data_ptr(), tf.data_ptr(), off.data_ptr()
+      si.weather_n = int(tt.shape[0])
+      si.weather_t_now, si.weather_t_next = self.weather.query_time(ts), self.weather.query_time(nxt)
+    elif isinstance(self.weather, host_inputs.BatchedSinusoidWeather):   # per-building weather, on the device
       si.weather_lohi_dev = self._weather_lohi.data_ptr()
       si.weather_f_now, si.weather_f_next = self.weather.factor(ts), self.weather.factor(nxt)
     else:
@@ -575,7 +585,7 @@ class BatchedEnvironment:
     self._episode_count += 1
     self._step_count = 0
     self._needs_reset = False
-    if isinstance(self.weather, host_inputs.BatchedSinusoidWeather):
+    if isinstance(self.weather, (host_inputs.BatchedSinusoidWeather, host_inputs.BatchedReplayWeather)):
       t_amb = torch.tensor(self.weather.temps(self._now), dtype=torch.float64, device=self.sim.tdev)
     else:
       t_amb = self.weather.get_current_temp(self._now)

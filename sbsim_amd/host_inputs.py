@@ -153,6 +153,48 @@ class ReplayWeatherController:
     return self.convection_coefficient
 
 
+class BatchedReplayWeather(ReplayWeatherController):
+  """One ``ReplayWeatherController`` per building over the same CSV, building b reading the trace
+  ``offsets_sec[b]`` seconds ahead (per-building weather diversity).  The
+  interpolation runs on the device (``sb_step_in.weather_times_dev``): np.interp's arithmetic and
+  the reference's Fahrenheit -> kelvin conversion, bit-identical to ``temps()`` below."""
+
+  def __init__(self, local_weather_path: str, offsets_sec, convection_coefficient: float = 12.0):
+    super().__init__(local_weather_path, convection_coefficient)
+    self.offsets_sec = np.ascontiguousarray(offsets_sec, dtype=np.float64)
+    if self.offsets_sec.ndim != 1:
+      raise ValueError("offsets_sec must be one offset per building")
+
+  @property
+  def times(self) -> np.ndarray:
+    return self._times
+
+  @property
+  def temps_f(self) -> np.ndarray:
+    return self._temps
+
+  def query_time(self, timestamp) -> float:
+    ts = as_datetime(timestamp)
+    if ts.tzinfo is None:
+      raise TypeError("ReplayWeatherController needs a tz-aware timestamp (reference: tz_convert)")
+    target = ts.timestamp()
+    lo, hi = target + self.offsets_sec.min(), target + self.offsets_sec.max()
+    if lo < self._times.min():   # weather_controller.py:196-205, for every building
+      raise ValueError(f"Attempting to get weather data at {ts}, before the latest timestamp.")
+    if hi > self._times.max():
+      raise ValueError(f"Attempting to get weather data at {ts}, after the latest timestamp.")
+    return target
+
+  def temps(self, timestamp) -> np.ndarray:
+    """[B] ambient temperatures, K."""
+    x = self.query_time(timestamp) + self.offsets_sec
+    temp_f = np.array([np.interp(v, self._times, self._temps) for v in x])   # scalar calls: arr_interp's scalar path
+    return (temp_f - 32.0) * 5.0 / 9.0 + 273.15
+
+  def get_current_temp(self, timestamp) -> float:
+    raise TypeError("per-building weather: use temps() / BatchedEnvironment")
+
+
 # --------------------------------------------------------------------------- schedule
 class SetpointSchedule:
   """Day (comfort) / night (eco) temperature windows (simulator/setpoint_schedule.py:29-128)."""
