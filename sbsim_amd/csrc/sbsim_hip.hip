@@ -404,7 +404,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
     r.lw[0] = 64; r.l0[0] = 0; r.rowbase[0] = 0;
     r.nch[0] = (NR + 63 + 7) / 8;
     r.lag = 0; r.nslots = r.nch[0];
-    r.steps = NR + 63 + 8 * r.T; // a tail row's scans cost about 8 wavefront steps
+    r.steps = NR + 4 * r.T; // overlapped sweeps: NR steps per sweep; a tail row's scan costs about 4 wavefront steps
   } else if (P == 1) {
     r.lw[0] = Hs; r.l0[0] = 0; r.rowbase[0] = 0;
     r.nch[0] = (NR + Hs - 1 + 7) / 8;

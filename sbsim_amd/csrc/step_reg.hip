@@ -675,10 +675,16 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       // one 8-byte store per register straight from e[]: a wider store would have to be
       // assembled in a temporary that the next store overwrites (measured 6x slower)
       double *tp = a.temp + (size_t)b * a.state_doubles;
+#ifndef SB_EPI
+#define SB_EPI 2
+#endif
+      constexpr bool kFuse = SB_EPI >= 1 && P == kTail; // store, zone add (and next load) slot by slot
+      if (!kFuse) {
 #pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        tp[R] = e[j];
-        tp += P == kTail ? RS : opaque_s(RS);
+        for (int j = 0; j < NR; ++j) {
+          tp[R] = e[j];
+          tp += P == kTail ? RS : opaque_s(RS);
+        }
       }
       for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + R] = 0.0;
       __builtin_amdgcn_wave_barrier();
@@ -690,18 +696,21 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
             __hip_atomic_fetch_add(zs + (size_t)a.Z * ZRS + lane, tv, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
           }
+      const double *np_ = a.temp + (size_t)(bn < a.B ? bn : b) * a.state_doubles;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const unsigned off = (unsigned)((zwv[j >> 2] >> (16 * (j & 3))) & 0xffffull);
+        if (kFuse) { tp[R] = e[j]; tp += RS; }
         __hip_atomic_fetch_add((double *)((char *)zs + off), e[j], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (kFuse && SB_EPI >= 2) { e[j] = np_[R]; np_ += RS; }
         if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(5);
     if (bn < a.B) {
-      SB_LOAD_ROW(bn);
+      if (!(SB_EPI >= 2 && P == kTail)) SB_LOAD_ROW(bn);
       SB_LOAD_AUX(bn);
     }
     __builtin_amdgcn_sched_barrier(0);
