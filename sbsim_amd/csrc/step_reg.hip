@@ -157,6 +157,7 @@ struct SweepCtx {
   const double *tab, *Arow, *seam_in, *seam_in2; // seam_in2 == seam_in, but the compiler cannot tell
   double *seam_out;
   const unsigned long long *cmap;
+  const unsigned long long *cmapu; // the same table, wave-uniform base (index with lane + 64 * chunk)
   unsigned long long rowmask;
   int lane, lp, nch, edge_off;
   bool edge;
@@ -295,7 +296,8 @@ template <int NR, int D, int D1, int NAR>
 __device__ __forceinline__ void roll_steps(double (&e)[NR], double (&bk)[kWin], const double (&Areg)[NAR],
                                            Pipe &p, const SweepCtx &x, double &dcur, double &dnext) {
   if constexpr (D < D1) {
-    if constexpr (D % 8 == 0) p.cw[(D / 8 + 2) % 3] = x.cmap[opaque(0) + (D / 8 + 2) * 64];
+    // uniform base + lane offset + immediate: one global_load, no 64-bit address arithmetic
+    if constexpr (D % 8 == 0) p.cw[(D / 8 + 2) % 3] = x.cmapu[x.lane + (D / 8 + 2) * 64];
     if constexpr (D + kLook < D1) prefetch<NR, kTail, D + kLook>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
     if constexpr (D < NR) update<NR, kTail, D>(e, p.co[D % (kLook + 1)], x.lp, x.rowmask, dcur);
     else update_mixed<NR, D - NR>(e, bk, p.co[D % (kLook + 1)], x.lp, dcur, dnext);
@@ -424,6 +426,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   x.Arow = A + (size_t)R * a.AS; // odd row stride: the 64 lanes of a ds_read_b64 cover all 32 banks
   constexpr int kNL = lds_slots(NR, P), kNAR = NR - kNL > 0 ? NR - kNL : 1;
   x.cmap = a.cmapS + (size_t)w * (kMaxCh + 3) * 64 + lane;
+  x.cmapu = a.cmapS + (size_t)w * (kMaxCh + 3) * 64;
   x.rowmask = __builtin_amdgcn_ballot_w64(rowvalid);
   x.lane = lane; x.lp = rowvalid ? lp : (int)0x80000000; x.nch = a.nch[w];
   x.edge_off = (P == kPair && w == 0) ? lw - 1 : (P == kTail ? 63 : 0);
@@ -594,8 +597,8 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       asm volatile("" : "+v"(xr.lp)); // one v_cmp per step instead of hoisted, spilled masks
       Pipe pp;
       double dcur = 0.0, dnext = 0.0, bk[kWin];
-      pp.cw[0] = xr.cmap[opaque(0)];
-      pp.cw[1] = xr.cmap[opaque(0) + 64];
+      pp.cw[0] = xr.cmapu[xr.lane];
+      pp.cw[1] = xr.cmapu[xr.lane + 64];
       pp.cw[2] = 0;
       prefetch<NR, P, 0>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
       prefetch<NR, P, 1>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
@@ -603,9 +606,9 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       roll_steps<NR, 0, kWin>(e, bk, Areg, pp, xr, dcur, dnext);
       // class bytes of steps 56..79: loaded before the tail pass that precedes their use
       auto restart_classes = [&]() {
-        pp.cw[(kWin / 8) % 3] = xr.cmap[opaque(0) + (kWin / 8) * 64];
-        pp.cw[(kWin / 8 + 1) % 3] = xr.cmap[opaque(0) + (kWin / 8 + 1) * 64];
-        pp.cw[(kWin / 8 + 2) % 3] = xr.cmap[opaque(0) + (kWin / 8 + 2) * 64];
+        pp.cw[(kWin / 8) % 3] = xr.cmapu[xr.lane + (kWin / 8) * 64];
+        pp.cw[(kWin / 8 + 1) % 3] = xr.cmapu[xr.lane + (kWin / 8 + 1) * 64];
+        pp.cw[(kWin / 8 + 2) % 3] = xr.cmapu[xr.lane + (kWin / 8 + 2) * 64];
       };
       restart_classes();
 #pragma nounroll
