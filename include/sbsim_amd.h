@@ -235,6 +235,21 @@ int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, flo
 int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed, int64_t first_building,
                          int32_t transposed);
 
+/* SURVEY.md 8(f) rank 4 (first half) -- floor-plan preprocessing without OpenCV, on the host (no
+ * device needed).  floor_plan / zone_map: [H][W] file-input codes 0 = interior space, 1 = wall,
+ * 2 = exterior space (simulator/constants.py:24-36); zone_map may be NULL (= floor_plan).
+ * sb_floorplan_padded_shape: shape after guarantee_air_padding_in_frame
+ * (building_utils.py:137-208).  sb_floorplan_preprocess fills caller-allocated [Hp][Wp] maps:
+ * exterior_space (1 = exterior), wall_kind (0 air, 1 interior wall, 2 exterior wall after
+ * enlarge_exterior_walls, building.py:183-229), interior_wall (the un-shrunk interior-wall map the
+ * diffuser placement tests, building.py:751-756), zone_label (room index in raster order of the
+ * room's first cell, -1 elsewhere: cv2.connectedComponents with 4-connectivity,
+ * building_utils.py:406-414) and the number of rooms. */
+int sb_floorplan_padded_shape(const int8_t *floor_plan, int32_t H, int32_t W, int32_t *H_out, int32_t *W_out);
+int sb_floorplan_preprocess(const int8_t *floor_plan, const int8_t *zone_map, int32_t H, int32_t W,
+                            uint8_t *exterior_space, uint8_t *wall_kind, uint8_t *interior_wall,
+                            int16_t *zone_label, int32_t *n_rooms);
+
 /* Parity taps (all DEVICE outputs, float64). */
 int sb_get_temps(sb_handle *h, double *out_dev /* [B][H*W] */, void *stream);
 int sb_get_zone_temps(sb_handle *h, double *out_dev /* [B][Z] post-update means */, void *stream);

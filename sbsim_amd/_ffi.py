@@ -88,7 +88,8 @@ class LaunchInfo(C.Structure):
 
 EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",
            "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_convection_attach", "sb_step", "sb_step_phases", "sb_get_temps", "sb_get_zone_temps",
-           "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles")
+           "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles",
+           "sb_floorplan_padded_shape", "sb_floorplan_preprocess")
 
 _lib = None
 
@@ -128,6 +129,8 @@ def load():
                "sb_get_zone_power"):
     getattr(L, name).argtypes = [vp, vp, vp]
   L.sb_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_longlong)]
+  L.sb_floorplan_padded_shape.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+  L.sb_floorplan_preprocess.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
   _lib = L
   return L
 

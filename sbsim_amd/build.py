@@ -12,7 +12,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["sbsim_hip.hip", "step_reg.hip", "step_lds.hip"]   # one translation unit per step kernel
+SOURCES = ["sbsim_hip.hip", "step_reg.hip", "step_lds.hip",    # one translation unit per step kernel
+           "floorplan.cpp"]                                  # host-only: floor-plan preprocessing
 HEADERS = [os.path.join(CSRC, "sb_device.h"), os.path.join(ROOT, "include", "sbsim_amd.h")]
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(_HERE, "libsbsim_amd.so")
@@ -39,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
   inc = ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
   procs, objs = [], []
   for src in srcs:                       # the translation units compile in parallel
-    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
     objs.append(obj)
     if not force and _newer(obj, [src] + HEADERS):
       continue

@@ -8,10 +8,12 @@ setup").  Two jobs:
     ``FloorPlanBasedBuilding`` ends up with (``simulator/building.py:717-764``,
     ``simulator/building_utils.py:437-487``, ``simulator/thermal_diffuser_utils.py``):
     material maps, exterior-space mask, zone (room) label map in raster order, diffuser
-    weights.  OpenCV is not used: connected components come from ``scipy.ndimage.label``
-    and the "enlarge exterior walls by distance <= 2" step is written as the binary
-    dilation it is equivalent to (see ``_CHAMFER_LE_2``).  tests/test_host_golden.py checks
-    the result against arrays dumped from the reference for its own test plans.
+    weights.  OpenCV is not used: frame padding, the exterior-wall shell, the "enlarge
+    exterior walls by distance <= 2" step and the rooms' connected components run in the
+    library's own C++ (``sb_floorplan_preprocess``, csrc/floorplan.cpp, host-only).
+    tests/test_host_golden.py checks the result against arrays dumped from the reference for
+    its own test plans, tests/test_floorplan_native.py against a SciPy restatement on random
+    plans.
 
 2.  ``FloorPlan.compile`` folds everything the Gauss-Seidel sweep needs about a cell into
     a one-byte *class id* plus a small per-class coefficient table, so that the HIP
@@ -29,23 +31,44 @@ import dataclasses
 import math
 from typing import List, Optional, Sequence, Tuple
 
+import ctypes as C
+
 import numpy as np
-from scipy import ndimage
+
+from sbsim_amd import _ffi
 
 # File-input cell codes (simulator/constants.py:24-36).
 INTERIOR_SPACE, WALL, EXTERIOR_SPACE = 0, 1, 2
 
-# cv2.distanceTransform(DIST_L2, 3) uses chamfer weights a=0.955 (axial), b=1.3693
-# (diagonal).  "round(d, 2) <= 2" (building_utils.py:504-509, constants.py:
-# EXPAND_EXTERIOR_WALLS_BY_CV_AMOUNT = 2) therefore selects exactly the offsets with
-# a*(max-min)+b*min <= 2: (1,0)=.955 (2,0)=1.91 (1,1)=1.3693; (2,1)=2.32 and (3,0)=2.865
-# are out.  As a structuring element:
-_CHAMFER_LE_2 = np.array([[0, 0, 1, 0, 0],
-                          [0, 1, 1, 1, 0],
-                          [1, 1, 1, 1, 1],
-                          [0, 1, 1, 1, 0],
-                          [0, 0, 1, 0, 0]], dtype=bool)
-_CROSS = ndimage.generate_binary_structure(2, 1)
+
+def preprocess_native(floor_plan: np.ndarray, zone_map: Optional[np.ndarray] = None):
+  """sb_floorplan_preprocess: frame padding, exterior space, walls (0 air / 1 interior / 2
+  exterior after enlarge_exterior_walls), the un-shrunk interior-wall map, room labels in
+  raster order.  Returns (padded floor plan shape, exterior_space, wall_kind, interior_walls,
+  zone_label, n_rooms).
+
+  cv2.distanceTransform(DIST_L2, 3) uses chamfer weights a=0.955 (axial), b=1.3693 (diagonal);
+  "round(d, 2) <= 2" (building_utils.py:504-509, EXPAND_EXTERIOR_WALLS_BY_CV_AMOUNT = 2)
+  selects exactly the offsets with a*(max-min)+b*min <= 2: (1,0)=.955 (2,0)=1.91 (1,1)=1.3693;
+  (2,1)=2.32 and (3,0)=2.865 are out -- the 13-cell diamond of csrc/floorplan.cpp."""
+  fp = np.ascontiguousarray(floor_plan, dtype=np.int8)
+  if fp.ndim != 2 or 1 in fp.shape or 0 in fp.shape:
+    raise ValueError("floor plan is a 1 dimensional array")   # building_utils.py:150-151
+  zm = None if zone_map is None else np.ascontiguousarray(zone_map, dtype=np.int8)
+  if zm is not None and zm.shape != fp.shape:
+    raise ValueError("zone map and floor plan must have the same shape")
+  lib = _ffi.load()
+  H, W = fp.shape
+  hp, wp = C.c_int32(), C.c_int32()
+  _ffi.check(lib.sb_floorplan_padded_shape(fp.ctypes.data, H, W, C.byref(hp), C.byref(wp)), "sb_floorplan_padded_shape")
+  shape = (hp.value, wp.value)
+  ext, kind, iw = (np.zeros(shape, dtype=np.uint8) for _ in range(3))
+  label = np.zeros(shape, dtype=np.int16)
+  n = C.c_int32()
+  _ffi.check(lib.sb_floorplan_preprocess(fp.ctypes.data, zm.ctypes.data if zm is not None else None, H, W,
+                                         ext.ctypes.data, kind.ctypes.data, iw.ctypes.data, label.ctypes.data,
+                                         C.byref(n)), "sb_floorplan_preprocess")
+  return shape, ext.astype(bool), kind, iw.astype(bool), label, n.value
 
 
 @dataclasses.dataclass(frozen=True)
@@ -68,21 +91,6 @@ class Materials:
     heat capacity and density; only their product enters the physics)."""
     return Materials(air=Material(50.0, 700.0, 1.0), interior_wall=Material(50.0, 1.0, 700.0),
                      exterior_wall=Material(0.05, 700.0, 1.0))
-
-
-def _pad_frame(plan: np.ndarray) -> np.ndarray:
-  """building_utils.py:137-208 guarantee_air_padding_in_frame."""
-  if 1 in plan.shape or 0 in plan.shape:
-    raise ValueError("floor plan is a 1 dimensional array")
-  if np.any(plan[0, :] == WALL):
-    plan = np.concatenate((np.full((1, plan.shape[1]), EXTERIOR_SPACE), plan), axis=0)
-  if np.any(plan[:, 0] == WALL):
-    plan = np.concatenate((np.full((plan.shape[0], 1), EXTERIOR_SPACE), plan), axis=1)
-  if np.any(plan[-1, :] == WALL):
-    plan = np.concatenate((plan, np.full((1, plan.shape[1]), EXTERIOR_SPACE)), axis=0)
-  if np.any(plan[:, -1] == WALL):
-    plan = np.concatenate((plan, np.full((plan.shape[0], 1), EXTERIOR_SPACE)), axis=1)
-  return plan
 
 
 def _evenly_spaced(start: int, end: int, spacing: int) -> List[int]:
@@ -156,29 +164,16 @@ class FloorPlan:
                       buffer_from_walls: int = 3, diffuser_spacing: int = 10,
                       diffusers: Optional[np.ndarray] = None) -> "FloorPlan":
     """building.py:633-764 + building_utils.py:437-487."""
-    fp = _pad_frame(np.asarray(floor_plan))
-    zm = fp if zone_map is None else _pad_frame(np.asarray(zone_map))
-    exterior_space = fp == EXTERIOR_SPACE                       # _determine_exterior_space
-    # _label_exterior_wall_shell: 4-neighbourhood of exterior space, minus itself
-    shell = ndimage.binary_dilation(exterior_space, structure=_CROSS) & ~exterior_space
-    interior_walls = (fp == WALL) & ~shell                      # _label_interior_walls
-    # building.py:183-229 enlarge_exterior_walls
-    near_shell = ndimage.binary_dilation(shell, structure=_CHAMFER_LE_2)
-    exterior_walls = (near_shell.astype(int) + interior_walls + shell) >= 2
-    interior_walls_shrunk = interior_walls & ~exterior_walls
-    # rooms: 4-connected components of the zone map's interior space, raster order
-    labels, n_rooms = ndimage.label(zm == INTERIOR_SPACE, structure=_CROSS)
-    zone_label = (labels.astype(np.int16) - 1)
-    zone_label[zm == EXTERIOR_SPACE] = -1                       # _set_exterior_space_neg
+    shape, exterior_space, wall_kind, interior_walls, zone_label, n_rooms = preprocess_native(floor_plan, zone_map)
 
     def assign(prop: str) -> np.ndarray:                        # building.py:232-268
-      return np.where(interior_walls_shrunk, getattr(materials.interior_wall, prop),
-                      np.where(exterior_walls, getattr(materials.exterior_wall, prop),
+      return np.where(wall_kind == 1, getattr(materials.interior_wall, prop),
+                      np.where(wall_kind == 2, getattr(materials.exterior_wall, prop),
                                getattr(materials.air, prop))).astype(np.float64)
 
     if diffusers is None:
-      diffusers = np.zeros(fp.shape, dtype=np.float64)
-      H, W = fp.shape
+      diffusers = np.zeros(shape, dtype=np.float64)
+      H, W = shape
       for z in range(n_rooms):
         flat = np.nonzero(zone_label.reshape(-1) == z)[0]
         cells = np.stack([flat // W, flat % W], axis=1)

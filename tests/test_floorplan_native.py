@@ -1,0 +1,88 @@
+"""sb_floorplan_preprocess (csrc/floorplan.cpp) against a SciPy restatement of the same steps
+on random floor plans (the reference's own test plans: tests/test_host_golden.py)."""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from sbsim_amd.floorplan import EXTERIOR_SPACE, INTERIOR_SPACE, WALL, preprocess_native
+
+_CHAMFER_LE_2 = np.array([[0, 0, 1, 0, 0],
+                          [0, 1, 1, 1, 0],
+                          [1, 1, 1, 1, 1],
+                          [0, 1, 1, 1, 0],
+                          [0, 0, 1, 0, 0]], dtype=bool)
+_CROSS = ndimage.generate_binary_structure(2, 1)
+
+
+def _pad_frame(plan):
+  """building_utils.py:137-208 guarantee_air_padding_in_frame."""
+  if np.any(plan[0, :] == WALL):
+    plan = np.concatenate((np.full((1, plan.shape[1]), EXTERIOR_SPACE), plan), axis=0)
+  if np.any(plan[:, 0] == WALL):
+    plan = np.concatenate((np.full((plan.shape[0], 1), EXTERIOR_SPACE), plan), axis=1)
+  if np.any(plan[-1, :] == WALL):
+    plan = np.concatenate((plan, np.full((1, plan.shape[1]), EXTERIOR_SPACE)), axis=0)
+  if np.any(plan[:, -1] == WALL):
+    plan = np.concatenate((plan, np.full((plan.shape[0], 1), EXTERIOR_SPACE)), axis=1)
+  return plan
+
+
+def _scipy_preprocess(floor_plan, zone_map=None):
+  fp = _pad_frame(np.asarray(floor_plan))
+  zm = fp if zone_map is None else _pad_frame(np.asarray(zone_map))
+  exterior_space = fp == EXTERIOR_SPACE
+  shell = ndimage.binary_dilation(exterior_space, structure=_CROSS) & ~exterior_space
+  interior_walls = (fp == WALL) & ~shell
+  near_shell = ndimage.binary_dilation(shell, structure=_CHAMFER_LE_2)
+  exterior_walls = (near_shell.astype(int) + interior_walls + shell) >= 2
+  kind = np.where(exterior_walls, 2, np.where(interior_walls, 1, 0)).astype(np.uint8)
+  labels, n_rooms = ndimage.label(zm == INTERIOR_SPACE, structure=_CROSS)
+  zone_label = labels.astype(np.int16) - 1
+  zone_label[zm == EXTERIOR_SPACE] = -1
+  return fp.shape, exterior_space, kind, interior_walls, zone_label, n_rooms
+
+
+def _random_plan(rs, H, W):
+  """Exterior margin of random width (sometimes none: frame padding), a walled box, random
+  interior wall segments (with gaps, so rooms merge), a few exterior notches."""
+  plan = np.full((H, W), EXTERIOR_SPACE, dtype=np.int8)
+  t, l = rs.randint(0, 3), rs.randint(0, 3)
+  b, r = H - rs.randint(0, 3), W - rs.randint(0, 3)
+  plan[t:b, l:r] = WALL
+  plan[t + 1:b - 1, l + 1:r - 1] = INTERIOR_SPACE
+  for _ in range(rs.randint(2, 9)):
+    if rs.rand() < 0.5:
+      x = rs.randint(t + 2, b - 2); y0, y1 = sorted(rs.randint(l + 1, r - 1, size=2))
+      plan[x, y0:y1 + 1] = WALL
+    else:
+      y = rs.randint(l + 2, r - 2); x0, x1 = sorted(rs.randint(t + 1, b - 1, size=2))
+      plan[x0:x1 + 1, y] = WALL
+  for _ in range(rs.randint(0, 3)):      # a courtyard: exterior space inside, walled off
+    x, y = rs.randint(t + 3, b - 5), rs.randint(l + 3, r - 5)
+    plan[x - 1:x + 3, y - 1:y + 3] = WALL
+    plan[x:x + 2, y:y + 2] = EXTERIOR_SPACE
+  return plan
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_native_preprocessing_equals_the_scipy_restatement(seed):
+  rs = np.random.RandomState(seed)
+  plan = _random_plan(rs, rs.randint(14, 40), rs.randint(14, 60))
+  got = preprocess_native(plan)
+  want = _scipy_preprocess(plan)
+  assert got[0] == want[0] and got[5] == want[5] and got[5] >= 1
+  for a, b, name in zip(got[1:5], want[1:5], ("exterior_space", "wall_kind", "interior_walls", "zone_label")):
+    assert np.array_equal(a, b), name
+
+
+def test_zone_map_and_argument_checks():
+  rs = np.random.RandomState(3)
+  plan = _random_plan(rs, 20, 30)
+  zone_map = plan.copy()
+  zone_map[9, :] = np.where(zone_map[9, :] == INTERIOR_SPACE, WALL, zone_map[9, :])   # zones split finer than rooms
+  got, want = preprocess_native(plan, zone_map), _scipy_preprocess(plan, zone_map)
+  assert got[5] == want[5] and np.array_equal(got[4], want[4]) and np.array_equal(got[2], want[2])
+  with pytest.raises(ValueError, match="1 dimensional"):
+    preprocess_native(np.zeros((1, 8), dtype=np.int8))
+  with pytest.raises(ValueError, match="same shape"):
+    preprocess_native(plan, zone_map[:-1])
