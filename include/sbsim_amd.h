@@ -47,7 +47,7 @@ extern "C" {
 #define SB_ABI_VERSION 4
 #define SB_NUM_ACTIONS 2   /* boiler supply_water_setpoint, AHU supply_air_heating_temperature_setpoint */
 #define SB_NUM_AUX 7       /* hod cos/sin, dow cos/sin, comfort_now, comfort_soon, num_occupants */
-#define SB_INFO_STRIDE 8   /* floats per building in the optional info output */
+#define SB_INFO_STRIDE 24  /* floats per building in the optional info output */
 
 typedef enum sb_status {
   SB_OK = 0,
@@ -182,7 +182,11 @@ int sb_observe_occupancy(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb
 /* One Environment._step for every building.  actions_dev [B][2] fp32 in [-1,1] (or NULL
  * when in->has_action == 0); obs_dev [B][O] fp32; reward_dev [B] fp32; info_dev optional
  * [B][SB_INFO_STRIDE] fp32 = {blower W, air-conditioning W, gas W, pump W, sweeps,
- * converged, supply air K, reward before the fp32 store}. */
+ * converged, supply air K, reward before the fp32 store, then RewardResponse fields 2..17
+ * (proto/smart_control_reward.proto:124-181; setpoint_energy_carbon_regret.py:239-291):
+ * productivity_reward, electricity_energy_cost, natural_gas_energy_cost, carbon_emitted,
+ * carbon_cost (0), the three weights, person_productivity, total_occupancy, reward_scale (1),
+ * reward_shift (0), productivity_regret, normalized productivity regret / energy cost / carbon}. */
 int sb_step(sb_handle *h, const float *actions_dev, const sb_step_in *in, float *obs_dev,
             float *reward_dev, float *info_dev, void *stream);
 
@@ -249,6 +253,39 @@ int sb_floorplan_padded_shape(const int8_t *floor_plan, int32_t H, int32_t W, in
 int sb_floorplan_preprocess(const int8_t *floor_plan, const int8_t *zone_map, int32_t H, int32_t W,
                             uint8_t *exterior_space, uint8_t *wall_kind, uint8_t *interior_wall,
                             int16_t *zone_label, int32_t *n_rooms);
+
+/* SURVEY.md 8(f) rank 4 (second half) -- ProtoWriter-compatible episode shards, host-only:
+ * the reference's four per-step messages encoded from plain arrays (proto3 wire format, no
+ * protobuf library) and appended, length-prefixed, to hourly files
+ * (utils/controller_writer.py:53-131), readable by the reference's ProtoReader.  The sb_pb_*
+ * encoders return the serialized size (the bytes are written when out != NULL and the size fits
+ * cap), or a negative sb_status.  Map entries are emitted in key order
+ * (= SerializeToString(deterministic=True)). */
+typedef struct sb_pb_time { int64_t seconds; int32_t nanos; } sb_pb_time;
+/* RewardInfo (proto/smart_control_reward.proto:49-118; simulator.py:548-576).  zone_vals [n][6]:
+ * heating setpoint, cooling setpoint, zone air temperature, air-flow setpoint, air flow, average
+ * occupancy; ahu_vals [n][2]: blower W, air-conditioning W; blr_vals [n][2]: gas W, pump W. */
+int64_t sb_pb_reward_info(sb_pb_time start, sb_pb_time end, const char *agent_id, const char *scenario_id,
+                          int32_t n_zones, const char *const *zone_ids, const float *zone_vals,
+                          int32_t n_ahu, const char *const *ahu_ids, const float *ahu_vals,
+                          int32_t n_blr, const char *const *blr_ids, const float *blr_vals,
+                          uint8_t *out, int64_t cap);
+/* RewardResponse (:124-185): vals = fields 1..17 in proto order. */
+int64_t sb_pb_reward_response(const float vals[17], sb_pb_time start, sb_pb_time end, uint8_t *out, int64_t cap);
+/* ObservationResponse as SimulatorBuilding.request_observations builds it
+ * (simulator_building.py:151-202): every single response carries the timestamp, its request,
+ * observation_valid and (when valid) continuous_value. */
+int64_t sb_pb_observation_response(sb_pb_time ts, int32_t n, const char *const *device_ids,
+                                   const char *const *measurement_names, const float *values,
+                                   const uint8_t *valid, uint8_t *out, int64_t cap);
+/* ActionResponse as request_action builds it (simulator_building.py:204-263); response_types:
+ * SingleActionResponse.ActionResponseType (1 = ACCEPTED). */
+int64_t sb_pb_action_response(sb_pb_time ts, sb_pb_time request_ts, int32_t n, const char *const *device_ids,
+                              const char *const *setpoint_names, const float *values,
+                              const int32_t *response_types, uint8_t *out, int64_t cap);
+/* ProtoWriter._write_msg_to_disk: append <4-byte LE size><msg> to <dir>/<prefix>_YYYY.MM.DD.HH
+ * (the hour of unix_seconds, read as UTC). */
+int sb_shard_append(const char *dir, const char *prefix, int64_t unix_seconds, const uint8_t *msg, int64_t n);
 
 /* Parity taps (all DEVICE outputs, float64). */
 int sb_get_temps(sb_handle *h, double *out_dev /* [B][H*W] */, void *stream);

@@ -199,6 +199,9 @@ def install() -> None:
           distanceTransform=_distance_transform, dilate=_dilate, DIST_L2=2)
   _module("mediapy")
   _module("seaborn")
+  # utils/writer_lib.py only names the type in an annotation
+  ir_abc = _module("importlib_resources.abc", Traversable=object)
+  _module("importlib_resources", abc=ir_abc)
 
   # tf_agents.specs is only touched to build ArraySpecs; give it inert constructors.
   specs = _module("tf_agents.specs", BoundedArraySpec=_Inert, ArraySpec=_Inert)

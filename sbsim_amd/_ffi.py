@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SBSIM_LIB") or os.path.join(_HERE, "libsbsim_amd.so")
 SB_NUM_ACTIONS = 2
 SB_NUM_AUX = 7
 SB_ABI_VERSION = 4   # include/sbsim_amd.h
-SB_INFO_STRIDE = 8
+SB_INFO_STRIDE = 24
 SB_NUM_SCALARS = 16
 
 _dp = C.POINTER(C.c_double)
@@ -78,6 +78,10 @@ class OccupancyConfig(C.Structure):
               ("seed", C.c_uint64), ("first_building", C.c_int64)]
 
 
+class PbTime(C.Structure):
+  _fields_ = [("seconds", C.c_int64), ("nanos", C.c_int32)]
+
+
 class LaunchInfo(C.Structure):
   _fields_ = [("waves_per_workgroup", C.c_int32), ("workgroups", C.c_int32),
               ("lds_bytes_per_workgroup", C.c_int32), ("sweep_steps", C.c_int32),
@@ -89,7 +93,8 @@ class LaunchInfo(C.Structure):
 EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",
            "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_convection_attach", "sb_step", "sb_step_phases", "sb_get_temps", "sb_get_zone_temps",
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles",
-           "sb_floorplan_padded_shape", "sb_floorplan_preprocess")
+           "sb_floorplan_padded_shape", "sb_floorplan_preprocess", "sb_pb_reward_info", "sb_pb_reward_response",
+           "sb_pb_observation_response", "sb_pb_action_response", "sb_shard_append")
 
 _lib = None
 
@@ -129,6 +134,15 @@ def load():
                "sb_get_zone_power"):
     getattr(L, name).argtypes = [vp, vp, vp]
   L.sb_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_longlong)]
+  cpp, fp_ = C.POINTER(C.c_char_p), C.POINTER(C.c_float)
+  L.sb_pb_reward_info.argtypes = [PbTime, PbTime, C.c_char_p, C.c_char_p, C.c_int32, cpp, fp_, C.c_int32, cpp, fp_,
+                                  C.c_int32, cpp, fp_, vp, C.c_int64]
+  L.sb_pb_reward_response.argtypes = [fp_, PbTime, PbTime, vp, C.c_int64]
+  L.sb_pb_observation_response.argtypes = [PbTime, C.c_int32, cpp, cpp, fp_, vp, vp, C.c_int64]
+  L.sb_pb_action_response.argtypes = [PbTime, PbTime, C.c_int32, cpp, cpp, fp_, vp, vp, C.c_int64]
+  for name in ("sb_pb_reward_info", "sb_pb_reward_response", "sb_pb_observation_response", "sb_pb_action_response"):
+    getattr(L, name).restype = C.c_int64
+  L.sb_shard_append.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, vp, C.c_int64]
   L.sb_floorplan_padded_shape.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
   L.sb_floorplan_preprocess.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
   _lib = L

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["sbsim_hip.hip", "step_reg.hip", "step_lds.hip",    # one translation unit per step kernel
-           "floorplan.cpp"]                                  # host-only: floor-plan preprocessing
+           "floorplan.cpp", "episode.cpp"]                   # host-only: floor-plan preprocessing, episode shards
 HEADERS = [os.path.join(CSRC, "sb_device.h"), os.path.join(ROOT, "include", "sbsim_amd.h")]
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(_HERE, "libsbsim_amd.so")

@@ -456,6 +456,11 @@ __device__ inline void post_building(const Dev &a, const StepArgs &s, int b) {
     float *I = s.info + (size_t)b * SB_INFO_STRIDE;
     I[0] = blower; I[1] = ac; I[2] = gas; I[3] = pump;
     I[4] = (float)n_sweeps; I[5] = (float)converged; I[6] = (float)v.t_sa; I[7] = (float)reward;
+    // RewardResponse fields 2..17 (setpoint_energy_carbon_regret.py:239-291), proto floats
+    I[8] = (float)actual; I[9] = (float)ce; I[10] = (float)cg; I[11] = (float)(ke + kg); I[12] = 0.0f;
+    I[13] = (float)p.w_prod; I[14] = (float)p.w_cost; I[15] = (float)p.w_carbon; I[16] = (float)p.max_prod;
+    I[17] = (float)total_occ; I[18] = 1.0f; I[19] = 0.0f; I[20] = (float)(actual - max_p);
+    I[21] = (float)npr; I[22] = (float)nec; I[23] = (float)nce;
   }
   if (s.obs) write_obs(a, b, s.obs, in.aux, v.t_next, S, in.num_occupants_dev, in.occupancy_norm);
 }

@@ -97,6 +97,13 @@ def test_one_day_rollout_against_reference_golden(tag, kernel, monkeypatch):
     r = rew.cpu().numpy().astype(np.float64)
     worst_r = max(worst_r, np.abs(r - float(g["reward"][t])).max())
     assert np.abs(r - float(g["reward"][t])).max() < 1e-6, t
+    # RewardResponse diagnostics (info[8:24] = proto fields 2..17) against the reference's response
+    rr = np.array([g["rr_productivity"][t], g["rr_elec_cost"][t], g["rr_gas_cost"][t], g["rr_carbon"][t]], np.float64)
+    assert np.allclose(i[:, 8:12], rr, rtol=3e-6, atol=1e-9), (t, i[0, 8:12], rr)
+    nr = np.array([g["rr_norm_prod_regret"][t], g["rr_norm_energy_cost"][t], g["rr_norm_carbon"][t]], np.float64)
+    assert np.allclose(i[:, 21:24], nr, rtol=3e-6, atol=1e-7), (t, i[0, 21:24], nr)
+    assert (i[:, 12] == 0).all() and (i[:, 18] == 1).all() and (i[:, 19] == 0).all()
+    assert np.allclose(i[:, 17], 9 * float(g["occupancy"][t]), rtol=1e-6) and np.allclose(i[:, 20], i[:, 8] - i[:, 16] * i[:, 17] * 300.0 / 3600.0, rtol=1e-4, atol=1e-4)
     # native observation values (identity normalisation) == the proto's fp32 values
     o = obs.cpu().numpy()
     assert np.allclose(o[:, :col_aux], g["obs"][t], rtol=1e-6, atol=1e-6), t
