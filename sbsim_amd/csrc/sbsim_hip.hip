@@ -2,7 +2,9 @@
 // handle creation (floor-plan tables, launch geometry, choice of step kernel), reset /
 // observe / parity-tap kernels.  The step kernels live in step_reg.hip (temperature grid in
 // registers; floor plans whose trimmed grid has <= 128 rows and <= 96 columns) and
-// step_lds.hip (grid in LDS; any shape that fits a CU's LDS); both share sb_device.h.
+// step_lds.hip (grid in LDS; any shape that fits a CU's LDS); both share sb_device.h.  The
+// optional input generators (occupancy, convection) live in generators.hip; sb_host.h holds
+// what the two host files share (the handle, device buffers, error reporting).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (fma only where written).
 #include <hip/hip_runtime.h>
@@ -15,25 +17,11 @@
 #include <string>
 #include <vector>
 
-#include "sb_device.h"
+#include "sb_host.h"
 
 using namespace sb;
 
 namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const std::string &msg) {
-  g_err = msg;
-  return code;
-}
-
-#define SB_HIP(call)                                                                     \
-  do {                                                                                   \
-    hipError_t e_ = (call);                                                              \
-    if (e_ != hipSuccess)                                                                \
-      return fail(SB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
-  } while (0)
 
 constexpr int kGuardHost = 16; // must match kGuard in step_lds.hip
 
@@ -110,166 +98,6 @@ __global__ void k_observe(Dev a, float *obs, float aux0, float aux1, float aux2,
     write_obs(a, b, obs, aux, t_amb_b ? t_amb_b[b] : t_amb, a.scal + (size_t)b * kNScal, num_occupants, occ_norm);
 }
 
-// ---------------------------------------------------------------- randomized occupancy
-// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): ten
-// rounds of two 32x32 -> 64 multiplies on a 128-bit counter under a 64-bit key.
-__device__ inline void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-
-struct OccArgs {
-  uint32_t *state; // [B][Z]: bit i = occupant i of the zone is at WORK
-  int B, Z, n_occ, hour, workday, e_arr, l_arr, e_dep;
-  double p_arr, p_dep;
-  uint64_t seed;
-  long long first_building;
-  uint32_t query;
-  float *count, *total;
-};
-
-// ZoneOccupant.peek (randomized_arrival_departure_occupancy.py:138-160) for every occupant of
-// every zone of one building per thread.  Uniform of occupant i: word i & 3 of the Philox block
-// with counter (building lo, building hi, zone, query * 8 + (i >> 2)), u = (x >> 8) / 2^24.
-__global__ void k_occupancy(OccArgs o) {
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < o.B; b += gridDim.x * blockDim.x) {
-    const unsigned long long gb = (unsigned long long)(o.first_building + b);
-    float tot = 0.0f;
-    for (int z = 0; z < o.Z; ++z) {
-      uint32_t st = o.state[(size_t)b * o.Z + z];
-      if (!o.workday) st = 0;
-      else {
-        const bool arr_open = !(o.hour < o.e_arr || o.hour > o.l_arr), dep_open = !(o.hour < o.e_dep);
-        if (arr_open || dep_open)
-          for (int blk = 0; blk * 4 < o.n_occ; ++blk) {
-            uint32_t c[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)z, o.query * 8u + (uint32_t)blk};
-            philox4x32_10(c, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
-            for (int k = 0; k < 4 && blk * 4 + k < o.n_occ; ++k) {
-              const int i = blk * 4 + k;
-              const double u = (double)(c[k] >> 8) * (1.0 / 16777216.0);
-              const bool at_work = (st >> i) & 1u;
-              if (!at_work && arr_open && u < o.p_arr) st |= 1u << i;
-              else if (at_work && dep_open && u < o.p_dep) st &= ~(1u << i);
-            }
-          }
-      }
-      o.state[(size_t)b * o.Z + z] = st;
-      const float n = (float)__popc(st);
-      if (o.count) o.count[(size_t)b * o.Z + z] = n;
-      tot += n;
-    }
-    if (o.total) o.total[b] = tot;
-  }
-}
-
-// ---------------------------------------------------------------- stochastic convection
-// StochasticConvectionSimulator._shuffle_max_dist (stochastic_convection_simulator.py:101-145),
-// one workgroup per building, room by room.  Every air cell of a room is, with probability p,
-// the first half of a swap whose second half is drawn uniformly from the room's cells within
-// the offset table (dx^2 + dy^2 <= distance inside the [-distance, distance) window, :125-131);
-// the swaps are applied one after the other in a uniformly random order (:137).  Random order:
-// swap i gets the time stamp T_i = (32 random bits, i) and swaps run by increasing T.  Instead of
-// replaying the sequence, every VALUE is followed through it: at cell c after time t the next
-// swap touching c is the earliest of c's own swap and the swaps that chose c (a linked list per
-// cell, built with LDS atomics); the value moves to that swap's other cell.  All values move
-// in parallel, reads before writes.  Randomness: Philox4x32-10, key = seed, counter = (global
-// building lo, hi, call number, grid cell): word 0 -> inclusion, 1 -> choice, 2 -> time stamp.
-struct ConvCell {
-  int g0;                  // the cell's index in the caller's [H, W] grid: Philox counter, tie-break
-  int gh;                  // ... in the handle's grid (which may be the transposed plan)
-  int sidx;                // index into the building's state
-  int pad;
-  unsigned long long mask; // bit k: offset k of the table leads to a cell of the same room
-};
-
-struct ConvArgs {
-  double *temp;
-  size_t stride; // doubles per building
-  const int *zone_off, *local, *off;
-  const ConvCell *cells; // every zone's cells, within a zone by increasing state index: lanes that
-                         // read / write neighbouring cells of the list touch neighbouring memory
-  int B, Z, W, n_off, max_room;
-  double p;
-  uint64_t seed;
-  long long first_building;
-  uint32_t call;
-};
-
-constexpr int kConvMaxThreads = 512, kConvMaxPerLane = 8; // rooms up to 4,096 cells
-
-// Q: cells per lane; the workgroup has ceil(largest room / Q) lanes rounded up to a wavefront
-template <int Q>
-__global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
-  const int kConvThreads = blockDim.x;
-  extern __shared__ unsigned long long conv_lds[];
-  unsigned long long *T = conv_lds;            // [max_room] time stamp of the cell's own swap
-  double *vout = (double *)(T + o.max_room);   // [max_room] the value that ends in this cell
-  int *part = (int *)(vout + o.max_room);      // [max_room] other cell of the cell's own swap (itself: none)
-  int *head = part + o.max_room;               // [max_room] first swap that chose this cell
-  int *nxt = head + o.max_room;                // [max_room] next swap that chose the same cell
-  const int tid = threadIdx.x;
-  for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
-    double *st = o.temp + (size_t)b * o.stride;
-    const unsigned long long gb = (unsigned long long)(o.first_building + b);
-    for (int z = 0; z < o.Z; ++z) {
-      const int c0 = o.zone_off[z], n = o.zone_off[z + 1] - c0;
-      for (int i = tid; i < n; i += kConvThreads) head[i] = -1;
-      __syncthreads();
-      double val[Q];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int i = tid + q * kConvThreads;
-        if (i < n) {
-          const ConvCell cc = o.cells[c0 + i];
-          val[q] = st[cc.sidx];
-          uint32_t c[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc.g0};
-          philox4x32_10(c, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
-          const double u = (double)(c[0] >> 8) * (1.0 / 16777216.0);
-          int other = i;
-          if (!(u > o.p)) { // :119
-            const int cnt = __popcll(cc.mask);
-            int pick = (int)(((unsigned long long)c[1] * (unsigned long long)cnt) >> 32); // uniform in [0, cnt)
-            unsigned long long m = cc.mask;
-            for (; pick > 0; --pick) m &= m - 1; // drop the lowest set bits
-            const int k = __ffsll((long long)m) - 1;
-            other = o.local[cc.gh + o.off[k]]; // off[k]: offset k as a step in the handle's grid
-          }
-          part[i] = other;
-          T[i] = (((unsigned long long)c[2] << 20) | (unsigned long long)cc.g0) + 1ull; // ties: raster order of the caller's grid
-          if (other != i) nxt[i] = atomicExch(&head[other], i);
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int i = tid + q * kConvThreads;
-        if (i < n) {
-          int pos = i;
-          unsigned long long t = 0;
-          for (;;) {
-            unsigned long long best = ~0ull;
-            int to = -1;
-            if (part[pos] != pos && T[pos] > t) { best = T[pos]; to = part[pos]; }
-            for (int j = head[pos]; j >= 0; j = nxt[j])
-              if (T[j] > t && T[j] < best) { best = T[j]; to = j; }
-            if (to < 0) break;
-            t = best;
-            pos = to;
-          }
-          vout[pos] = val[q];
-        }
-      }
-      __syncthreads();
-      for (int i = tid; i < n; i += kConvThreads) st[o.cells[c0 + i].sidx] = vout[i];
-      __syncthreads();
-    }
-  }
-}
-
 // building.temp in the caller's row-major layout, whichever state layout the handle uses.
 __global__ void k_copy_temps(Dev a, double *out) {
   size_t n = (size_t)a.B * a.N;
@@ -308,12 +136,6 @@ __global__ void __launch_bounds__(64) k_post(Dev a, StepArgs s) {
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
     post_building(a, s, b);
 }
-
-template <typename Tp>
-struct DevBuf {
-  Tp *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-};
 
 // ---------------------------------------------------------------- register-path planning
 // Host-only: decides whether k_step_reg can own this floor plan and builds its tables.
@@ -608,58 +430,10 @@ void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan 
 
 } // namespace
 
-struct sb_handle {
-  Dev d{};
-  int device = 0, cus = 256;
-  sb_launch_info info{};
-  DevBuf<uint8_t> cls, tcls;
-  DevBuf<double> ctab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum,
-      hist_bins;
-  DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone, cell_state, nsw, next_b, src_dest,
-      hist_col, hist_off;
-  DevBuf<Bld> bld;
-  DevBuf<uint4> zl16;
-  DevBuf<int4> sched;
-  DevBuf<unsigned long long> smask, cmapS, amapS, zmapS;
-  DevBuf<long long> dbg;
-  // host copies for the optional generators
-  std::vector<int> h_zone_off, h_zone_cells, h_state_index; // state index of every grid cell (< 0: exterior ring)
-  // sb_convection_attach
-  DevBuf<int> conv_local, conv_off; // per grid cell: index in its room's list; the offset table as linear steps
-  DevBuf<ConvCell> conv_cells;
-  double conv_p = 0.0;
-  int conv_n_off = 0, conv_max_room = 0;
-  uint64_t conv_seed = 0;
-  long long conv_first = 0;
-  uint32_t conv_calls = 0;
-  bool conv_attached = false;
-  DevBuf<uint32_t> occ_state; // sb_occupancy_attach
-  sb_occupancy_config occ{};
-  uint32_t occ_queries = 0;
-  bool occ_attached = false;
-};
-
-namespace {
-
-template <typename Tp>
-int upload(DevBuf<Tp> &buf, const Tp *src, size_t n) {
-  SB_HIP(hipMalloc((void **)&buf.p, std::max<size_t>(n, 1) * sizeof(Tp)));
-  if (n) SB_HIP(hipMemcpy(buf.p, src, n * sizeof(Tp), hipMemcpyHostToDevice));
-  return SB_OK;
-}
-template <typename Tp>
-int alloc_zero(DevBuf<Tp> &buf, size_t n) {
-  SB_HIP(hipMalloc((void **)&buf.p, std::max<size_t>(n, 1) * sizeof(Tp)));
-  SB_HIP(hipMemset(buf.p, 0, std::max<size_t>(n, 1) * sizeof(Tp)));
-  return SB_OK;
-}
-
-} // namespace
-
 extern "C" {
 
 int sb_abi_version(void) { return SB_ABI_VERSION; }
-const char *sb_last_error(void) { return g_err.c_str(); }
+const char *sb_last_error(void) { return sb::host::g_err.c_str(); }
 
 int sb_plan_info(const sb_plan_desc *plan, int32_t n_obs, int32_t n_buildings, sb_launch_info *out) {
   if (!out) return fail(SB_ERR_INVALID, "sb_plan_info: null argument");
@@ -923,145 +697,6 @@ int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const do
   return sb_observe_occupancy(h, aux, t_amb, t_amb_dev, nullptr, 0.0, obs_dev, stream);
 }
 
-int sb_occupancy_attach(sb_handle *h, const sb_occupancy_config *cfg) {
-  if (!h || !cfg) return fail(SB_ERR_INVALID, "sb_occupancy_attach: null argument");
-  if (cfg->zone_assignment < 1 || cfg->zone_assignment > 32)
-    return fail(SB_ERR_INVALID, "sb_occupancy_attach: zone_assignment must be 1..32 (one state word per zone)");
-  if (!(cfg->earliest_arrival_hour < cfg->latest_arrival_hour &&
-        cfg->latest_arrival_hour < cfg->earliest_departure_hour &&
-        cfg->earliest_departure_hour < cfg->latest_departure_hour))
-    return fail(SB_ERR_INVALID, "sb_occupancy_attach: hours must be strictly increasing "
-                                "(randomized_arrival_departure_occupancy.py:68-73)");
-  if (!(cfg->time_step_sec > 0) || cfg->first_building < 0)
-    return fail(SB_ERR_INVALID, "sb_occupancy_attach: time_step_sec must be positive, first_building >= 0");
-  SB_HIP(hipSetDevice(h->device));
-  if (!h->occ_state.p) {
-    const int rc = alloc_zero(h->occ_state, (size_t)h->d.B * h->d.Z);
-    if (rc != SB_OK) return rc;
-  } else SB_HIP(hipMemset(h->occ_state.p, 0, (size_t)h->d.B * h->d.Z * sizeof(uint32_t)));
-  h->occ = *cfg;
-  h->occ_queries = 0;
-  h->occ_attached = true;
-  return SB_OK;
-}
-
-int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, float *count_dev,
-                      float *total_dev, void *stream) {
-  if (!h) return fail(SB_ERR_INVALID, "sb_occupancy_peek: null handle");
-  if (!h->occ_attached) return fail(SB_ERR_INVALID, "sb_occupancy_peek: sb_occupancy_attach first");
-  if (local_hour < 0 || local_hour > 23) return fail(SB_ERR_INVALID, "sb_occupancy_peek: hour must be 0..23");
-  SB_HIP(hipSetDevice(h->device));
-  const sb_occupancy_config &c = h->occ;
-  OccArgs o;
-  o.state = h->occ_state.p; o.B = h->d.B; o.Z = h->d.Z; o.n_occ = c.zone_assignment;
-  o.hour = local_hour; o.workday = is_work_day != 0;
-  o.e_arr = c.earliest_arrival_hour; o.l_arr = c.latest_arrival_hour; o.e_dep = c.earliest_departure_hour;
-  // _get_event_probability (:100-112): 1 / (half the window in time steps)
-  o.p_arr = 1.0 / ((double)(c.latest_arrival_hour - c.earliest_arrival_hour) * 3600.0 / c.time_step_sec / 2.0);
-  o.p_dep = 1.0 / ((double)(c.latest_departure_hour - c.earliest_departure_hour) * 3600.0 / c.time_step_sec / 2.0);
-  o.seed = c.seed; o.first_building = c.first_building; o.query = h->occ_queries++;
-  o.count = count_dev; o.total = total_dev;
-  const int blocks = std::max(1, std::min((o.B + 63) / 64, 4096));
-  hipLaunchKernelGGL(k_occupancy, dim3(blocks), dim3(64), 0, (hipStream_t)stream, o);
-  SB_HIP(hipGetLastError());
-  return SB_OK;
-}
-
-int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed, int64_t first_building,
-                         int32_t transposed) {
-  if (!h) return fail(SB_ERR_INVALID, "sb_convection_attach: null handle");
-  if (!(p >= 0.0 && p <= 1.0)) return fail(SB_ERR_INVALID, "sb_convection_attach: p must be in [0, 1]");
-  if (first_building < 0) return fail(SB_ERR_INVALID, "sb_convection_attach: first_building must be >= 0");
-  if (p == 0.0 || distance == 0) { h->conv_attached = false; return SB_OK; } // stochastic_convection_simulator.py:70-71
-  if (distance < 0 || distance > 64)
-    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: distance must be 1..64 (distance = -1, the whole-room "
-                                    "shuffle of stochastic_convection_simulator.py:80-99, is not implemented)");
-  SB_HIP(hipSetDevice(h->device));
-  const Dev &d = h->d;
-  // :125-131: window [-distance, distance) in both directions, squared distance <= distance
-  // (in the order of the caller's grid: the handle may hold the transposed floor plan)
-  if (d.N >= (1 << 20)) return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: more than 2^20 grid cells");
-  std::vector<int> odx, ody, offd; // offsets in the handle's coordinates, linear steps
-  for (int dx = -distance; dx < distance; ++dx)
-    for (int dy = -distance; dy < distance; ++dy)
-      if (dx * dx + dy * dy <= distance) {
-        odx.push_back(transposed ? dy : dx);
-        ody.push_back(transposed ? dx : dy);
-        offd.push_back(odx.back() * d.W + ody.back());
-      }
-  if (offd.size() > 64)
-    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: more than 64 candidate offsets (distance <= 17)");
-  std::vector<int> room((size_t)d.N, -1), local((size_t)d.N, -1);
-  for (int z = 0; z < d.Z; ++z)
-    for (int i = h->h_zone_off[z]; i < h->h_zone_off[z + 1]; ++i) room[h->h_zone_cells[i]] = z;
-  std::vector<ConvCell> cells(h->h_zone_cells.size());
-  int max_room = 1;
-  for (int z = 0; z < d.Z; ++z) {
-    const int c0 = h->h_zone_off[z], n = h->h_zone_off[z + 1] - c0;
-    max_room = std::max(max_room, n);
-    std::vector<int> order(h->h_zone_cells.begin() + c0, h->h_zone_cells.begin() + c0 + n);
-    for (int g : order)
-      if (h->h_state_index[g] < 0) return fail(SB_ERR_INVALID, "sb_convection_attach: a zone cell lies in the exterior ring");
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return h->h_state_index[a] < h->h_state_index[b]; });
-    for (int i = 0; i < n; ++i) {
-      const int g = order[i], x = g / d.W, y = g % d.W;
-      local[g] = i;
-      ConvCell &c = cells[(size_t)c0 + i];
-      c.gh = g; c.g0 = transposed ? y * d.H + x : g; c.sidx = h->h_state_index[g]; c.pad = 0; c.mask = 0;
-      for (size_t k = 0; k < offd.size(); ++k) {
-        const int xx = x + odx[k], yy = y + ody[k];
-        if (xx >= 0 && xx < d.H && yy >= 0 && yy < d.W && room[xx * d.W + yy] == z) c.mask |= 1ull << k;
-      }
-    }
-  }
-  if (max_room > kConvMaxThreads * kConvMaxPerLane)
-    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: a room has more than 2048 cells");
-  for (DevBuf<int> *buf : {&h->conv_local, &h->conv_off}) {
-    if (buf->p) (void)hipFree(buf->p); // attached before: replace
-    buf->p = nullptr;
-  }
-  if (h->conv_cells.p) { (void)hipFree(h->conv_cells.p); h->conv_cells.p = nullptr; }
-  int rc;
-  if ((rc = upload(h->conv_local, local.data(), local.size())) != SB_OK) return rc;
-  if ((rc = upload(h->conv_off, offd.data(), offd.size())) != SB_OK) return rc;
-  if ((rc = upload(h->conv_cells, cells.data(), cells.size())) != SB_OK) return rc;
-  h->conv_p = p; h->conv_n_off = (int)offd.size(); h->conv_max_room = max_room;
-  h->conv_seed = seed; h->conv_first = first_building; h->conv_calls = 0;
-  h->conv_attached = true;
-  return SB_OK;
-}
-
-namespace {
-int launch_convection(sb_handle *h, hipStream_t stream) {
-  const Dev &d = h->d;
-  ConvArgs o;
-  o.temp = d.temp; o.stride = d.reg ? (size_t)d.state_doubles : (size_t)d.Np;
-  o.zone_off = h->zone_off.p; o.local = h->conv_local.p; o.off = h->conv_off.p; o.cells = h->conv_cells.p;
-  o.B = d.B; o.Z = d.Z; o.W = d.W; o.n_off = h->conv_n_off; o.max_room = h->conv_max_room;
-  o.p = h->conv_p; o.seed = h->conv_seed; o.first_building = h->conv_first; o.call = h->conv_calls++;
-  const size_t lds = (size_t)o.max_room * (8 + 8 + 3 * 4);
-  // workgroups of about 256 lanes measured best on R9's 600-cell rooms (5.4 ms per launch for 65,536
-  // buildings; 320 lanes x 2 cells: 7.4 ms); every resident workgroup gets the same number of buildings
-  int q = std::max(1, (o.max_room + 255) / 256);
-  if (q > kConvMaxPerLane) q = kConvMaxPerLane;
-  const int threads = ((o.max_room + q - 1) / q + 63) / 64 * 64;
-  const int per_cu = std::max(1, std::min(std::min(8, 2048 / threads), (int)(kLdsCap / ((lds + 1279) / 1280 * 1280))));
-  const int blocks = std::max(1, std::min(d.B, h->cus * per_cu));
-  switch (q) {
-    case 1: hipLaunchKernelGGL(k_convect<1>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 2: hipLaunchKernelGGL(k_convect<2>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 3: hipLaunchKernelGGL(k_convect<3>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 4: hipLaunchKernelGGL(k_convect<4>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 5: hipLaunchKernelGGL(k_convect<5>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 6: hipLaunchKernelGGL(k_convect<6>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 7: hipLaunchKernelGGL(k_convect<7>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    default: hipLaunchKernelGGL(k_convect<8>, dim3(blocks), dim3(threads), lds, stream, o); break;
-  }
-  SB_HIP(hipGetLastError());
-  return SB_OK;
-}
-} // namespace
-
 int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in, float *obs_dev,
                    float *reward_dev, float *info_dev, void *stream, int32_t phases) {
   if (!h || !in || !reward_dev) return fail(SB_ERR_INVALID, "sb_step: null argument");
@@ -1085,7 +720,7 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   }
   if (phases & SB_PHASE_POST) {
     if (h->conv_attached) { // simulator_flexible_floor_plan.py:156: after the FD update; the zone sums of
-      const int rc = launch_convection(h, (hipStream_t)stream); // k_post do not change (values move inside rooms)
+      const int rc = sb_launch_convection(h, (hipStream_t)stream); // k_post do not change (values move inside rooms)
       if (rc != SB_OK) return rc;
     }
     hipLaunchKernelGGL(k_post, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s);
