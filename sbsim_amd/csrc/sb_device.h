@@ -125,6 +125,7 @@ bool sweep_reg_supported(int NR, int P);     // is there an instantiation for th
 int sweep_reg_table_stride(int NR, int P);   // coefficient-table stride of the instantiation (classes + 1 <= stride)
 int sweep_reg_lds_slots(int NR, int P);      // slots of A the instantiation keeps in LDS (the rest: registers)
 int sweep_reg_waves_per_simd(int NR, int P); // register budget of the instantiation: wavefronts per SIMD
+bool sweep_reg_overlaps_sweeps(int NR, int P); // a sweep costs NR steps (lanes start the next sweep while others finish)
 
 // ---------------------------------------------------------------- wave helpers
 // DPP move of a double; lanes without a source (or outside row_mask) receive 0.

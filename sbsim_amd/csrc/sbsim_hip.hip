@@ -231,7 +231,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
     r.lw[0] = Hs; r.l0[0] = 0; r.rowbase[0] = 0;
     r.nch[0] = (NR + Hs - 1 + 7) / 8;
     r.lag = 0; r.nslots = r.nch[0];
-    r.steps = NR + Hs - 1;
+    r.steps = sweep_reg_overlaps_sweeps(NR, 1) ? NR : NR + Hs - 1;
   } else {
     int best = -1, best_slots = 1 << 30;
     for (int a0 = Hs - 64; a0 <= 64; ++a0) {
@@ -292,7 +292,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
         unsigned long long word = 0;
         for (int k = 0; k < 8; ++k) {
           int col = 8 * ch + k - lp;
-          if (P == 3 && col >= NR) col -= NR; // overlapped sweeps: the lane is in its next sweep
+          if (P != 2 && col >= NR) col -= NR; // overlapped sweeps: the lane is in its next sweep
           const int c = valid ? cell_class(R, col) : pad;
           word |= (unsigned long long)(c * cscale) << (8 * k); // stride 32: the byte offset into a table column
         }

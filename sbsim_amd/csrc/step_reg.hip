@@ -50,6 +50,20 @@ constexpr int waves_per_simd(int NR, int P) { return (P == kPair && NR <= 66) ? 
 #define SB_LOOK 2
 #endif
 constexpr int kLook = SB_LOOK; // steps between the LDS reads of a step and its arithmetic
+#ifndef SB_ROLL
+#define SB_ROLL 1
+#endif
+constexpr int kWin = 63; // overlapped sweeps: steps of a period in which the lanes are in two different sweeps
+// Which instantiations overlap consecutive sweeps (see "overlapped sweeps" below): the period (NR
+// steps) must hold the window and the read-ahead.  Only the tail-row mode, whose 64 lanes all own
+// a row: with 43 rows on one wavefront (mode 1) the 63 heavier window steps cost what the shorter
+// sweep saves (measured 2.78 vs 2.71 ms per step for 65,536 buildings of 45 x 96 cells).
+#ifndef SB_ROLL_MODE1
+#define SB_ROLL_MODE1 0
+#endif
+constexpr bool rolls(int NR, int P) {
+  return SB_ROLL != 0 && (P == 3 || (SB_ROLL_MODE1 != 0 && P == 1)) && NR > kWin + kLook;
+}
 // Coefficient-table stride: classes + the pad class <= stride.  The class maps hold
 // class * (256 / stride) in a byte; times stride / 32 that is the class's byte offset into a
 // table column (stride 32: the byte IS the offset, one SDWA add per step).
@@ -148,7 +162,9 @@ __device__ __forceinline__ void update(double (&e)[NR], const Co &o, int lp, uns
   else if (need_lo) act = lp > D - NR;
   else act = __builtin_amdgcn_inverse_ballot_w64(rowmask);
   // mode kTail: all 64 lanes own a row, so the middle steps need no select at all
-  const double sel = (P == kTail && !need_hi && !need_lo) ? nv : (act ? nv : e[r]);
+  // all 64 lanes own a row (mode kTail), or the schedule overlaps sweeps (lanes without a row work
+  // on a copy nobody stores; the caller drops their max |delta|): the middle steps need no select
+  const double sel = ((P == kTail || rolls(NR, P)) && !need_hi && !need_lo) ? nv : (act ? nv : e[r]);
   dmax = fmax(dmax, fabs(sel - e[r]));
   e[r] = sel;
 }
@@ -260,18 +276,13 @@ __device__ __forceinline__ double sweep_reg(double (&e)[NR], const double (&Areg
 // start of sweep k+1 is speculative; every step of the window first copies the value it
 // overwrites (bk[j]), and the last period restores lanes <= j from the copies.  Max |delta|
 // goes to the accumulator of the lane's own sweep (dcur: sweep k, dnext: sweep k+1).
-#ifndef SB_ROLL
-#define SB_ROLL 1
-#endif
-constexpr bool kRoll = SB_ROLL != 0;
-constexpr int kWin = 63; // steps of a period in which the lanes are in two different sweeps
 
-template <int NR, int J>
+template <int NR, int P, int J>
 __device__ __forceinline__ void update_mixed(double (&e)[NR], double (&bk)[kWin], const Co &o, int lp,
                                              double &dcur, double &dnext) {
   constexpr int r = J, rm = (J + NR - 1) % NR, rp = J + 1;
   const double U = wave_shift1<0x138, false>(e[rm], 0.0);
-  const double Dn = wave_shift1<0x130, true>(e[rp], o.smD);
+  const double Dn = wave_shift1<0x130, P == kTail>(e[rp], o.smD);
   double t = fma(o.bD, Dn, o.A);
   t = fma(o.bR, e[rp], t);
   t = fma(o.bL, e[rm], t);
@@ -292,17 +303,17 @@ __device__ __forceinline__ void update_mixed(double (&e)[NR], double (&bk)[kWin]
 
 // Steps D0 <= D < D1 of the overlapped schedule: D < 63 ramp-up of the first sweep (lanes > D
 // idle), 63 <= D < NR all lanes in one sweep, NR <= D < NR + 63 the mixed window.
-template <int NR, int D, int D1, int NAR>
+template <int NR, int P, int D, int D1, int NAR>
 __device__ __forceinline__ void roll_steps(double (&e)[NR], double (&bk)[kWin], const double (&Areg)[NAR],
                                            Pipe &p, const SweepCtx &x, double &dcur, double &dnext) {
   if constexpr (D < D1) {
     // uniform base + lane offset + immediate: one global_load, no 64-bit address arithmetic
     if constexpr (D % 8 == 0) p.cw[(D / 8 + 2) % 3] = x.cmapu[x.lane + (D / 8 + 2) * 64];
-    if constexpr (D + kLook < D1) prefetch<NR, kTail, D + kLook>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
-    if constexpr (D < NR) update<NR, kTail, D>(e, p.co[D % (kLook + 1)], x.lp, x.rowmask, dcur);
-    else update_mixed<NR, D - NR>(e, bk, p.co[D % (kLook + 1)], x.lp, dcur, dnext);
+    if constexpr (D + kLook < D1) prefetch<NR, P, D + kLook>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
+    if constexpr (D < NR) update<NR, P, D>(e, p.co[D % (kLook + 1)], x.lp, x.rowmask, dcur);
+    else update_mixed<NR, P, D - NR>(e, bk, p.co[D % (kLook + 1)], x.lp, dcur, dnext);
     __builtin_amdgcn_sched_barrier(0);
-    roll_steps<NR, D + 1, D1>(e, bk, Areg, p, x, dcur, dnext);
+    roll_steps<NR, P, D + 1, D1>(e, bk, Areg, p, x, dcur, dnext);
   }
 }
 
@@ -450,7 +461,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
   // live in AGPRs between their uses (the allocator spills what the sweep does not touch)
   // instead of costing a global round trip per building.  (The two-wavefront mode has no
   // registers to spare and reloads them.)
-  constexpr bool kReloadAmap = P == kPair || (P == kTail && kRoll); // no registers to spare
+  constexpr bool kReloadAmap = P == kPair || rolls(NR, P); // no registers to spare
   unsigned long long amapw[kASlots];
   if (!kReloadAmap) {
 #pragma unroll
@@ -502,7 +513,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       if (P == kPair && lane == 0) *draw_slot = bn;
     }
     SB_STAMP(0);
-    if (kReloadAmap && P == kTail) { // issued here, used by the A pass: the setup hides the latency
+    if (kReloadAmap && P != kPair) { // issued here, used by the A pass: the setup hides the latency
       const int o = opaque(0);
 #pragma unroll
       for (int g = 0; g < kASlots; ++g) amapw[g] = amap[o + g * 64];
@@ -548,7 +559,8 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
 
     // A = ap*Tprev + g for every cell of the lane's row (E = Tprev before the first sweep)
     double Areg[kNAR];
-    Areg[0] = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNAR; ++k) Areg[k] = 0.0; // lanes without a row keep finite values (0 * NaN would reach a real row)
     if (rowvalid) {
       if (kReloadAmap && P == kPair) {
         const int o = opaque(0);
@@ -591,8 +603,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
     SB_STAMP(2);
 
     int n_sweeps = 0, converged = 0;
-    if constexpr (P == kTail && kRoll) {
-      static_assert(P != kTail || NR > kWin + kLook, "the period must hold the mixed window");
+    if constexpr (rolls(NR, P)) {
       SweepCtx xr = x;
       asm volatile("" : "+v"(xr.lp)); // one v_cmp per step instead of hoisted, spilled masks
       Pipe pp;
@@ -603,7 +614,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       prefetch<NR, P, 0>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
       prefetch<NR, P, 1>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
       __builtin_amdgcn_sched_barrier(0);
-      roll_steps<NR, 0, kWin>(e, bk, Areg, pp, xr, dcur, dnext);
+      roll_steps<NR, P, 0, kWin>(e, bk, Areg, pp, xr, dcur, dnext);
       // class bytes of steps 56..79: loaded before the tail pass that precedes their use
       auto restart_classes = [&]() {
         pp.cw[(kWin / 8) % 3] = xr.cmapu[xr.lane + (kWin / 8) * 64];
@@ -619,14 +630,16 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
         prefetch<NR, P, kWin>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
         prefetch<NR, P, kWin + 1>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
         __builtin_amdgcn_sched_barrier(0);
-        roll_steps<NR, kWin, NR + kWin>(e, bk, Areg, pp, xr, dcur, dnext);
+        roll_steps<NR, P, kWin, NR + kWin>(e, bk, Areg, pp, xr, dcur, dnext);
         if (xr.edge) { // row 63 is still in sweep k: its new values for the tail scan
 #pragma unroll
           for (int c = 0; c < NR; ++c) xr.seam_out[c + 63] = e[(c + 63) % NR];
         }
         restart_classes();
         __builtin_amdgcn_wave_barrier();
-        double md = wave_max(fmax(dcur, tail_pass<NR>(a.T, lane, tab, tE, r63, At, tclsw)));
+        double dm = rowvalid ? dcur : 0.0; // lanes without a row ran on a copy
+        if constexpr (P == kTail) dm = fmax(dm, tail_pass<NR>(a.T, lane, tab, tE, r63, At, tclsw));
+        double md = wave_max(dm);
         if (n_sweeps == 0) md = fmax(md, ring_d);
         ++n_sweeps;
         converged = md <= p.conv_threshold;
@@ -780,6 +793,7 @@ bool sweep_reg_supported(int NR, int P) { return find_variant(NR, P) != nullptr;
 int sweep_reg_table_stride(int NR, int P) { return table_stride(NR, P); }
 int sweep_reg_lds_slots(int NR, int P) { return lds_slots(NR, P); }
 int sweep_reg_waves_per_simd(int NR, int P) { return waves_per_simd(NR, P); }
+bool sweep_reg_overlaps_sweeps(int NR, int P) { return rolls(NR, P); }
 
 int prepare_sweep_reg(const Dev &d) {
   const Variant *v = find_variant(d.NR, d.P);

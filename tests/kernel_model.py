@@ -360,7 +360,7 @@ class RegSweepModel:
     ring_d = max(abs(t_amb - ring.min()), abs(t_amb - ring.max())) if ring.size else 0.0
     n = 0
     if schedule == "rolling":
-      assert self.mode == 3
+      assert self.mode in (1, 3) and NR > 63 + K_LOOK
       n = self._fd_rolling(es[0], tail, As[0], At, tcls, ring_d, thr, iter_limit)
       iter_limit = 0
     for it in range(iter_limit):
@@ -388,7 +388,7 @@ class RegSweepModel:
     return out, n
 
   def _fd_rolling(self, e, tail, A, At, tcls, ring_d, thr, iter_limit):
-    """Mode 3 with overlapped sweeps: period NR steps, lane l works on column (s - l) mod NR at
+    """Modes 1 and 3 with overlapped sweeps: period NR steps, lane l works on column (s - l) mod NR at
     global step s, so lanes 0..j start sweep k+1 during steps j = 0..62 of the period while
     lanes j+1..63 finish sweep k.  The stopping decision for sweep k falls after step 62 (and
     the tail pass); the speculative updates of sweep k+1 are undone from per-step backups."""
@@ -403,7 +403,7 @@ class RegSweepModel:
       U = np.empty(64); U[1:] = e[:-1, rm]; U[0] = 0.0
       Dn = np.empty(64); Dn[:-1] = e[1:, rp]
       tc = col[63]
-      Dn[63] = tail[0, tc] if 0 <= tc < NR else 0.0
+      Dn[63] = tail[0, tc] if (self.T and 0 <= tc < NR) else 0.0
       nv = co[:, 1] * Dn + A[:, r]
       nv = co[:, 3] * e[:, rp] + nv
       nv = co[:, 2] * e[:, rm] + nv
@@ -415,6 +415,7 @@ class RegSweepModel:
       e[:, r] = sel
       return d, old
 
+    valid = lane < self.lw[0]               # mode 1: lanes without a row run on a copy nobody stores
     dcur = np.zeros(64)
     for D in range(63):                       # ramp-up of sweep 0
       d, _ = step(D, True)
@@ -432,7 +433,9 @@ class RegSweepModel:
         dcur = np.maximum(dcur, np.where(lane > j, d, 0.0))
         dnext = np.maximum(dnext, np.where(lane <= j, d, 0.0))
       row63 = e[63, (np.arange(NR) + 63) % NR].copy()
-      md = max(float(dcur.max()), self._tail_pass(tail, At, tcls, row63))
+      md = float(dcur[valid].max())
+      if self.T:
+        md = max(md, self._tail_pass(tail, At, tcls, row63))
       if n == 0:
         md = max(md, ring_d)
       n += 1

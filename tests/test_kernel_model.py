@@ -59,6 +59,7 @@ def _r9_like(rooms, room_shape):
     ((2, 3), (30, 30), False, 3, "tight"),    # one tail row
     ((3, 3), (20, 30), False, 3, "rolling"),  # R9 with overlapped sweeps (speculative start + undo)
     ((2, 3), (30, 30), False, 3, "rolling"),
+    ((2, 3), (20, 30), False, 1, "rolling"),  # 43 x 94 on 96 slots: the schedule also holds with idle lanes (kernel: SB_ROLL_MODE1)
     ((3, 3), (20, 30), True, 2, "tight"),     # R9, lanes = columns: two wavefronts, wave 1 as early as allowed
     ((3, 3), (20, 30), True, 2, "late"),      # ... and as late as possible: same grid
     ((2, 5), (30, 12), True, 2, "tight"),     # uneven split
