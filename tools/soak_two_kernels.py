@@ -2,7 +2,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from sbsim_amd.environment import BatchedEnvironment, SimConfig
 from bench import r9_plan
-B, T = 4096, 900
+B, T = int(os.environ.get("B", 4096)), int(os.environ.get("T", 900))
 plan = r9_plan()
 envs = []
 for force in (False, True):
