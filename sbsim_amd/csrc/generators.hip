@@ -92,24 +92,38 @@ struct ConvArgs {
   uint32_t call;
 };
 
-constexpr int kConvMaxThreads = 512, kConvMaxPerLane = 8; // rooms up to 4,096 cells
+constexpr int kConvMaxThreads = 512, kConvMaxPerLane = 8;
+constexpr int kConvMaxRoom = 2047; // a cell's index in its room fits 11 bits next to the 20-bit grid index
 
-// Q: cells per lane; the workgroup has ceil(largest room / Q) lanes rounded up to a wavefront
+// A cell's own swap in LDS, one 16-byte read per visit: the random key of its time stamp; the
+// cell's grid index (ties, low 20 bits) and the other cell of the swap (bits 20..30; itself: no
+// swap); the next swap that chose the same cell as this one (list link, 0xffff: end).
+struct __attribute__((aligned(16))) ConvRec {
+  uint32_t key, tie_other, nxt, pad;
+};
+
+// Q: cells per lane; the workgroup has ceil(largest room / Q) lanes rounded up to a wavefront.
+// Room-major: the lane keeps its cells' table entries in registers while the workgroup walks
+// through its share of the buildings.
 template <int Q>
 __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
   const int kConvThreads = blockDim.x;
-  extern __shared__ unsigned long long conv_lds[];
-  unsigned long long *T = conv_lds;            // [max_room] time stamp of the cell's own swap
-  double *vout = (double *)(T + o.max_room);   // [max_room] the value that ends in this cell
-  int *part = (int *)(vout + o.max_room);      // [max_room] other cell of the cell's own swap (itself: none)
-  int *head = part + o.max_room;               // [max_room] first swap that chose this cell
-  int *nxt = head + o.max_room;                // [max_room] next swap that chose the same cell
+  extern __shared__ __attribute__((aligned(16))) unsigned long long conv_lds[];
+  ConvRec *rec = (ConvRec *)conv_lds;            // [max_room]
+  double *vout = (double *)(rec + o.max_room);   // [max_room] the value that ends in this cell
+  int *head = (int *)(vout + o.max_room);        // [max_room] first swap that chose this cell (-1: none)
   const int tid = threadIdx.x;
-  for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
-    double *st = o.temp + (size_t)b * o.stride;
-    const unsigned long long gb = (unsigned long long)(o.first_building + b);
-    for (int z = 0; z < o.Z; ++z) {
-      const int c0 = o.zone_off[z], n = o.zone_off[z + 1] - c0;
+  for (int z = 0; z < o.Z; ++z) {
+    const int c0 = o.zone_off[z], n = o.zone_off[z + 1] - c0;
+    ConvCell cc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = tid + q * kConvThreads;
+      cc[q] = o.cells[c0 + (i < n ? i : 0)];
+    }
+    for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
+      double *st = o.temp + (size_t)b * o.stride;
+      const unsigned long long gb = (unsigned long long)(o.first_building + b);
       for (int i = tid; i < n; i += kConvThreads) head[i] = -1;
       __syncthreads();
       double val[Q];
@@ -117,23 +131,25 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
         if (i < n) {
-          const ConvCell cc = o.cells[c0 + i];
-          val[q] = st[cc.sidx];
-          uint32_t c[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc.g0};
+          val[q] = st[cc[q].sidx];
+          uint32_t c[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc[q].g0};
           philox4x32_10(c, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
           const double u = (double)(c[0] >> 8) * (1.0 / 16777216.0);
           int other = i;
           if (!(u > o.p)) { // :119
-            const int cnt = __popcll(cc.mask);
+            const int cnt = __popcll(cc[q].mask);
             int pick = (int)(((unsigned long long)c[1] * (unsigned long long)cnt) >> 32); // uniform in [0, cnt)
-            unsigned long long m = cc.mask;
+            unsigned long long m = cc[q].mask;
             for (; pick > 0; --pick) m &= m - 1; // drop the lowest set bits
             const int k = __ffsll((long long)m) - 1;
-            other = o.local[cc.gh + o.off[k]]; // off[k]: offset k as a step in the handle's grid
+            other = o.local[cc[q].gh + o.off[k]]; // off[k]: offset k as a step in the handle's grid
           }
-          part[i] = other;
-          T[i] = (((unsigned long long)c[2] << 20) | (unsigned long long)cc.g0) + 1ull; // ties: raster order of the caller's grid
-          if (other != i) nxt[i] = atomicExch(&head[other], i);
+          ConvRec r;
+          r.key = c[2];
+          r.tie_other = (uint32_t)cc[q].g0 | ((uint32_t)other << 20);
+          r.nxt = other != i ? (uint32_t)atomicExch(&head[other], i) & 0xffffu : 0xffffu;
+          r.pad = 0;
+          rec[i] = r;
         }
       }
       __syncthreads();
@@ -142,13 +158,21 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
         const int i = tid + q * kConvThreads;
         if (i < n) {
           int pos = i;
-          unsigned long long t = 0;
+          unsigned long long t = 0; // time stamps: (key << 20 | grid index) + 1, ties in raster order of the caller's grid
           for (;;) {
+            const ConvRec own = rec[pos];
+            int j = head[pos];
             unsigned long long best = ~0ull;
             int to = -1;
-            if (part[pos] != pos && T[pos] > t) { best = T[pos]; to = part[pos]; }
-            for (int j = head[pos]; j >= 0; j = nxt[j])
-              if (T[j] > t && T[j] < best) { best = T[j]; to = j; }
+            const int own_other = (int)(own.tie_other >> 20);
+            const unsigned long long own_t = (((unsigned long long)own.key << 20) | (own.tie_other & 0xfffffu)) + 1ull;
+            if (own_other != pos && own_t > t) { best = own_t; to = own_other; }
+            while (j >= 0) { // the swaps that chose this cell
+              const ConvRec rj = rec[j];
+              const unsigned long long tj = (((unsigned long long)rj.key << 20) | (rj.tie_other & 0xfffffu)) + 1ull;
+              if (tj > t && tj < best) { best = tj; to = j; }
+              j = rj.nxt == 0xffffu ? -1 : (int)rj.nxt;
+            }
             if (to < 0) break;
             t = best;
             pos = to;
@@ -157,12 +181,15 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
         }
       }
       __syncthreads();
-      for (int i = tid; i < n; i += kConvThreads) st[o.cells[c0 + i].sidx] = vout[i];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int i = tid + q * kConvThreads;
+        if (i < n) st[cc[q].sidx] = vout[i];
+      }
       __syncthreads();
     }
   }
 }
-
 
 } // namespace
 
@@ -259,8 +286,8 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
       }
     }
   }
-  if (max_room > kConvMaxThreads * kConvMaxPerLane)
-    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: a room has more than 2048 cells");
+  if (max_room > kConvMaxRoom)
+    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: a room has more than 2047 cells");
   for (DevBuf<int> *buf : {&h->conv_local, &h->conv_off}) {
     if (buf->p) (void)hipFree(buf->p); // attached before: replace
     buf->p = nullptr;
@@ -285,24 +312,33 @@ int sb_launch_convection(sb_handle *h, hipStream_t stream) {
   o.zone_off = h->zone_off.p; o.local = h->conv_local.p; o.off = h->conv_off.p; o.cells = h->conv_cells.p;
   o.B = d.B; o.Z = d.Z; o.W = d.W; o.n_off = h->conv_n_off; o.max_room = h->conv_max_room;
   o.p = h->conv_p; o.seed = h->conv_seed; o.first_building = h->conv_first; o.call = h->conv_calls++;
-  const size_t lds = (size_t)o.max_room * (8 + 8 + 3 * 4);
-  // workgroups of about 256 lanes measured best on R9's 600-cell rooms (5.4 ms per launch for 65,536
-  // buildings; 320 lanes x 2 cells: 7.4 ms); every resident workgroup gets the same number of buildings
+  const size_t lds = (size_t)o.max_room * (16 + 8 + 4);
+  // cells per lane: workgroups of about 256 lanes; the grid is exactly what is resident at once
+  // (the runtime's occupancy for this instantiation), so that every workgroup gets the same number
+  // of buildings and there is no second round
   int q = std::max(1, (o.max_room + 255) / 256);
   if (q > kConvMaxPerLane) q = kConvMaxPerLane;
   const int threads = ((o.max_room + q - 1) / q + 63) / 64 * 64;
-  const int per_cu = std::max(1, std::min(std::min(8, 2048 / threads), (int)(kLdsCap / ((lds + 1279) / 1280 * 1280))));
-  const int blocks = std::max(1, std::min(d.B, h->cus * per_cu));
+  if (threads > kConvMaxThreads) return fail(SB_ERR_UNSUPPORTED, "convection: room too large for one workgroup");
+  auto go = [&](auto kernel) -> int {
+    int per_cu = 0;
+    SB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
+    const int blocks = std::max(1, std::min(d.B, h->cus * std::max(per_cu, 1)));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, stream, o);
+    return SB_OK;
+  };
+  int rc;
   switch (q) {
-    case 1: hipLaunchKernelGGL(k_convect<1>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 2: hipLaunchKernelGGL(k_convect<2>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 3: hipLaunchKernelGGL(k_convect<3>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 4: hipLaunchKernelGGL(k_convect<4>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 5: hipLaunchKernelGGL(k_convect<5>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 6: hipLaunchKernelGGL(k_convect<6>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    case 7: hipLaunchKernelGGL(k_convect<7>, dim3(blocks), dim3(threads), lds, stream, o); break;
-    default: hipLaunchKernelGGL(k_convect<8>, dim3(blocks), dim3(threads), lds, stream, o); break;
+    case 1: rc = go(k_convect<1>); break;
+    case 2: rc = go(k_convect<2>); break;
+    case 3: rc = go(k_convect<3>); break;
+    case 4: rc = go(k_convect<4>); break;
+    case 5: rc = go(k_convect<5>); break;
+    case 6: rc = go(k_convect<6>); break;
+    case 7: rc = go(k_convect<7>); break;
+    default: rc = go(k_convect<8>); break;
   }
+  if (rc != SB_OK) return rc;
   SB_HIP(hipGetLastError());
   return SB_OK;
 }
