@@ -53,6 +53,9 @@ constexpr int kLook = SB_LOOK; // steps between the LDS reads of a step and its 
 #ifndef SB_ROLL
 #define SB_ROLL 1
 #endif
+#ifndef SB_SURE
+#define SB_SURE 0
+#endif
 constexpr int kWin = 63; // overlapped sweeps: steps of a period in which the lanes are in two different sweeps
 // Which instantiations overlap consecutive sweeps (see "overlapped sweeps" below): the period (NR
 // steps) must hold the window and the read-ahead.  Only the tail-row mode, whose 64 lanes all own
@@ -277,7 +280,10 @@ __device__ __forceinline__ double sweep_reg(double (&e)[NR], const double (&Areg
 // overwrites (bk[j]), and the last period restores lanes <= j from the copies.  Max |delta|
 // goes to the accumulator of the lane's own sweep (dcur: sweep k, dnext: sweep k+1).
 
-template <int NR, int P, int J>
+// SURE: the sweep the upper lanes are finishing is known not to be the last one (some |delta| of
+// it already exceeds the threshold and the iteration limit is not reached), so the start of the
+// next sweep is not speculative: no copy, and the finishing lanes' |delta| need not be tracked.
+template <int NR, int P, int J, bool SURE>
 __device__ __forceinline__ void update_mixed(double (&e)[NR], double (&bk)[kWin], const Co &o, int lp,
                                              double &dcur, double &dnext) {
   constexpr int r = J, rm = (J + NR - 1) % NR, rp = J + 1;
@@ -288,14 +294,14 @@ __device__ __forceinline__ void update_mixed(double (&e)[NR], double (&bk)[kWin]
   t = fma(o.bL, e[rm], t);
   const double nv = fma(o.bU, U, t);
   const double d = nv - e[r];
-  bk[J] = e[r];
+  if (!SURE) bk[J] = e[r];
   e[r] = nv;
   // |d| into one accumulator, (almost) zero into the other: only the high word is switched,
   // the low word alone is a subnormal < 5e-314
   const bool nw = lanes_upto<J>(lp);
   const int hi = __double2hiint(d), lo = __double2loint(d);
   dnext = fmax(dnext, fabs(__hiloint2double(nw ? hi : 0, lo)));
-  dcur = fmax(dcur, fabs(__hiloint2double(nw ? 0 : hi, lo)));
+  if (!SURE) dcur = fmax(dcur, fabs(__hiloint2double(nw ? 0 : hi, lo)));
   // here, not after the window: e[J] and bk[J] both survive the window, so the compiler would
   // sink all of this behind it and keep 63 lane masks alive (spilled SGPRs)
   asm volatile("" : "+v"(dcur), "+v"(dnext));
@@ -303,17 +309,18 @@ __device__ __forceinline__ void update_mixed(double (&e)[NR], double (&bk)[kWin]
 
 // Steps D0 <= D < D1 of the overlapped schedule: D < 63 ramp-up of the first sweep (lanes > D
 // idle), 63 <= D < NR all lanes in one sweep, NR <= D < NR + 63 the mixed window.
-template <int NR, int P, int D, int D1, int NAR>
+template <int NR, int P, int D, int D1, bool SURE = false, int DP = D1, int NAR>
 __device__ __forceinline__ void roll_steps(double (&e)[NR], double (&bk)[kWin], const double (&Areg)[NAR],
                                            Pipe &p, const SweepCtx &x, double &dcur, double &dnext) {
+  // DP: where the read-ahead ends (a range may be executed in two pieces)
   if constexpr (D < D1) {
     // uniform base + lane offset + immediate: one global_load, no 64-bit address arithmetic
     if constexpr (D % 8 == 0) p.cw[(D / 8 + 2) % 3] = x.cmapu[x.lane + (D / 8 + 2) * 64];
-    if constexpr (D + kLook < D1) prefetch<NR, P, D + kLook>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
+    if constexpr (D + kLook < DP) prefetch<NR, P, D + kLook>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
     if constexpr (D < NR) update<NR, P, D>(e, p.co[D % (kLook + 1)], x.lp, x.rowmask, dcur);
-    else update_mixed<NR, P, D - NR>(e, bk, p.co[D % (kLook + 1)], x.lp, dcur, dnext);
+    else update_mixed<NR, P, D - NR, SURE>(e, bk, p.co[D % (kLook + 1)], x.lp, dcur, dnext);
     __builtin_amdgcn_sched_barrier(0);
-    roll_steps<NR, P, D + 1, D1>(e, bk, Areg, p, x, dcur, dnext);
+    roll_steps<NR, P, D + 1, D1, SURE, DP>(e, bk, Areg, p, x, dcur, dnext);
   }
 }
 
@@ -630,7 +637,27 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
         prefetch<NR, P, kWin>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
         prefetch<NR, P, kWin + 1>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
         __builtin_amdgcn_sched_barrier(0);
-        roll_steps<NR, P, kWin, NR + kWin>(e, bk, Areg, pp, xr, dcur, dnext);
+        roll_steps<NR, P, kWin, NR, false, NR + kWin>(e, bk, Areg, pp, xr, dcur, dnext);
+        // Is this sweep certainly not the last one?  (Some |delta| so far -- its first steps of the
+        // previous window, the all-lanes steps -- exceeds the threshold, and the limit allows
+        // another sweep.)  Then the window runs without copies and without the finishing lanes'
+        // |delta|: the common case on all but a step's last sweep.
+        const bool over = (rowvalid && dcur > p.conv_threshold) || (n_sweeps == 0 && ring_d > p.conv_threshold);
+        if (SB_SURE && __builtin_amdgcn_ballot_w64(over) != 0 && n_sweeps + 1 < p.iter_limit) {
+          roll_steps<NR, P, NR, NR + kWin, true>(e, bk, Areg, pp, xr, dcur, dnext);
+          if (xr.edge) {
+#pragma unroll
+            for (int c = 0; c < NR; ++c) xr.seam_out[c + 63] = e[(c + 63) % NR];
+          }
+          restart_classes();
+          __builtin_amdgcn_wave_barrier();
+          if constexpr (P == kTail) (void)tail_pass<NR>(a.T, lane, tab, tE, r63, At, tclsw);
+          ++n_sweeps;
+          dcur = dnext;
+          dnext = 0.0;
+          continue;
+        }
+        roll_steps<NR, P, NR, NR + kWin>(e, bk, Areg, pp, xr, dcur, dnext);
         if (xr.edge) { // row 63 is still in sweep k: its new values for the tail scan
 #pragma unroll
           for (int c = 0; c < NR; ++c) xr.seam_out[c + 63] = e[(c + 63) % NR];
