@@ -15,7 +15,7 @@ import ctypes as C
 import dataclasses
 import os
 import subprocess
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -124,6 +124,17 @@ def lib():
                            C.POINTER(_StepIn), C.POINTER(_StepOut)]
     L.sbo_boiler_dissipation.restype = C.c_double
     L.sbo_boiler_dissipation.argtypes = [C.POINTER(_Params), C.c_double, C.c_double]
+    d = C.c_double
+    for name, args in (("sbo_dev_ahu_mixed", [d, d, d]), ("sbo_dev_ahu_supply", [d, d, d]),
+                       ("sbo_dev_ahu_blower_power", [C.POINTER(_Params), d]),
+                       ("sbo_dev_ahu_thermal_rate", [d, d, d]), ("sbo_dev_vav_supply_temp", [d, d, d, d]),
+                       ("sbo_dev_vav_energy", [d, d, d]),
+                       ("sbo_dev_boiler_gas_rate", [C.POINTER(_Params), d, d, d, d, d, d]),
+                       ("sbo_dev_boiler_pump_power", [C.POINTER(_Params), d])):
+      getattr(L, name).restype = d
+      getattr(L, name).argtypes = args
+    L.sbo_dev_thermostat.restype = C.c_int32
+    L.sbo_dev_thermostat.argtypes = [C.c_int32, d, d, d, C.c_int32, C.c_int32, _dp, _dp]
     L.sbo_reward.restype = C.c_double
     L.sbo_reward.argtypes = [C.POINTER(_Params), C.c_int32, _fp, _fp, _fp, _fp, C.c_float,
                              C.c_float, C.c_float, C.c_float, C.c_double, C.c_double,
@@ -289,6 +300,23 @@ def reward(params: OracleParams, zone_temp, heat_sp, cool_sp, occ, blower, ac, g
                        np.float32(blower), np.float32(ac), np.float32(gas), np.float32(pump),
                        dt, e_price, e_carbon, g_price, g_carbon, _d(diag))
   return r, diag
+
+
+def device(name: str, *args, params: Optional[OracleParams] = None) -> float:
+  """One of the device formulas sbo_step is made of (sb_oracle.h: sbo_dev_*)."""
+  fn = getattr(lib(), "sbo_dev_" + name)
+  if params is not None:
+    pc = params.to_c()
+    return fn(C.byref(pc), *args)
+  return fn(*args)
+
+
+def thermostat(mode: int, tz: float, window: Tuple[float, float], comfort_now: bool, comfort_prev: int):
+  """thermostat.py:114-148 + vav.py:229-243 -> (mode, damper, reheat valve); comfort_prev -1 = none."""
+  damper, valve = np.zeros(1), np.zeros(1)
+  mode = lib().sbo_dev_thermostat(mode, tz, window[0], window[1], int(comfort_now), int(comfort_prev),
+                                  _d(damper), _d(valve))
+  return mode, float(damper[0]), float(valve[0])
 
 
 def boiler_dissipation(params: OracleParams, water_temp: float, outside_temp: float) -> float:

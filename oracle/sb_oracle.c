@@ -185,6 +185,25 @@ static int32_t default_control(int32_t mode, double tz, double hsp, double csp) 
   return 0;
 }
 
+/* thermostat.py:114-148 update() + vav.py:229-243 (mode -> damper, reheat valve).  comfort_prev:
+ * is_comfort_mode(previous timestamp), -1 = no previous timestamp.  Modes: 0 OFF, 1 HEAT, 2 COOL,
+ * 3 PASSIVE_COOL. */
+int32_t sbo_dev_thermostat(int32_t mode, double tz, double hsp, double csp, int32_t comfort_now,
+                           int32_t comfort_prev, double *damper, double *valve) {
+  if (comfort_now) {
+    mode = default_control(mode, tz, hsp, csp);
+  } else if (comfort_prev > 0) {
+    mode = 3;
+  } else {
+    if (mode == 3 && tz > hsp) mode = 3;
+    else mode = default_control(mode, tz, hsp, csp);
+  }
+  if (mode == 1) { *damper = 1.0; *valve = 1.0; }
+  else if (mode == 2) { *damper = 1.0; *valve = 0.0; }
+  else { *damper = 0.1; *valve = 0.0; }
+  return mode;
+}
+
 /* simulator.py:383-396 setup_step_sim -> vav.py:219-243 -> thermostat.py:114-148 */
 void sbo_setup_step(const sbo_plan *p, const sbo_params *prm, sbo_state *s,
                     int32_t comfort_now, int32_t comfort_prev) {
@@ -194,32 +213,41 @@ void sbo_setup_step(const sbo_plan *p, const sbo_params *prm, sbo_state *s,
   for (int z = 0; z < p->Z; z++) {
     double tz = zone_mean(p, s->temp, z, buf);
     s->zone_air_temp[z] = tz;
-    int32_t mode = s->mode[z];
-    if (comfort_now) {
-      mode = default_control(mode, tz, hsp, csp);
-    } else if (s->thermostat_has_prev && comfort_prev) {
-      mode = 3;
-    } else {
-      if (mode == 3 && tz > hsp) mode = 3;
-      else mode = default_control(mode, tz, hsp, csp);
-    }
-    s->mode[z] = mode;
-    if (mode == 1) { s->damper[z] = 1.0; s->valve[z] = 1.0; }
-    else if (mode == 2) { s->damper[z] = 1.0; s->valve[z] = 0.0; }
-    else { s->damper[z] = 0.1; s->valve[z] = 0.0; }
+    s->mode[z] = sbo_dev_thermostat(s->mode[z], tz, hsp, csp, comfort_now,
+                                    s->thermostat_has_prev ? comfort_prev : -1, &s->damper[z], &s->valve[z]);
   }
   s->thermostat_has_prev = 1;
 }
 
 /* air_handler.py:204-233 */
-static double ahu_mixed(double r, double recirc, double amb) {
+double sbo_dev_ahu_mixed(double r, double recirc, double amb) {
   return r * recirc + (1 - r) * amb;
 }
-static double ahu_supply(const sbo_state *s, double mixed) {
-  if (mixed > s->ahu_cool_sp) return s->ahu_cool_sp;
-  if (mixed < s->ahu_heat_sp) return s->ahu_heat_sp;
+double sbo_dev_ahu_supply(double heat_sp, double cool_sp, double mixed) {
+  if (mixed > cool_sp) return cool_sp;
+  if (mixed < heat_sp) return heat_sp;
   return mixed;
 }
+static double ahu_mixed(double r, double recirc, double amb) { return sbo_dev_ahu_mixed(r, recirc, amb); }
+static double ahu_supply(const sbo_state *s, double mixed) {
+  return sbo_dev_ahu_supply(s->ahu_heat_sp, s->ahu_cool_sp, mixed);
+}
+/* air_handler.py:287-320 intake + exhaust fan power; :270-285 thermal energy rate */
+double sbo_dev_ahu_blower_power(const sbo_params *prm, double air_flow) {
+  double intake = air_flow * prm->ahu_dp / prm->ahu_eff;
+  double exhaust = (air_flow * (1.0 - prm->ahu_recirc)) * prm->ahu_dp / prm->ahu_eff;
+  return intake + exhaust;
+}
+double sbo_dev_ahu_thermal_rate(double air_flow, double supply, double mixed) {
+  return air_flow * C_AIR * (supply - mixed);
+}
+/* vav.py:168-195 compute_zone_supply_temp, :197-217 compute_energy_applied_to_zone */
+double sbo_dev_vav_supply_temp(double t_sa, double tw, double air_flow, double reheat_flow) {
+  double heat_diff = C_AIR * air_flow - C_WATER * reheat_flow;
+  double water_heat = tw * C_WATER * reheat_flow;
+  return (t_sa * heat_diff + water_heat) / air_flow / C_AIR;
+}
+double sbo_dev_vav_energy(double air_flow, double t_zs, double tz) { return air_flow * C_AIR * (t_zs - tz); }
 
 /* boiler.py:275-320 compute_thermal_dissipation_rate */
 double sbo_boiler_dissipation(const sbo_params *prm, double water_temp, double outside_temp) {
@@ -230,6 +258,20 @@ double sbo_boiler_dissipation(const sbo_params *prm, double water_temp, double o
   double cond = log(r2 / r1) / prm->blr_ins_k;
   double conv = 1.0 / prm->blr_conv / r2;
   return num / (cond + conv);
+}
+
+/* boiler.py:233-273 compute_thermal_energy_rate (+ the tank term of :158-217), :322-333 pump */
+double sbo_dev_boiler_gas_rate(const sbo_params *prm, double setpoint, double total_flow, double return_temp,
+                               double outside_temp, double tank_change, double last_duration) {
+  double supply_w = setpoint > return_temp ? setpoint : return_temp;
+  double flow_heat = C_WATER * total_flow * (supply_w - return_temp);
+  double diss = sbo_boiler_dissipation(prm, supply_w, outside_temp);
+  double tank = 0;
+  if (last_duration > 0) tank = C_WATER * prm->blr_capacity * tank_change / last_duration;
+  return flow_heat + diss + tank;
+}
+double sbo_dev_boiler_pump_power(const sbo_params *prm, double total_flow) {
+  return total_flow * RHO_WATER * GRAVITY * prm->blr_head / prm->blr_pump_eff;
 }
 
 /* boiler.py:146-217: reading supply_water_temperature_sensor at obs_ts advances the tank
@@ -364,12 +406,10 @@ void sbo_step(const sbo_plan *p, const sbo_params *prm, sbo_state *s, const sbo_
     double tw = s->blr_setpoint;
     double reheat_flow = valve * prm->vav_max_water_flow;
     double air_flow = damper * prm->vav_max_air_flow;
-    double heat_diff = C_AIR * air_flow - C_WATER * reheat_flow;
-    double water_heat = tw * C_WATER * reheat_flow;
-    double t_zs = (t_sa * heat_diff + water_heat) / air_flow / C_AIR;
+    double t_zs = sbo_dev_vav_supply_temp(t_sa, tw, air_flow, reheat_flow);
     double qz;
     if (damper == 0 || prm->vav_max_air_flow == 0) qz = 0;
-    else qz = air_flow * C_AIR * (t_zs - tz_pre[z]);
+    else qz = sbo_dev_vav_energy(air_flow, t_zs, tz_pre[z]);
     tzs[z] = t_zs;
     if (air_flow > 0) { /* air_handler.py:254-268 */
       s->ahu_flow += air_flow;
@@ -411,23 +451,14 @@ void sbo_step(const sbo_plan *p, const sbo_params *prm, sbo_state *s, const sbo_
     oc32[z] = (float)in->occupancy[z];
   }
   /* air_handler.py:287-320 fan powers */
-  double intake = s->ahu_flow * prm->ahu_dp / prm->ahu_eff;
-  double exhaust = (s->ahu_flow * (1.0 - prm->ahu_recirc)) * prm->ahu_dp / prm->ahu_eff;
-  double blower = intake + exhaust;
+  double blower = sbo_dev_ahu_blower_power(prm, s->ahu_flow);
   double recirc2 = sbo_np_mean(s->temp, N);
   double mixed2 = ahu_mixed(prm->ahu_recirc, recirc2, in->t_amb_next);
   double supply2 = ahu_supply(s, mixed2);
-  double ac = s->ahu_flow * C_AIR * (supply2 - mixed2); /* air_handler.py:270-285 */
-  /* boiler.py:233-273 */
-  double ret = s->blr_return_temp;
-  double supply_w = s->blr_setpoint > ret ? s->blr_setpoint : ret;
-  double flow_heat = C_WATER * s->blr_flow * (supply_w - ret);
-  double diss = sbo_boiler_dissipation(prm, supply_w, in->t_amb_next);
-  double tank = 0;
-  if (s->blr_last_duration > 0)
-    tank = C_WATER * prm->blr_capacity * s->blr_tank_change / s->blr_last_duration;
-  double gas = flow_heat + diss + tank;
-  double pump = s->blr_flow * RHO_WATER * GRAVITY * prm->blr_head / prm->blr_pump_eff; /* :322-333 */
+  double ac = sbo_dev_ahu_thermal_rate(s->ahu_flow, supply2, mixed2);
+  double gas = sbo_dev_boiler_gas_rate(prm, s->blr_setpoint, s->blr_flow, s->blr_return_temp, in->t_amb_next,
+                                       s->blr_tank_change, s->blr_last_duration);
+  double pump = sbo_dev_boiler_pump_power(prm, s->blr_flow);
 
   out->n_sweeps = n_sweeps;
   out->converged = conv;

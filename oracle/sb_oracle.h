@@ -125,6 +125,19 @@ void sbo_setup_step(const sbo_plan *p, const sbo_params *prm, sbo_state *s,
 void sbo_step(const sbo_plan *p, const sbo_params *prm, sbo_state *s, const sbo_step_in *in,
               sbo_step_out *out);
 double sbo_boiler_dissipation(const sbo_params *prm, double water_temp, double outside_temp);
+/* The device formulas sbo_step is made of, callable on their own: the reference's device tests
+ * (boiler_test.py, air_handler_test.py, vav_test.py) pin them (tests/test_device_kats.py). */
+int32_t sbo_dev_thermostat(int32_t mode, double tz, double hsp, double csp, int32_t comfort_now,
+                           int32_t comfort_prev, double *damper, double *valve);
+double sbo_dev_ahu_mixed(double r, double recirc, double amb);
+double sbo_dev_ahu_supply(double heat_sp, double cool_sp, double mixed);
+double sbo_dev_ahu_blower_power(const sbo_params *prm, double air_flow);
+double sbo_dev_ahu_thermal_rate(double air_flow, double supply, double mixed);
+double sbo_dev_vav_supply_temp(double t_sa, double tw, double air_flow, double reheat_flow);
+double sbo_dev_vav_energy(double air_flow, double t_zs, double tz);
+double sbo_dev_boiler_gas_rate(const sbo_params *prm, double setpoint, double total_flow, double return_temp,
+                               double outside_temp, double tank_change, double last_duration);
+double sbo_dev_boiler_pump_power(const sbo_params *prm, double total_flow);
 double sbo_reward(const sbo_params *prm, int32_t Z, const float *zone_temp, const float *heat_sp,
                   const float *cool_sp, const float *occ, float blower, float ac, float gas,
                   float pump, double dt, double e_price, double e_carbon, double g_price,
