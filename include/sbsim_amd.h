@@ -283,6 +283,17 @@ int64_t sb_pb_observation_response(sb_pb_time ts, int32_t n, const char *const *
 int64_t sb_pb_action_response(sb_pb_time ts, sb_pb_time request_ts, int32_t n, const char *const *device_ids,
                               const char *const *setpoint_names, const float *values,
                               const int32_t *response_types, uint8_t *out, int64_t cap);
+/* DeviceInfo / ZoneInfo records of ProtoWriter.write_device_infos / write_zone_infos
+ * (utils/controller_writer.py:149-171): field maps as parallel (name, DeviceInfo.ValueType) arrays. */
+int64_t sb_pb_device_info(const char *device_id, const char *name_space, const char *code, const char *zone_id,
+                          int32_t device_type, int32_t n_observable, const char *const *observable_names,
+                          const int32_t *observable_types, int32_t n_action, const char *const *action_names,
+                          const int32_t *action_types, uint8_t *out, int64_t cap);
+int64_t sb_pb_zone_info(const char *zone_id, const char *building_id, const char *zone_description, float area,
+                        int32_t n_devices, const char *const *devices, int32_t zone_type, int32_t floor,
+                        uint8_t *out, int64_t cap);
+/* One <4-byte LE size><msg> record appended to `path` (truncate != 0: the file starts over). */
+int sb_record_append(const char *path, const uint8_t *msg, int64_t n, int32_t truncate);
 /* ProtoWriter._write_msg_to_disk: append <4-byte LE size><msg> to <dir>/<prefix>_YYYY.MM.DD.HH
  * (the hour of unix_seconds, read as UTC). */
 int sb_shard_append(const char *dir, const char *prefix, int64_t unix_seconds, const uint8_t *msg, int64_t n);

@@ -118,6 +118,23 @@ def main() -> None:
     out[f"action_response_{k}"] = np.frombuffer(aresp.SerializeToString(deterministic=True), dtype=np.uint8)
     writer.write_action_response(aresp, t)
 
+  # device / zone infos
+  dev = bpb.DeviceInfo(device_id="vav_room_1", namespace="sim", code="VAV-1", zone_id="room_1",
+                       device_type=bpb.DeviceInfo.DeviceType.VAV)
+  for n in ("zone_air_temperature_sensor", "supply_air_damper_percentage_command", "supply_air_flowrate_setpoint"):
+    dev.observable_fields[n] = bpb.DeviceInfo.ValueType.VALUE_CONTINUOUS
+  dev.action_fields["supply_air_damper_percentage_command"] = bpb.DeviceInfo.ValueType.VALUE_CONTINUOUS
+  blr = bpb.DeviceInfo(device_id="boiler_id", device_type=bpb.DeviceInfo.DeviceType.BLR)
+  blr.action_fields["supply_water_setpoint"] = bpb.DeviceInfo.ValueType.VALUE_CONTINUOUS
+  zone = bpb.ZoneInfo(zone_id="room_1", building_id="US-SIM-001", zone_description="Simulated zone", area=62.5,
+                      devices=["vav_room_1", "sensor_1"], zone_type=bpb.ZoneInfo.ZoneType.ROOM, floor=2)
+  zone0 = bpb.ZoneInfo(zone_id="room_2", devices=["vav_room_2"])
+  out["device_info_0"] = np.frombuffer(dev.SerializeToString(deterministic=True), dtype=np.uint8)
+  out["device_info_1"] = np.frombuffer(blr.SerializeToString(deterministic=True), dtype=np.uint8)
+  out["zone_info_0"] = np.frombuffer(zone.SerializeToString(deterministic=True), dtype=np.uint8)
+  out["zone_info_1"] = np.frombuffer(zone0.SerializeToString(deterministic=True), dtype=np.uint8)
+  writer.write_zone_infos([zone, zone0])
+
   files = sorted(os.listdir(tmp))
   out["shard_names"] = np.array(files)
   for f in files:

@@ -94,7 +94,8 @@ EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_d
            "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_convection_attach", "sb_step", "sb_step_phases", "sb_get_temps", "sb_get_zone_temps",
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles",
            "sb_floorplan_padded_shape", "sb_floorplan_preprocess", "sb_pb_reward_info", "sb_pb_reward_response",
-           "sb_pb_observation_response", "sb_pb_action_response", "sb_shard_append")
+           "sb_pb_observation_response", "sb_pb_action_response", "sb_shard_append", "sb_pb_device_info",
+           "sb_pb_zone_info", "sb_record_append")
 
 _lib = None
 
@@ -143,6 +144,13 @@ def load():
   for name in ("sb_pb_reward_info", "sb_pb_reward_response", "sb_pb_observation_response", "sb_pb_action_response"):
     getattr(L, name).restype = C.c_int64
   L.sb_shard_append.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, vp, C.c_int64]
+  ip_ = C.POINTER(C.c_int32)
+  L.sb_pb_device_info.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, cpp, ip_,
+                                  C.c_int32, cpp, ip_, vp, C.c_int64]
+  L.sb_pb_zone_info.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_float, C.c_int32, cpp, C.c_int32, C.c_int32,
+                                vp, C.c_int64]
+  L.sb_pb_device_info.restype = L.sb_pb_zone_info.restype = C.c_int64
+  L.sb_record_append.argtypes = [C.c_char_p, vp, C.c_int64, C.c_int32]
   L.sb_floorplan_padded_shape.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
   L.sb_floorplan_preprocess.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
   _lib = L

@@ -164,6 +164,63 @@ int64_t sb_pb_action_response(sb_pb_time ts, sb_pb_time request_ts, int32_t n, c
   return emit(m, out, cap);
 }
 
+// DeviceInfo / ZoneInfo (proto/smart_control_building.proto): what ProtoWriter.write_device_infos /
+// write_zone_infos put, record by record, into the files "device_info" / "zone_info".
+int64_t sb_pb_device_info(const char *device_id, const char *name_space, const char *code, const char *zone_id,
+                          int32_t device_type, int32_t n_observable, const char *const *observable_names,
+                          const int32_t *observable_types, int32_t n_action, const char *const *action_names,
+                          const int32_t *action_types, uint8_t *out, int64_t cap) {
+  if (n_observable < 0 || n_action < 0 || (n_observable && (!observable_names || !observable_types)) ||
+      (n_action && (!action_names || !action_types)))
+    return SB_ERR_INVALID;
+  Buf m;
+  f_str(m, 1, device_id);
+  f_str(m, 2, name_space);
+  f_str(m, 3, code);
+  f_str(m, 4, zone_id);
+  f_varint(m, 5, device_type);
+  auto fields = [&](int field, int n, const char *const *names, const int32_t *types) { // map<string, ValueType>
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int c) { return std::strcmp(names[a], names[c]) < 0; });
+    for (int i : order) {
+      Buf e;
+      f_str(e, 1, names[i], true);
+      f_varint(e, 2, types[i], true);
+      f_msg(m, field, e);
+    }
+  };
+  fields(6, n_observable, observable_names, observable_types);
+  fields(7, n_action, action_names, action_types);
+  return emit(m, out, cap);
+}
+
+int64_t sb_pb_zone_info(const char *zone_id, const char *building_id, const char *zone_description, float area,
+                        int32_t n_devices, const char *const *devices, int32_t zone_type, int32_t floor,
+                        uint8_t *out, int64_t cap) {
+  if (n_devices < 0 || (n_devices && !devices)) return SB_ERR_INVALID;
+  Buf m;
+  f_str(m, 1, zone_id);
+  f_str(m, 2, building_id);
+  f_str(m, 3, zone_description);
+  f_float(m, 4, area);
+  for (int i = 0; i < n_devices; ++i) f_str(m, 5, devices[i], true); // repeated: every element is written
+  f_varint(m, 6, zone_type);
+  f_varint(m, 7, floor);
+  return emit(m, out, cap);
+}
+
+// One length-prefixed record appended to (or, with truncate, starting) the file `path`.
+int sb_record_append(const char *path, const uint8_t *msg, int64_t n, int32_t truncate) {
+  if (!path || (!msg && n) || n < 0 || n > 0x7fffffffLL) return SB_ERR_INVALID;
+  FILE *f = std::fopen(path, truncate ? "wb" : "ab");
+  if (!f) return SB_ERR_INVALID;
+  const uint32_t size = (uint32_t)n;
+  unsigned char le[4] = {(unsigned char)size, (unsigned char)(size >> 8), (unsigned char)(size >> 16), (unsigned char)(size >> 24)};
+  const bool ok = std::fwrite(le, 1, 4, f) == 4 && (n == 0 || std::fwrite(msg, 1, (size_t)n, f) == (size_t)n);
+  return (std::fclose(f) == 0 && ok) ? SB_OK : SB_ERR_INVALID;
+}
+
 // ProtoWriter._write_msg_to_disk (controller_writer.py:118-131): append size (4 bytes, little
 // endian) + message to <dir>/<prefix>_YYYY.MM.DD.HH of the timestamp's hour (its own clock:
 // the caller passes the seconds of the timestamp as strftime would see it).

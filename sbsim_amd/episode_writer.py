@@ -114,6 +114,53 @@ class EpisodeWriter:
     self._append(REWARD_RESPONSE_PREFIX, timestamp, reward_response)
 
 
+# DeviceInfo.DeviceType / ValueType, ZoneInfo.ZoneType (proto/smart_control_building.proto)
+DEVICE_TYPES = dict(UNDEFINED=0, FAN=1, PMP=2, FCU=3, VAV=4, DH=5, AHU=6, BLR=7, OTHER=23)
+VALUE_CONTINUOUS, ZONE_TYPE_ROOM = 1, 1
+DEVICE_INFO_PREFIX, ZONE_INFO_PREFIX = "device_info", "zone_info"   # utils/constants.py:57-58
+
+
+def _ints(a):
+  arr = np.ascontiguousarray(a, dtype=np.int32)
+  return arr, arr.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def encode_device_info(device_id: str, namespace: str, code: str, zone_id: str, device_type: int,
+                       observable_fields: Mapping[str, int], action_fields: Mapping[str, int]) -> bytes:
+  lib = _ffi.load()
+  on, an = list(observable_fields), list(action_fields)
+  ot, otp = _ints([observable_fields[k] for k in on] or [0])
+  at, atp = _ints([action_fields[k] for k in an] or [0])
+  args = (device_id.encode(), namespace.encode(), code.encode(), zone_id.encode(), int(device_type), len(on),
+          _strs(on), otp, len(an), _strs(an), atp)
+  need = lib.sb_pb_device_info(*args, None, 0)
+  if need < 0:
+    raise _ffi.SbsimError(f"sb_pb_device_info failed ({need})")
+  buf = (C.c_uint8 * max(need, 1))()
+  lib.sb_pb_device_info(*args, C.cast(buf, C.c_void_p), need)
+  return bytes(buf[:need])
+
+
+def encode_zone_info(zone_id: str, building_id: str, zone_description: str, area: float, devices: Sequence[str],
+                     zone_type: int = ZONE_TYPE_ROOM, floor: int = 0) -> bytes:
+  lib = _ffi.load()
+  args = (zone_id.encode(), building_id.encode(), zone_description.encode(), float(area), len(devices),
+          _strs(list(devices)), int(zone_type), int(floor))
+  need = lib.sb_pb_zone_info(*args, None, 0)
+  if need < 0:
+    raise _ffi.SbsimError(f"sb_pb_zone_info failed ({need})")
+  buf = (C.c_uint8 * max(need, 1))()
+  lib.sb_pb_zone_info(*args, C.cast(buf, C.c_void_p), need)
+  return bytes(buf[:need])
+
+
+def write_records(path: str, records: Sequence[bytes]) -> None:
+  """write_device_infos / write_zone_infos (controller_writer.py:149-171): the file starts over."""
+  lib = _ffi.load()
+  for i, r in enumerate(records):
+    _ffi.check(lib.sb_record_append(path.encode(), r, len(r), int(i == 0)), "sb_record_append")
+
+
 def read_shard(path: str):
   """The records of one shard file (utils/controller_reader.py: 4-byte size, message)."""
   out = []
