@@ -53,9 +53,6 @@ constexpr int kLook = SB_LOOK; // steps between the LDS reads of a step and its 
 #ifndef SB_ROLL
 #define SB_ROLL 1
 #endif
-#ifndef SB_SURE
-#define SB_SURE 0
-#endif
 constexpr int kWin = 63; // overlapped sweeps: steps of a period in which the lanes are in two different sweeps
 // Which instantiations overlap consecutive sweeps (see "overlapped sweeps" below): the period (NR
 // steps) must hold the window and the read-ahead.  Only the tail-row mode, whose 64 lanes all own
@@ -88,17 +85,11 @@ __device__ __forceinline__ int opaque_s(int v) { // the same for a wave-uniform 
 // Lanes 0..J as a lane predicate without a VALU compare: the mask is built by one SALU
 // instruction where it is used (a compare per step costs a VALU slot plus wait states before
 // the select; masks computed once per kernel would be ~130 SGPR pairs, i.e. spilled).
-#ifndef SB_BFM
-#define SB_BFM 1
-#endif
 template <int J>
-__device__ __forceinline__ bool lanes_upto(int lp) {
-  if (SB_BFM) {
-    unsigned long long m;
-    asm volatile("s_bfm_b64 %0, %1, 0" : "=s"(m) : "n"(J + 1));
-    return __builtin_amdgcn_inverse_ballot_w64(m);
-  }
-  return (unsigned)lp <= (unsigned)J;
+__device__ __forceinline__ bool lanes_upto(int) {
+  unsigned long long m;
+  asm volatile("s_bfm_b64 %0, %1, 0" : "=s"(m) : "n"(J + 1));
+  return __builtin_amdgcn_inverse_ballot_w64(m);
 }
 
 struct Co { double bU, bD, bL, bR, A, smU, smD; };
@@ -280,10 +271,7 @@ __device__ __forceinline__ double sweep_reg(double (&e)[NR], const double (&Areg
 // overwrites (bk[j]), and the last period restores lanes <= j from the copies.  Max |delta|
 // goes to the accumulator of the lane's own sweep (dcur: sweep k, dnext: sweep k+1).
 
-// SURE: the sweep the upper lanes are finishing is known not to be the last one (some |delta| of
-// it already exceeds the threshold and the iteration limit is not reached), so the start of the
-// next sweep is not speculative: no copy, and the finishing lanes' |delta| need not be tracked.
-template <int NR, int P, int J, bool SURE>
+template <int NR, int P, int J>
 __device__ __forceinline__ void update_mixed(double (&e)[NR], double (&bk)[kWin], const Co &o, int lp,
                                              double &dcur, double &dnext) {
   constexpr int r = J, rm = (J + NR - 1) % NR, rp = J + 1;
@@ -294,14 +282,14 @@ __device__ __forceinline__ void update_mixed(double (&e)[NR], double (&bk)[kWin]
   t = fma(o.bL, e[rm], t);
   const double nv = fma(o.bU, U, t);
   const double d = nv - e[r];
-  if (!SURE) bk[J] = e[r];
+  bk[J] = e[r];
   e[r] = nv;
   // |d| into one accumulator, (almost) zero into the other: only the high word is switched,
   // the low word alone is a subnormal < 5e-314
   const bool nw = lanes_upto<J>(lp);
   const int hi = __double2hiint(d), lo = __double2loint(d);
   dnext = fmax(dnext, fabs(__hiloint2double(nw ? hi : 0, lo)));
-  if (!SURE) dcur = fmax(dcur, fabs(__hiloint2double(nw ? 0 : hi, lo)));
+  dcur = fmax(dcur, fabs(__hiloint2double(nw ? 0 : hi, lo)));
   // here, not after the window: e[J] and bk[J] both survive the window, so the compiler would
   // sink all of this behind it and keep 63 lane masks alive (spilled SGPRs)
   asm volatile("" : "+v"(dcur), "+v"(dnext));
@@ -309,18 +297,17 @@ __device__ __forceinline__ void update_mixed(double (&e)[NR], double (&bk)[kWin]
 
 // Steps D0 <= D < D1 of the overlapped schedule: D < 63 ramp-up of the first sweep (lanes > D
 // idle), 63 <= D < NR all lanes in one sweep, NR <= D < NR + 63 the mixed window.
-template <int NR, int P, int D, int D1, bool SURE = false, int DP = D1, int NAR>
+template <int NR, int P, int D, int D1, int NAR>
 __device__ __forceinline__ void roll_steps(double (&e)[NR], double (&bk)[kWin], const double (&Areg)[NAR],
                                            Pipe &p, const SweepCtx &x, double &dcur, double &dnext) {
-  // DP: where the read-ahead ends (a range may be executed in two pieces)
   if constexpr (D < D1) {
     // uniform base + lane offset + immediate: one global_load, no 64-bit address arithmetic
     if constexpr (D % 8 == 0) p.cw[(D / 8 + 2) % 3] = x.cmapu[x.lane + (D / 8 + 2) * 64];
-    if constexpr (D + kLook < DP) prefetch<NR, P, D + kLook>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
+    if constexpr (D + kLook < D1) prefetch<NR, P, D + kLook>(p, x.tab, x.Arow, Areg, x.seam_in, x.seam_in2);
     if constexpr (D < NR) update<NR, P, D>(e, p.co[D % (kLook + 1)], x.lp, x.rowmask, dcur);
-    else update_mixed<NR, P, D - NR, SURE>(e, bk, p.co[D % (kLook + 1)], x.lp, dcur, dnext);
+    else update_mixed<NR, P, D - NR>(e, bk, p.co[D % (kLook + 1)], x.lp, dcur, dnext);
     __builtin_amdgcn_sched_barrier(0);
-    roll_steps<NR, P, D + 1, D1, SURE, DP>(e, bk, Areg, p, x, dcur, dnext);
+    roll_steps<NR, P, D + 1, D1>(e, bk, Areg, p, x, dcur, dnext);
   }
 }
 
@@ -637,27 +624,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
         prefetch<NR, P, kWin>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
         prefetch<NR, P, kWin + 1>(pp, xr.tab, xr.Arow, Areg, xr.seam_in, xr.seam_in2);
         __builtin_amdgcn_sched_barrier(0);
-        roll_steps<NR, P, kWin, NR, false, NR + kWin>(e, bk, Areg, pp, xr, dcur, dnext);
-        // Is this sweep certainly not the last one?  (Some |delta| so far -- its first steps of the
-        // previous window, the all-lanes steps -- exceeds the threshold, and the limit allows
-        // another sweep.)  Then the window runs without copies and without the finishing lanes'
-        // |delta|: the common case on all but a step's last sweep.
-        const bool over = (rowvalid && dcur > p.conv_threshold) || (n_sweeps == 0 && ring_d > p.conv_threshold);
-        if (SB_SURE && __builtin_amdgcn_ballot_w64(over) != 0 && n_sweeps + 1 < p.iter_limit) {
-          roll_steps<NR, P, NR, NR + kWin, true>(e, bk, Areg, pp, xr, dcur, dnext);
-          if (xr.edge) {
-#pragma unroll
-            for (int c = 0; c < NR; ++c) xr.seam_out[c + 63] = e[(c + 63) % NR];
-          }
-          restart_classes();
-          __builtin_amdgcn_wave_barrier();
-          if constexpr (P == kTail) (void)tail_pass<NR>(a.T, lane, tab, tE, r63, At, tclsw);
-          ++n_sweeps;
-          dcur = dnext;
-          dnext = 0.0;
-          continue;
-        }
-        roll_steps<NR, P, NR, NR + kWin>(e, bk, Areg, pp, xr, dcur, dnext);
+        roll_steps<NR, P, kWin, NR + kWin>(e, bk, Areg, pp, xr, dcur, dnext);
         if (xr.edge) { // row 63 is still in sweep k: its new values for the tail scan
 #pragma unroll
           for (int c = 0; c < NR; ++c) xr.seam_out[c + 63] = e[(c + 63) % NR];
@@ -718,10 +685,7 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
       // one 8-byte store per register straight from e[]: a wider store would have to be
       // assembled in a temporary that the next store overwrites (measured 6x slower)
       double *tp = a.temp + (size_t)b * a.state_doubles;
-#ifndef SB_EPI
-#define SB_EPI 2
-#endif
-      constexpr bool kFuse = SB_EPI >= 1 && P == kTail; // store, zone add (and next load) slot by slot
+      constexpr bool kFuse = P == kTail; // store, zone add and the next building's load slot by slot
       if (!kFuse) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
@@ -746,14 +710,14 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
         if (kFuse) { tp[R] = e[j]; tp += RS; }
         __hip_atomic_fetch_add((double *)((char *)zs + off), e[j], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (kFuse && SB_EPI >= 2) { e[j] = np_[R]; np_ += RS; }
+        if (kFuse) { e[j] = np_[R]; np_ += RS; }
         if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(5);
     if (bn < a.B) {
-      if (!(SB_EPI >= 2 && P == kTail)) SB_LOAD_ROW(bn);
+      if (P != kTail) SB_LOAD_ROW(bn);
       SB_LOAD_AUX(bn);
     }
     __builtin_amdgcn_sched_barrier(0);
