@@ -553,8 +553,11 @@ __global__ void __launch_bounds__(P == kPair ? 128 : 64)
 
     // A = ap*Tprev + g for every cell of the lane's row (E = Tprev before the first sweep)
     double Areg[kNAR];
+    Areg[0] = 0.0;
+    if (P != kTail) { // lanes without a row keep finite values (0 * NaN would reach a real row)
 #pragma unroll
-    for (int k = 0; k < kNAR; ++k) Areg[k] = 0.0; // lanes without a row keep finite values (0 * NaN would reach a real row)
+      for (int k = 0; k < kNAR; ++k) Areg[k] = 0.0;
+    }
     if (rowvalid) {
       if (kReloadAmap && P == kPair) {
         const int o = opaque(0);
