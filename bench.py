@@ -64,13 +64,14 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
       eco_lo=c.eco_temp_window[0], eco_hi=c.eco_temp_window[1],
       blr_heating_rate=c.boiler_heating_rate, blr_cooling_rate=c.boiler_cooling_rate, ahu_has_weather=1)
   threads = max(1, min(orc.lib().sbo_max_threads(), os.cpu_count() or 1))
-  nb = min(init.shape[0], max(8, 4 * threads))
+  nb = min(init.shape[0], max(8, 16 * threads))   # >= 16 buildings per thread and step: ms of work between barriers
   batch = orc.OracleBatch(oplan, oprm, init[:nb])
   lo, hi = c.action_ranges
   ts = env._start_timestamp
   step = dt.timedelta(seconds=c.time_step_sec)
   prev = None
   n_steps, t_cpu, sweeps, step_times = 0, 0.0, 0, []
+  single_times, n_now = [], threads   # after the all-cores sample: two steps of the same rollout on ONE thread
   max_steps = acts.shape[0]
   while n_steps < max_steps:
     env._prev_thermostat_ts = prev
@@ -87,20 +88,27 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
           e_price=si.e_price, e_carbon=si.e_carbon, g_price=si.g_price, g_carbon=si.g_carbon,
           action=native))
     t0 = time.perf_counter()
-    outs = batch.step(ins, n_threads=threads)
+    outs = batch.step(ins, n_threads=n_now)
     n_steps += 1
     prev, ts = ts, ts + step
     if n_steps <= warmup:
+      continue
+    if n_now == 1:
+      single_times.append(time.perf_counter() - t0)
+      if len(single_times) >= 2:
+        break
       continue
     step_times.append(time.perf_counter() - t0)
     t_cpu += step_times[-1]
     sweeps += sum(outs[b].n_sweeps for b in range(nb))
     # bounded sample: all of the timed steps unless the host is so busy that it would take long
     if (t_cpu * threads >= target_cpu_seconds and len(step_times) >= 12) or t_cpu > 20.0:
-      break
+      if threads == 1 or n_steps + 2 > max_steps:
+        break
+      n_now = 1
   env._prev_thermostat_ts = None
   zones = oplan.Z
-  n_timed = n_steps - warmup
+  n_timed = len(step_times)
   # median step time: a sub-second sample on a shared 128-thread host is noisy in the mean
   value = nb * zones / float(np.median(step_times))
   grids = np.stack([b.grid() for b in batch.buildings])
@@ -108,7 +116,8 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
               sample=f"{nb} buildings x {n_timed} steps of the bench workload after {warmup} untimed "
                      f"warm-up steps ({sweeps / (nb * n_timed):.2f} sweeps/step), oracle/sb_oracle.c "
                      f"with OpenMP over buildings, {t_cpu:.2f} s wall x {threads} threads; rate from the median step",
-              env_steps_per_s=nb / float(np.median(step_times))), grids, n_steps, nb
+              env_steps_per_s=nb / float(np.median(step_times)),
+              single_thread_value=(nb * zones / float(min(single_times)) if single_times else None)), grids, n_steps, nb
 
 
 def main() -> None:
@@ -241,7 +250,7 @@ def main() -> None:
       result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
       result["roofline"]["traffic_source"] = t.get("source")
     if world == 1 and not args.no_cpu_baseline:
-      nb_s = 512
+      nb_s = 2048
       acts_cpu = actions[:, :nb_s].cpu().numpy()
       base, grids, n_s, nb = cpu_baseline(env, plan, np.broadcast_to(t_init[:nb_s, None], (nb_s, H * Wd)).copy(),
                                           acts_cpu, W)
