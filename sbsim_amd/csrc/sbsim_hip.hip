@@ -128,6 +128,7 @@ __global__ void k_copy_scalars(Dev a, double *out) {
 
 // Per-building algebra before / after the sweep kernel: one thread per building (sb_device.h).
 __global__ void __launch_bounds__(64) k_pre(Dev a, StepArgs s) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_b = 0; // the sweep kernel's draw counter
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
     pre_building(a, s, b);
 }
@@ -711,7 +712,8 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
     SB_HIP(hipGetLastError());
   }
   if (phases & SB_PHASE_SWEEP) {
-    SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream)); // the sweep kernel's draw counter
+    if (!(phases & SB_PHASE_PRE)) // k_pre zeroes the sweep kernel's draw counter; without it in this call:
+      SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream));
     const int e = d.reg ? launch_sweep_reg(d, h->cus, (hipStream_t)stream)
                         : launch_sweep_lds(d, h->info.workgroups, h->info.waves_per_workgroup,
                                            (size_t)h->info.lds_bytes_per_workgroup, (hipStream_t)stream);
