@@ -526,6 +526,10 @@ class BatchedEnvironment:
     if self._occ_total is not None:   # per building, on the device: overrides aux[6]
       t5 = ts - dt.timedelta(minutes=5)
       self.sim.occupancy_peek(self.occupancy.local(t5).hour, self.occupancy.is_work_day(t5), None, self._occ_total)
+    elif isinstance(self.occupancy, host_inputs.StepFunctionOccupancy):
+      v = self.occupancy.average_zone_occupancy("", ts - dt.timedelta(minutes=5), ts)   # stateless, the same for
+      for _ in range(self.sim.Z):                                                        # every zone: one query,
+        n_occ += v                                                                       # the reference's sum
     else:
       for z in range(self.sim.Z):
         n_occ += self.occupancy.average_zone_occupancy(self.sim.zone_names[z], ts - dt.timedelta(minutes=5), ts)

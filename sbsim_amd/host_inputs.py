@@ -279,7 +279,9 @@ def is_work_day(ts, holiday_calendar: Optional[Iterable[dt.date]] = "us") -> boo
   if holiday_calendar is None:
     return True
   if holiday_calendar == "us":
-    cal = _HOLIDAY_CACHE.setdefault(ts.year, us_federal_holidays(ts.year))
+    cal = _HOLIDAY_CACHE.get(ts.year)
+    if cal is None:   # (setdefault would rebuild the year's calendar on every call)
+      cal = _HOLIDAY_CACHE[ts.year] = us_federal_holidays(ts.year)
   else:
     cal = holiday_calendar
   return ts.date() not in cal
