@@ -15,7 +15,9 @@
 // moves + 4 fp64 FMAs in the association order of step_lds.hip (bit-identical iterates).
 //
 // One or two rows beyond the 64th (R9 has 66) are finished after the wavefront's pass by a
-// scan along the row (mode 3, tail_pass below).  Otherwise floor plans with more than 64
+// scan along the row (mode 3, tail_pass below).  In that mode consecutive sweeps overlap: lanes
+// start sweep k+1 while the others finish sweep k ("overlapped sweeps" below), so a sweep costs
+// NR steps instead of NR + 63.  Otherwise floor plans with more than 64
 // rows use two wavefronts per building (mode 2): wave 0 owns the
 // upper rows (in its TOP lanes, so that its seam row is lane 63), wave 1 the lower rows
 // (seam row = lane 0).  The two seam rows are exchanged through LDS once per 8-step chunk;
