@@ -52,7 +52,9 @@ def _fptr(a: np.ndarray):
 class EpisodeWriter:
 
   def __init__(self, output_dir: str):
+    import os
     self._dir = str(output_dir)
+    os.makedirs(self._dir, exist_ok=True)   # controller_writer.py:50
     self._lib = _ffi.load()
 
   # ---- encoders (serialized bytes) ----

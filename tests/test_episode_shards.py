@@ -47,7 +47,9 @@ def test_encoders_reproduce_the_reference_serialization(tmp_path):
 
 
 def test_wire_format_corner_cases(tmp_path):
-  w = EpisodeWriter(str(tmp_path))
+  w = EpisodeWriter(str(tmp_path / "made" / "on" / "demand"))     # ProtoWriter.__init__: os.makedirs
+  w.write_reward_info(b"\x01\x02", dt.datetime(2024, 2, 29, 23, 59, tzinfo=UTC))
+  assert read_shard(str(tmp_path / "made" / "on" / "demand" / "reward_info_2024.02.29.23")) == [b"\x01\x02"]
   t = dt.datetime(1970, 1, 1, tzinfo=UTC)
   # all defaults: only the two (empty) timestamp submessages remain
   assert w.encode_reward_response(np.zeros(17), t, t) == bytes([0x92, 0x01, 0x00, 0x9a, 0x01, 0x00])
