@@ -292,6 +292,11 @@ int64_t sb_pb_device_info(const char *device_id, const char *name_space, const c
 int64_t sb_pb_zone_info(const char *zone_id, const char *building_id, const char *zone_description, float area,
                         int32_t n_devices, const char *const *devices, int32_t zone_type, int32_t floor,
                         uint8_t *out, int64_t cap);
+/* ContinuousVariableInfo records of ProtoWriter.write_normalization_info (file
+ * "normalization_info"; proto/smart_control_normalization.proto).  stats = sample variance, mean,
+ * median, maximum, minimum; has_start / has_end == 0 leave the timestamp unset. */
+int64_t sb_pb_variable_info(const char *id, int32_t has_start, sb_pb_time start, int32_t has_end, sb_pb_time end,
+                            int32_t sample_size, const float stats[5], uint8_t *out, int64_t cap);
 /* One <4-byte LE size><msg> record appended to `path` (truncate != 0: the file starts over). */
 int sb_record_append(const char *path, const uint8_t *msg, int64_t n, int32_t truncate);
 /* ProtoWriter._write_msg_to_disk: append <4-byte LE size><msg> to <dir>/<prefix>_YYYY.MM.DD.HH

@@ -135,6 +135,16 @@ def main() -> None:
   out["zone_info_1"] = np.frombuffer(zone0.SerializeToString(deterministic=True), dtype=np.uint8)
   writer.write_zone_infos([zone, zone0])
 
+  npb = refshim.ref("proto.smart_control_normalization_pb2")
+  v0 = npb.ContinuousVariableInfo(id="zone_air_temperature_sensor", sample_size=1000, sample_variance=4.0,
+                                  sample_mean=294.0, sample_median=293.5, sample_maximum=305.25, sample_minimum=285.0)
+  v0.sample_start.CopyFrom(conv.pandas_to_proto_timestamp(times[0]))
+  v0.sample_end.CopyFrom(conv.pandas_to_proto_timestamp(times[2]))
+  v1 = npb.ContinuousVariableInfo(id="supply_air_flowrate_sensor", sample_variance=0.25, sample_mean=0.5)
+  out["variable_info_0"] = np.frombuffer(v0.SerializeToString(deterministic=True), dtype=np.uint8)
+  out["variable_info_1"] = np.frombuffer(v1.SerializeToString(deterministic=True), dtype=np.uint8)
+  writer.write_normalization_info({"a": v0, "b": v1})
+
   files = sorted(os.listdir(tmp))
   out["shard_names"] = np.array(files)
   for f in files:

@@ -95,7 +95,7 @@ EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_d
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles",
            "sb_floorplan_padded_shape", "sb_floorplan_preprocess", "sb_pb_reward_info", "sb_pb_reward_response",
            "sb_pb_observation_response", "sb_pb_action_response", "sb_shard_append", "sb_pb_device_info",
-           "sb_pb_zone_info", "sb_record_append")
+           "sb_pb_zone_info", "sb_pb_variable_info", "sb_record_append")
 
 _lib = None
 
@@ -151,6 +151,8 @@ def load():
                                 vp, C.c_int64]
   L.sb_pb_device_info.restype = L.sb_pb_zone_info.restype = C.c_int64
   L.sb_record_append.argtypes = [C.c_char_p, vp, C.c_int64, C.c_int32]
+  L.sb_pb_variable_info.argtypes = [C.c_char_p, C.c_int32, PbTime, C.c_int32, PbTime, C.c_int32, fp_, vp, C.c_int64]
+  L.sb_pb_variable_info.restype = C.c_int64
   L.sb_floorplan_padded_shape.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
   L.sb_floorplan_preprocess.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
   _lib = L

@@ -210,6 +210,21 @@ int64_t sb_pb_zone_info(const char *zone_id, const char *building_id, const char
   return emit(m, out, cap);
 }
 
+// ContinuousVariableInfo (proto/smart_control_normalization.proto): the records of
+// ProtoWriter.write_normalization_info (file "normalization_info").  stats: variance, mean,
+// median, maximum, minimum.  A timestamp with has_* == 0 is left unset.
+int64_t sb_pb_variable_info(const char *id, int32_t has_start, sb_pb_time start, int32_t has_end, sb_pb_time end,
+                            int32_t sample_size, const float stats[5], uint8_t *out, int64_t cap) {
+  if (!stats) return SB_ERR_INVALID;
+  Buf m;
+  f_str(m, 1, id);
+  if (has_start) f_msg(m, 2, timestamp(start));
+  if (has_end) f_msg(m, 3, timestamp(end));
+  f_varint(m, 4, sample_size);
+  for (int k = 0; k < 5; ++k) f_float(m, 5 + k, stats[k]);
+  return emit(m, out, cap);
+}
+
 // One length-prefixed record appended to (or, with truncate, starting) the file `path`.
 int sb_record_append(const char *path, const uint8_t *msg, int64_t n, int32_t truncate) {
   if (!path || (!msg && n) || n < 0 || n > 0x7fffffffLL) return SB_ERR_INVALID;

@@ -156,6 +156,26 @@ def encode_zone_info(zone_id: str, building_id: str, zone_description: str, area
   return bytes(buf[:need])
 
 
+NORMALIZATION_FILENAME = "normalization_info"   # utils/constants.py:50
+
+
+def encode_variable_info(variable_id: str, sample_size: int, variance: float, mean: float, median: float = 0.0,
+                         maximum: float = 0.0, minimum: float = 0.0, sample_start=None, sample_end=None) -> bytes:
+  """ContinuousVariableInfo (write_normalization_info, controller_writer.py:134-147)."""
+  lib = _ffi.load()
+  stats = _floats([variance, mean, median, maximum, minimum])
+  t0 = _pb_time(sample_start)[0] if sample_start is not None else _ffi.PbTime(0, 0)
+  t1 = _pb_time(sample_end)[0] if sample_end is not None else _ffi.PbTime(0, 0)
+  args = (variable_id.encode(), int(sample_start is not None), t0, int(sample_end is not None), t1, int(sample_size),
+          _fptr(stats))
+  need = lib.sb_pb_variable_info(*args, None, 0)
+  if need < 0:
+    raise _ffi.SbsimError(f"sb_pb_variable_info failed ({need})")
+  buf = (C.c_uint8 * max(need, 1))()
+  lib.sb_pb_variable_info(*args, C.cast(buf, C.c_void_p), need)
+  return bytes(buf[:need])
+
+
 def write_records(path: str, records: Sequence[bytes]) -> None:
   """write_device_infos / write_zone_infos (controller_writer.py:149-171): the file starts over."""
   lib = _ffi.load()

@@ -40,7 +40,7 @@ def test_encoders_reproduce_the_reference_serialization(tmp_path):
     w.write_action_response(got, t)
   # the files: same names (hour of the timestamp), same bytes as the reference's ProtoWriter wrote
   names = sorted(os.listdir(tmp_path))
-  assert names == [str(n) for n in g["shard_names"] if str(n) != "zone_info"]   # (its own test below)
+  assert names == [str(n) for n in g["shard_names"] if str(n) not in ("zone_info", "normalization_info")]   # (their own tests below)
   for n in names:
     assert open(tmp_path / n, "rb").read() == g["shard_" + n].tobytes(), n
   assert len(read_shard(str(tmp_path / "observation_response_2023.07.06.08"))) == 2
@@ -178,3 +178,17 @@ def test_device_and_zone_info_records(tmp_path):
   ew.write_records(path, [z1])            # an existing file is replaced, not extended
   ew.write_records(path, [z0, z1])
   assert open(path, "rb").read() == g["shard_zone_info"].tobytes()
+
+
+def test_normalization_info_records(tmp_path):
+  """ContinuousVariableInfo (write_normalization_info, controller_writer.py:134-147)."""
+  from sbsim_amd import episode_writer as ew
+  g = load("episode_shards.npz")
+  times = _times(g)
+  v0 = ew.encode_variable_info("zone_air_temperature_sensor", 1000, 4.0, 294.0, 293.5, 305.25, 285.0,
+                               sample_start=times[0], sample_end=times[2])
+  v1 = ew.encode_variable_info("supply_air_flowrate_sensor", 0, 0.25, 0.5)
+  assert v0 == g["variable_info_0"].tobytes() and v1 == g["variable_info_1"].tobytes()
+  path = str(tmp_path / ew.NORMALIZATION_FILENAME)
+  ew.write_records(path, [v0, v1])
+  assert open(path, "rb").read() == g["shard_normalization_info"].tobytes()
