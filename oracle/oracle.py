@@ -130,7 +130,8 @@ def lib():
                        ("sbo_dev_ahu_thermal_rate", [d, d, d]), ("sbo_dev_vav_supply_temp", [d, d, d, d]),
                        ("sbo_dev_vav_energy", [d, d, d]),
                        ("sbo_dev_boiler_gas_rate", [C.POINTER(_Params), d, d, d, d, d, d]),
-                       ("sbo_dev_boiler_pump_power", [C.POINTER(_Params), d])):
+                       ("sbo_dev_boiler_pump_power", [C.POINTER(_Params), d]),
+                       ("sbo_dev_boiler_adjust", [d, d, d, d, d])):
       getattr(L, name).restype = d
       getattr(L, name).argtypes = args
     L.sbo_dev_thermostat.restype = C.c_int32

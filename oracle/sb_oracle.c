@@ -274,6 +274,22 @@ double sbo_dev_boiler_pump_power(const sbo_params *prm, double total_flow) {
   return total_flow * RHO_WATER * GRAVITY * prm->blr_head / prm->blr_pump_eff;
 }
 
+/* boiler.py:_adjust_temperature: the tank moves towards the setpoint at heating_rate /
+ * cooling_rate kelvin per minute and stops there. */
+double sbo_dev_boiler_adjust(double setpoint, double actual, double secs, double heating_rate, double cooling_rate) {
+  double cur;
+  if (setpoint > actual) {
+    cur = actual + heating_rate * secs / 60.0;
+    if (setpoint < cur) cur = setpoint; /* min(x, setpoint) */
+  } else if (setpoint < actual) {
+    cur = actual - cooling_rate * secs / 60.0;
+    if (setpoint > cur) cur = setpoint; /* max(x, setpoint) */
+  } else {
+    cur = setpoint;
+  }
+  return cur;
+}
+
 /* boiler.py:146-217: reading supply_water_temperature_sensor at obs_ts advances the tank
  * lag (smart_device.py:146-168 stamps _observation_timestamp first). */
 void sbo_observe_boiler(const sbo_params *prm, sbo_state *s, double obs_ts) {
@@ -285,18 +301,8 @@ void sbo_observe_boiler(const sbo_params *prm, sbo_state *s, double obs_ts) {
   }
   if (prm->blr_cooling_rate > 0.0 && prm->blr_heating_rate > 0.0) {
     double begin = s->blr_tank_temp;
-    double sp = s->blr_setpoint;
-    double secs = s->blr_last_duration;
-    double cur;
-    if (sp > begin) {
-      cur = begin + prm->blr_heating_rate * secs / 60.0;
-      if (sp < cur) cur = sp; /* min(x, setpoint) */
-    } else if (sp < begin) {
-      cur = begin - prm->blr_cooling_rate * secs / 60.0;
-      if (sp > cur) cur = sp; /* max(x, setpoint) */
-    } else {
-      cur = sp;
-    }
+    double cur = sbo_dev_boiler_adjust(s->blr_setpoint, begin, s->blr_last_duration, prm->blr_heating_rate,
+                                       prm->blr_cooling_rate);
     s->blr_tank_temp = cur;
     s->blr_tank_change = cur - begin;
   } else {

@@ -138,6 +138,7 @@ double sbo_dev_vav_energy(double air_flow, double t_zs, double tz);
 double sbo_dev_boiler_gas_rate(const sbo_params *prm, double setpoint, double total_flow, double return_temp,
                                double outside_temp, double tank_change, double last_duration);
 double sbo_dev_boiler_pump_power(const sbo_params *prm, double total_flow);
+double sbo_dev_boiler_adjust(double setpoint, double actual, double secs, double heating_rate, double cooling_rate);
 double sbo_reward(const sbo_params *prm, int32_t Z, const float *zone_temp, const float *heat_sp,
                   const float *cool_sp, const float *occ, float blower, float ac, float gas,
                   float pump, double dt, double e_price, double e_carbon, double g_price,

@@ -120,6 +120,17 @@ class BatchedSinusoidWeather:
     return self.convection_coefficient
 
 
+def _parse_weather_time(text: str) -> dt.datetime:
+  """``pd.Timestamp(t, tz='UTC')`` on the CSV's ``Time`` column (weather_controller.py:183-185): the
+  sbsim weather files write ``YYYYMMDD-HHMM`` (UTC); ISO strings are accepted as well."""
+  text = text.strip()
+  try:
+    t = dt.datetime.strptime(text, "%Y%m%d-%H%M")
+  except ValueError:
+    t = dt.datetime.fromisoformat(text.replace("Z", "+00:00").replace(" UTC", "+00:00"))
+  return t.replace(tzinfo=UTC) if t.tzinfo is None else t
+
+
 class ReplayWeatherController:
   """Linear interpolation of an hourly ``Time,TempF`` CSV
   (simulator/weather_controller.py:166-218)."""
@@ -128,9 +139,7 @@ class ReplayWeatherController:
     times, temps = [], []
     with open(local_weather_path, newline="") as fh:
       for row in csv.DictReader(fh):
-        t = dt.datetime.fromisoformat(row["Time"].replace("Z", "+00:00").replace(" UTC", "+00:00"))
-        if t.tzinfo is None:
-          t = t.replace(tzinfo=UTC)
+        t = _parse_weather_time(row["Time"])
         times.append(t.timestamp())
         temps.append(float(row["TempF"]))
     self._times = np.asarray(times, dtype=np.float64)

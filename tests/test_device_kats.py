@@ -88,3 +88,54 @@ def test_weather_controller_kats(day_of_year, seconds, expected):
   w = host_inputs.WeatherController(40.5, 62.5, special_days={110: (30, 70)})
   ts = dt.datetime(2021, 1, 1) + dt.timedelta(days=day_of_year - 1, seconds=seconds)
   assert w.get_current_temp(ts) == expected
+
+
+def test_replay_weather_controller_kats():
+  """weather_controller_test.py:138-176 on the reference's own test data (Time / TempF columns of
+  simulator/local_weather_test_data.csv, `YYYYMMDD-HHMM` time stamps): 298.15 K one second after
+  03:00 UTC, ValueError outside the trace."""
+  import os
+  path = os.path.join(os.path.dirname(__file__), "golden", "local_weather_test_data.csv")
+  w = host_inputs.ReplayWeatherController(path, 10.0)
+  utc = dt.timezone.utc
+  assert w.get_current_temp(dt.datetime(2023, 7, 1, 3, 0, 1, tzinfo=utc)) == pytest.approx(298.15, abs=1e-5)
+  assert w.get_air_convection_coefficient(dt.datetime(2023, 7, 1, 3, tzinfo=utc)) == 10.0
+  with pytest.raises(ValueError, match="before the latest"):
+    w.get_current_temp(dt.datetime(2023, 6, 30, 23, 59, tzinfo=utc))
+  with pytest.raises(ValueError, match="after the latest"):
+    w.get_current_temp(dt.datetime(2023, 7, 1, 10, 0, 1, tzinfo=utc))
+  b = host_inputs.BatchedReplayWeather(path, [0.0, 3600.0], 10.0)
+  t = b.temps(dt.datetime(2023, 7, 1, 2, 30, tzinfo=utc))
+  assert t[0] == w.get_current_temp(dt.datetime(2023, 7, 1, 2, 30, tzinfo=utc))
+  assert t[1] == w.get_current_temp(dt.datetime(2023, 7, 1, 3, 30, tzinfo=utc)) == pytest.approx(298.15, abs=1e-9)
+
+
+def test_boiler_adjust_temperature_kats():
+  """boiler_test.py:197-230: (setpoint, actual, seconds, heating K/min, cooling K/min) -> tank."""
+  for sp, actual, secs, h, c, want in ((330.0, 290.0, 60, 0.0, 0.0, 290.0), (330.0, 290.0, 60, 2.0, 0.0, 292.0),
+                                       (300.0, 290.0, 600, 2.0, 0.0, 300.0), (320.0, 330.0, 60, 0.0, 0.5, 329.5),
+                                       (320.0, 330.0, 600, 0.0, 2.0, 320.0)):
+    assert orc.device("boiler_adjust", sp, actual, float(secs), h, c) == pytest.approx(want, abs=1e-7)
+
+
+def test_thermostat_state_machine_kats():
+  """thermostat_test.py:47-135 with its schedule (9-18 h, comfort (292, 295), eco (290, 297)).
+  Modes: 0 OFF, 1 HEAT, 2 COOL, 3 PASSIVE_COOL."""
+  sched = host_inputs.SetpointSchedule(9, 18, (292, 295), (290, 297), holidays=set())
+  weekday, weekend = dt.datetime(2021, 5, 5, 11), dt.datetime(2021, 5, 8, 11)
+  low, high = sched.get_temperature_window(weekday)
+  mid = (low + high) / 2
+  assert sched.is_comfort_mode(weekday) and not sched.is_comfort_mode(weekend)
+  mode, seq = 0, []
+  for tz in (low - 1, mid - 1, high + 1, mid + 1, mid - 1, mid + 1):      # test_update_comfort_mode / _default_control
+    mode, _, _ = orc.thermostat(mode, tz, (low, high), True, 1)
+    seq.append(mode)
+  assert seq == [1, 1, 2, 2, 0, 0]
+  eco = sched.get_temperature_window(weekend)
+  m, _, _ = orc.thermostat(0, 0.0, (low, high), True, -1)                  # test_eco_transition
+  m, damper, valve = orc.thermostat(m, 0.0, eco, False, 1)
+  assert m == 3 and (damper, valve) == (0.1, 0.0)
+  m, _, _ = orc.thermostat(m, (eco[0] + eco[1]) / 2, eco, False, 0)        # test_eco_mode: stays passive above the
+  assert m == 3                                                            # heating setpoint, heats below it
+  m, _, _ = orc.thermostat(m, 0.0, eco, False, 0)
+  assert m == 1
