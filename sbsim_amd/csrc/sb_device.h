@@ -5,6 +5,8 @@
 //                            per-building g table; one thread per building
 //   sweep   step_reg.hip  k_sweep_reg  the Gauss-Seidel sweeps with the temperature grid in the
 //                            VGPRs of one or two wavefronts (lane = row, cyclic-skewed slots)
+//           step_roll.hip k_sweep_roll the same for 65..66-row plans (R9): one wavefront + tail rows,
+//                            consecutive sweeps overlapped
 //           step_lds.hip  k_sweep_lds  the same with the grid in LDS (any floor-plan shape)
 //   k_post  (sbsim_hip.hip)  reward_info, regret reward, observation row, scalar state
 // The sweep kernel is > 95 % of the time and is kept free of everything else: its unrolled
@@ -66,7 +68,10 @@ struct Dev {
   int P;                   // kernel mode: 1 / 2 wavefronts per building, 3 = 1 wavefront + tail rows
   int T;                   // mode 3: rows 64..64+T-1 are finished by the tail scan (T <= 2)
   int state_doubles;       // doubles of HBM state per building
-  const uint8_t *tcls;     // mode 3: [T][NR] classes of the tail cells
+  const uint8_t *tcls;     // mode 3: [T][NR] classes of the tail cells (class * 8)
+  const uint8_t *tcset;    // mode 3: [T][NR] coefficient sets of the tail cells (set * 8)
+  const double *csetab;    // mode 3: [ncset][4] distinct (bU, bD, bL, bR); the sweep's class bytes index this table
+  int ncset;
   int RS;                  // rows of the trimmed grid = row stride of the HBM state [NR][RS]
   int AS;                  // row stride of A in LDS (odd when it fits: bank-conflict free)
   int ZRS;                 // row stride of the zone-sum scratch [Z+1][ZRS] that aliases A (RS | 1)
@@ -126,6 +131,13 @@ int sweep_reg_table_stride(int NR, int P);   // coefficient-table stride of the 
 int sweep_reg_lds_slots(int NR, int P);      // slots of A the instantiation keeps in LDS (the rest: registers)
 int sweep_reg_waves_per_simd(int NR, int P); // register budget of the instantiation: wavefronts per SIMD
 bool sweep_reg_overlaps_sweeps(int NR, int P); // a sweep costs NR steps (lanes start the next sweep while others finish)
+// step_roll.hip: mode 3 (one wavefront + tail rows, overlapped sweeps)
+int launch_sweep_roll(const Dev &d, hipStream_t stream);
+int prepare_sweep_roll(const Dev &d);
+bool sweep_roll_supported(int NR);
+int sweep_roll_lds_slots(int NR);            // slots of A in LDS
+int sweep_roll_a_stride(int NR);             // row stride of A in LDS (doubles)
+int sweep_roll_seam_doubles(int NR, int T);  // LDS doubles of [pad | row 63 | pad][tail rows]
 
 // ---------------------------------------------------------------- wave helpers
 // DPP move of a double; lanes without a source (or outside row_mask) receive 0.

@@ -62,8 +62,8 @@ struct sb_handle {
   sb::Dev d{};
   int device = 0, cus = 256;
   sb_launch_info info{};
-  DevBuf<uint8_t> cls, tcls;
-  DevBuf<double> ctab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum,
+  DevBuf<uint8_t> cls, tcls, tcset;
+  DevBuf<double> ctab, csetab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum,
       hist_bins;
   DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone, cell_state, nsw, next_b, src_dest,
       hist_col, hist_off;

@@ -144,7 +144,8 @@ struct RegPlan {
   bool ok = false;
   std::string why;
   int NR = 0, P = 0, RS = 0, Ws = 0, r0 = 0, c0 = 0, n_ring = 0, T = 0, state_doubles = 0, ts = 32;
-  std::vector<uint8_t> tcls;
+  std::vector<uint8_t> tcls, tcset;
+  std::vector<double> csetab; // mode 3: distinct (bU, bD, bL, bR), the pad set (all zero) last
   int lw[2] = {0, 0}, l0[2] = {0, 0}, rowbase[2] = {0, 0}, nch[2] = {0, 0};
   int lag = 0, nslots = 0, steps = 0;
   int r_seam = 0, r_A = 0, r_xchg = 0, lds_bytes = 0, wg_per_cu = 0, AS = 0;
@@ -187,8 +188,11 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   for (int z = 0; z < Z; ++z)
     for (int i = plan->zone_off[z]; i < plan->zone_off[z + 1]; ++i) zone_of[plan->zone_cells[i]] = z;
   auto pick_slots = [&](int mode) { // narrowest instantiation that holds the width and the class count
-    for (int s : kRegSlots)
-      if (s >= Ws && sweep_reg_supported(s, mode) && ncls + 1 <= sweep_reg_table_stride(s, mode)) return s;
+    for (int s : kRegSlots) {
+      if (mode == 3) {
+        if (s >= Ws && sweep_roll_supported(s) && ncls + 1 <= 32) return s;
+      } else if (s >= Ws && sweep_reg_supported(s, mode) && ncls + 1 <= sweep_reg_table_stride(s, mode)) return s;
+    }
     return 0;
   };
   // mode 1: one wavefront; mode 3: one wavefront + one or two tail rows finished by a scan
@@ -211,11 +215,12 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   }
   if (!P) { r.why = "more than 128 rows inside the building"; return; }
   if (!NR) { r.why = "no kernel variant for this width and class count"; return; }
-  const int TS = sweep_reg_table_stride(NR, P), cscale = 256 / TS; // class byte = class * cscale
+  const int TS = P == 3 ? 32 : sweep_reg_table_stride(NR, P), cscale = 256 / TS; // class byte = class * cscale
+  const int nl_slots = P == 3 ? sweep_roll_lds_slots(NR) : sweep_reg_lds_slots(NR, P);
   r.ts = TS;
   const int RS = P == 3 ? 64 : Hs;
   const int ZRS = RS | 1; // odd stride: the zone reduce reads 16 zone rows at once
-  if ((size_t)(Z + 1) * ZRS > (size_t)RS * sweep_reg_lds_slots(NR, P) || (size_t)(Z + 1) * ZRS * 8 > 65535) {
+  if ((size_t)(Z + 1) * ZRS > (size_t)RS * nl_slots || (size_t)(Z + 1) * ZRS * 8 > 65535) {
     r.why = "too many zones for the zone-sum scratch"; // it aliases A: (Z+1) x ZRS doubles
     return;
   }
@@ -256,44 +261,87 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   auto layout = [&](int AS) {
     int off = 5 * TS + TS;
     r.r_seam = off;
-    off += P == 2 ? 2 * (NR + 2 * kRegSeamPad) : (P == 3 ? ((NR + 2 * kRegSeamPad + r.T * (NR + 2) + 1) & ~1) : 0);
+    off += P == 2 ? 2 * (NR + 2 * kRegSeamPad) : (P == 3 ? sweep_roll_seam_doubles(NR, r.T) : 0);
     r.r_A = off; off += RS * AS;
     r.r_xchg = off; off += 8;
     r.AS = AS;
     r.lds_bytes = off * 8;
     // workgroups per CU: LDS, and the registers (4 SIMDs x wavefronts per SIMD / wavefronts per building)
-    const int by_regs = 4 * sweep_reg_waves_per_simd(NR, P) / (P == 2 ? 2 : 1);
+    const int by_regs = P == 3 ? 4 : 4 * sweep_reg_waves_per_simd(NR, P) / (P == 2 ? 2 : 1);
     r.wg_per_cu = std::min(by_regs, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule));
   };
-  const int nl = sweep_reg_lds_slots(NR, P); // slots of A in LDS (the kernel keeps the rest in registers)
-  layout(nl);
-  const int plain = r.wg_per_cu;
-  layout(nl | 1);
-  if (r.wg_per_cu < plain) layout(nl);
+  const int nl = nl_slots; // slots of A in LDS (the kernel keeps the rest in registers)
+  if (P == 3) {
+    layout(sweep_roll_a_stride(NR)); // 2 mod 4 doubles: 16-byte aligned rows, conflict-free ds_read_b128
+  } else {
+    layout(nl);
+    const int plain = r.wg_per_cu;
+    layout(nl | 1);
+    if (r.wg_per_cu < plain) layout(nl);
+  }
   if (r.wg_per_cu < 1) { r.why = "one building does not fit in LDS"; return; }
 
   const int pad = ncls;
+  // mode 3: the sweep looks its four neighbour coefficients up by coefficient SET (classes that
+  // differ only in ap / g share one): fewer distinct LDS addresses per wavefront read
+  std::vector<int> set_of(ncls + 1, 0);
+  if (P == 3) {
+    for (int c = 0; c < ncls; ++c) {
+      int found = -1;
+      for (size_t k = 0; k < r.csetab.size() / 4 && found < 0; ++k)
+        if (r.csetab[4 * k] == coef(c, 0) && r.csetab[4 * k + 1] == coef(c, 1) && r.csetab[4 * k + 2] == coef(c, 2) &&
+            r.csetab[4 * k + 3] == coef(c, 3)) found = (int)k;
+      if (found < 0) {
+        found = (int)r.csetab.size() / 4;
+        for (int j = 0; j < 4; ++j) r.csetab.push_back(coef(c, j));
+      }
+      set_of[c] = found;
+    }
+    set_of[pad] = (int)r.csetab.size() / 4; // the pad set: no neighbour counts
+    for (int j = 0; j < 4; ++j) r.csetab.push_back(0.0);
+    if (r.csetab.size() / 4 > 32) { r.why = "more than 32 distinct coefficient sets"; r.ok = false; return; }
+  }
   auto cell_class = [&](int R, int col) { // trimmed coordinates
     return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? cls_at(x0 + R, y0 + col) : pad;
   };
   const int aslots = (NR + 7) / 8, zslots = (NR + 3) / 4;
   const int nw = P == 2 ? 2 : 1;
-  r.cmapS.assign((size_t)nw * (maxch + 3) * 64, 0);
+  r.cmapS.assign((size_t)nw * (maxch + 3) * 64 * (P == 3 ? 2 : 1), 0);
   r.amapS.assign((size_t)nw * aslots * 64, 0);
   r.zmapS.assign((size_t)nw * zslots * 64, 0);
   r.tcls.assign((size_t)std::max(r.T, 1) * NR, (uint8_t)(8 * pad));
+  r.tcset.assign((size_t)std::max(r.T, 1) * NR, (uint8_t)(8 * set_of[pad]));
   for (int t = 0; t < r.T; ++t)
-    for (int c = 0; c < NR; ++c) r.tcls[(size_t)t * NR + c] = (uint8_t)(8 * cell_class(64 + t, c));
+    for (int c = 0; c < NR; ++c) {
+      r.tcls[(size_t)t * NR + c] = (uint8_t)(8 * cell_class(64 + t, c));
+      r.tcset[(size_t)t * NR + c] = (uint8_t)(8 * set_of[cell_class(64 + t, c)]);
+    }
   for (int w = 0; w < nw; ++w)
     for (int lane = 0; lane < 64; ++lane) {
       const int lp = lane - r.l0[w];
       const bool valid = lp >= 0 && lp < r.lw[w];
       const int R = r.rowbase[w] + lp;
+      if (P == 3) {
+        // step_roll.hip: one 16-bit field per step = the LDS byte offset of the cell's coefficient
+        // set (set * 32), four steps per word; steps >= NR + 63 belong to the next period (the
+        // field of step NR + 63 = step 63 closes the period's last word)
+        for (int ch = 0; ch < (maxch + 3) * 2; ++ch) {
+          unsigned long long word = 0;
+          for (int k = 0; k < 4; ++k) {
+            int st = 4 * ch + k;
+            if (st >= NR + 63) st -= NR;
+            int col = st - lp;
+            if (col >= NR) col -= NR; // overlapped sweeps: the lane is in its next sweep
+            const int c = valid ? cell_class(R, col) : pad;
+            word |= (unsigned long long)(set_of[c] * 32) << (16 * k);
+          }
+          r.cmapS[(size_t)ch * 64 + lane] = word;
+        }
+      } else
       for (int ch = 0; ch < maxch + 3; ++ch) {
         unsigned long long word = 0;
         for (int k = 0; k < 8; ++k) {
           int col = 8 * ch + k - lp;
-          if (P != 2 && col >= NR) col -= NR; // overlapped sweeps: the lane is in its next sweep
           const int c = valid ? cell_class(R, col) : pad;
           word |= (unsigned long long)(c * cscale) << (8 * k); // stride 32: the byte offset into a table column
         }
@@ -516,6 +564,9 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     SB_TRY(upload(h->cell_state, r.cell_state.data(), r.cell_state.size()));
     SB_TRY(alloc_zero(h->ring, (size_t)d.B * std::max(r.n_ring, 1)));
     SB_TRY(upload(h->tcls, r.tcls.data(), r.tcls.size()));
+    SB_TRY(upload(h->tcset, r.tcset.data(), r.tcset.size()));
+    SB_TRY(upload(h->csetab, r.csetab.data(), r.csetab.size()));
+    d.tcset = h->tcset.p; d.csetab = h->csetab.p; d.ncset = (int)r.csetab.size() / 4;
     SB_TRY(alloc_zero(h->temp, (size_t)d.B * d.state_doubles));
     d.tcls = h->tcls.p;
     d.cmapS = h->cmapS.p; d.amapS = h->amapS.p; d.zmapS = h->zmapS.p; d.cell_state = h->cell_state.p;
@@ -648,7 +699,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     if (alloc_zero(h->dbg, 16) == SB_OK) d.dbg = h->dbg.p;
   }
 
-  const int e = d.reg ? prepare_sweep_reg(d) : prepare_sweep_lds((size_t)h->info.lds_bytes_per_workgroup);
+  const int e = d.reg ? (d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
+                      : prepare_sweep_lds((size_t)h->info.lds_bytes_per_workgroup);
   if (e != (int)hipSuccess) {
     delete h;
     return fail(SB_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") +
@@ -714,7 +766,7 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   if (phases & SB_PHASE_SWEEP) {
     if (!(phases & SB_PHASE_PRE)) // k_pre zeroes the sweep kernel's draw counter; without it in this call:
       SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream));
-    const int e = d.reg ? launch_sweep_reg(d, h->cus, (hipStream_t)stream)
+    const int e = d.reg ? (d.P == 3 ? launch_sweep_roll(d, (hipStream_t)stream) : launch_sweep_reg(d, h->cus, (hipStream_t)stream))
                         : launch_sweep_lds(d, h->info.workgroups, h->info.waves_per_workgroup,
                                            (size_t)h->info.lds_bytes_per_workgroup, (hipStream_t)stream);
     if (e != (int)hipSuccess)

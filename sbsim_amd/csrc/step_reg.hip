@@ -774,7 +774,7 @@ void launch_variant(const Dev &d, int workgroups, hipStream_t stream) {
 
 #define SB_VARIANT(NR, P) {NR, P, (const void *)k_sweep_reg<NR, P>, launch_variant<NR, P>}
 const Variant kVariants[] = {SB_VARIANT(32, 1), SB_VARIANT(66, 1), SB_VARIANT(66, 2), SB_VARIANT(96, 1),
-                            SB_VARIANT(96, 2), SB_VARIANT(96, 3)};
+                            SB_VARIANT(96, 2)}; // mode 3 (tail rows, overlapped sweeps): step_roll.hip
 #undef SB_VARIANT
 
 const Variant *find_variant(int NR, int P) {

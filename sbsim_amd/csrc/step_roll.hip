@@ -1,0 +1,594 @@
+// step_roll.hip -- the sweep kernel for floor plans of 65..66 rows inside their exterior ring
+// (R9: 66 x 96): one wavefront per building, the grid in registers, rows 64.. finished by a scan,
+// consecutive Gauss-Seidel sweeps overlapped ("rolling" sweeps).  simulator.py:278-371.
+//
+// Layout and schedule are those of step_reg.hip (lane l owns row l, column c in register slot
+// (c + l) mod NR, every lane works on slot s mod NR at step s, neighbours by DPP) with all 64
+// lanes owning a row, so that lanes 0..j START sweep k+1 during steps j = 0..62 of a period
+// while lanes j+1..63 FINISH sweep k: a sweep costs NR steps.  Whether sweep k was the last one
+// (simulator.py:360) is known only after step 62 and the tail scan, so the first steps of sweep
+// k+1 are speculative: every window step keeps a copy of the value it overwrites and the last
+// period restores lanes <= j from the copies.
+//
+// What this file is built around (tools/ubench_issue.hip, one wavefront per SIMD on gfx950):
+// every instruction of a lone wavefront -- VALU of any width, DPP, SALU, LDS, s_waitcnt, s_nop,
+// dependent or not -- costs one ~4.35-cycle issue slot, and the four wavefronts of a CU share one
+// LDS pipe (ds_read_b64 2 cycles, ds_read_b128 4, ds_read2_b64 8, ds_write_b64 6).  So the
+// step is written for the fewest instructions and few LDS cycles:
+//   * coefficients as array-of-structs [set][bU bD | bL bR]: two ds_read_b128 (8 LDS cycles;
+//     the struct-of-arrays table took two ds_read2_b64 = 16, which alone made the step LDS-bound);
+//     cells with equal coefficients share a set (R9: 9 sets for 20 classes): fewer bank conflicts
+//   * steps go in pairs: A = ap*Tprev + g of two neighbouring slots and the two seam values under
+//     lane 63 are one ds_read_b128 each (A rows are stored rotated by one slot so that the pair of
+//     an odd step is 16-byte aligned; row stride 70 doubles: conflict-free), one s_waitcnt per pair
+//   * the class bytes of all steps live in registers (AGPRs) for the whole kernel
+//   * window steps route |delta| to the accumulator of the lane's own sweep by its SIGN: a lane
+//     mask that one DPP shift per step maintains is OR-ed into the high word, one running max
+//     (sweep k) and one running min (sweep k+1) -- no lane compare, no select
+// Plain step: 14.5 issue slots (was 16), window step 19.5 (was 22), 12 LDS cycles (was 20).
+#include "sb_device.h"
+
+namespace sb {
+namespace {
+
+#ifndef SB_ONE_WAIT
+#define SB_ONE_WAIT 0
+#endif
+constexpr int kWin = 63;      // steps of a period in which the lanes are in two different sweeps
+constexpr int kTailMax = 2;
+constexpr int kTS = 32;       // entries of the per-class tables (ap, g) and of the coefficient-set table
+constexpr int kSeamPad = 8;
+
+// Slots of A = ap*Tprev + g kept in LDS (the rest: AGPRs).  70 of 96: a building needs 39.9 KB of
+// LDS, so four buildings -- one per SIMD -- share a CU.  Even (pairs), and the row stride
+// (= this) is 2 mod 4 doubles: rows are 16-byte aligned and 16 lanes' ds_read_b128 cover all banks.
+constexpr int lds_slots(int NR) { return NR == 96 ? 70 : ((NR / 2) % 2 ? NR : NR + 2); }
+constexpr int a_stride(int NR) { return NR == 96 ? 70 : ((NR / 2) % 2 ? NR : NR + 2); }
+constexpr int tail_row(int NR) { return NR + 4; } // tail rows in LDS: column c at [2 + c], zero guards around
+
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// Lanes 0..J as a lane predicate: one SALU instruction where it is used.
+template <int J>
+__device__ __forceinline__ bool lanes_upto() {
+  unsigned long long m;
+  asm volatile("s_bfm_b64 %0, %1, 0" : "=s"(m) : "n"(J + 1));
+  return __builtin_amdgcn_inverse_ballot_w64(m);
+}
+
+// lane l <- lane l-1 (CTRL 0x138, wave_shr:1) / lane l+1 (0x130, wave_shl:1).  SEAM: the lane
+// without a source keeps `old`; otherwise it reads 0.
+template <int CTRL, bool SEAM>
+__device__ __forceinline__ double wave_shift1(double x, double old) {
+  int lo, hi;
+  if (SEAM) {
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, 0xf, false);
+  } else {
+    lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  }
+  return __hiloint2double(hi, lo);
+}
+
+typedef double d2 __attribute__((ext_vector_type(2))); // two doubles = one ds_read_b128
+typedef const d2 __attribute__((address_space(3))) *lds_d2;
+
+struct PairBuf { // LDS values of two consecutive steps
+  d2 ud0, lr0, ud1, lr1; // (bU, bD), (bL, bR)
+  d2 A;                  // A of the two slots
+  d2 sm;                 // old values of the first tail row under lane 63
+};
+
+struct Acc {
+  double cur; // max |delta| of the sweep the lanes are finishing
+  double neg; // -(max |delta|) of the sweep the lanes have started (window steps)
+  int sg;     // 0x80000000 in the lanes that have started the next sweep
+};
+
+
+template <int NR>
+struct Ctx {
+  const double *Arow;  // the lane's row of A, rotated: slot j at [(j + 1) mod NR]
+  const double *seam;  // first tail row by step: the value under lane 63 at step s is seam[s]
+  const char *cmap;    // class words: a.cmapS (uniform)
+  unsigned voff;       // byte offset of the lane's NEXT class word: 8 * lane + 512 * word
+  unsigned long long w, wn, wnn; // class word (4 steps) in use / the next two, in flight
+};
+
+// Class words hold one 16-bit field per step: the LDS byte offset of the step's coefficient set
+// (set * 32; the table sits at LDS address 0), four steps per 64-bit word, read from global memory
+// (L1/L2 hits) one word ahead.  Word k covers steps 4k .. 4k+3; the field of step NR + 63 (= step
+// 63 of the next period) closes the last word of a period, so that words change every fourth step.
+template <int NR>
+__device__ __forceinline__ unsigned long long class_word(Ctx<NR> &x) { // global_load: SGPR base + 32-bit VGPR offset
+  return *(const unsigned long long *)(x.cmap + x.voff);
+}
+template <int NR, int S>
+__device__ __forceinline__ lds_d2 step_set(Ctx<NR> &x) {
+  if constexpr (S % 4 == 0) { // words are read two ahead (8 steps): an L2 hit takes longer than four steps
+    x.w = x.wn;
+    x.wn = x.wnn;
+    // after the period's last word comes step 64's (a running offset: not loop-invariant, nothing to hoist)
+    if constexpr (S == NR + kWin - 7) x.voff -= (unsigned)((NR + kWin - 3) / 4 - (kWin / 4 + 1)) * 512u;
+    else x.voff += 512u;
+    asm volatile("" : "+v"(x.voff)); // ... as far as the compiler can tell
+    x.wnn = class_word<NR>(x);
+  }
+  const unsigned h = S % 4 < 2 ? (unsigned)x.w : (unsigned)(x.w >> 32);
+  const unsigned off = S % 2 ? h >> 16 : h & 0xffffu;
+  return (lds_d2)off;
+}
+
+// LDS reads of the pair (S, S + 1), first half: coefficients of step S, both A values, both
+// seam values.  Position of slot j in the lane's A row: (j + 1) mod NR -- even for odd S.
+template <int NR, int S, bool SEAM, int NAR>
+__device__ __forceinline__ void load_first(PairBuf &p, Ctx<NR> &x, const double (&Areg)[NAR]) {
+  const lds_d2 ct = step_set<NR, S>(x);
+  p.ud0 = ct[0];
+  p.lr0 = ct[1];
+  constexpr int q = (S + 1) % NR, NL = lds_slots(NR);
+  static_assert(q % 2 == 0, "pairs start at odd steps");
+  if constexpr (q < NL) p.A = *(const d2 *)(x.Arow + q);
+  else p.A = d2{Areg[q - NL], Areg[q + 1 - NL]};
+  if constexpr (SEAM && S >= kWin) p.sm = *(const d2 *)(x.seam + S);
+  else p.sm = d2{0.0, 0.0};
+}
+template <int NR, int S>
+__device__ __forceinline__ void load_second(PairBuf &p, Ctx<NR> &x) {
+  const lds_d2 ct = step_set<NR, S>(x);
+  p.ud1 = ct[0];
+  p.lr1 = ct[1];
+}
+
+// One Gauss-Seidel update of every lane's current cell at step S of the overlapped schedule:
+//   S < 63            ramp-up of a building's first sweep: lanes > S have not started
+//   63 <= S < NR      all 64 lanes are in the same sweep
+//   NR <= S < NR + 63 window: lanes <= S - NR are in the next sweep
+// Association order of the four products as in step_reg.hip / step_lds.hip.
+template <int NR, int S>
+__device__ __forceinline__ void step(double (&e)[NR], double (&bk)[kWin], d2 ud, d2 lr, double A,
+                                     double sm, Acc &acc) {
+  constexpr int r = S % NR, rm = (S + NR - 1) % NR, rp = (S + 1) % NR;
+  const double Dn = wave_shift1<0x130, true>(e[rp], sm);
+  // the chain starts in a register of its own (early clobber): accumulated in place in A's
+  // register, the new value would have to be copied out of the ds_read_b128 tuple every step
+  double t;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t) : "v"(ud.y), "v"(Dn), "v"(A));
+  t = fma(lr.y, e[rp], t);
+  const double U = wave_shift1<0x138, false>(e[rm], 0.0);
+  t = fma(lr.x, e[rm], t);
+  const double nv = fma(ud.x, U, t);
+  if constexpr (S < kWin) {
+    const double sel = lanes_upto<S>() ? nv : e[r];
+    acc.cur = fmax(acc.cur, fabs(sel - e[r]));
+    e[r] = sel;
+  } else if constexpr (S < NR) {
+    acc.cur = fmax(acc.cur, fabs(nv - e[r]));
+    e[r] = nv;
+  } else {
+    constexpr int J = S - NR;
+    const double d = nv - e[r];
+    bk[J] = e[r];
+    e[r] = nv;
+    // +|d| in the lanes still in sweep k, -|d| in the lanes already in sweep k+1
+    const double sd = __hiloint2double((__double2hiint(d) & 0x7fffffff) | acc.sg, __double2loint(d));
+    acc.cur = fmax(acc.cur, sd);
+    acc.neg = fmin(acc.neg, sd);
+    if constexpr (J + 1 < kWin) // lane J + 1 starts its next sweep at the next step (lane 0 keeps its bit)
+      acc.sg = __builtin_amdgcn_update_dpp(acc.sg, acc.sg, 0x138, 0xf, 0xf, false);
+    // here, not after the window: e[J] and bk[J] both survive the window
+    asm volatile("" : "+v"(acc.cur), "+v"(acc.neg));
+  }
+}
+
+// Pairs S, S + 2, .. < S1 (S odd).  While pair S runs, the LDS reads of pair S + 2 are issued in
+// two halves (the registers of step S are free for the second half); the last pair reads ahead for
+// pair SNEXT (its seam values are read by the caller, after the tail scan).  One s_waitcnt per
+// pair: it stands before the first half is issued and covers the previous pair's second half.
+template <int NR, int S, int S1, int SNEXT, int NAR>
+__device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], const double (&Areg)[NAR],
+                                           PairBuf (&pb)[2], Ctx<NR> &x, Acc &acc) {
+  if constexpr (S < S1) {
+    constexpr bool last = S + 2 >= S1;
+    constexpr int N = last ? SNEXT : S + 2;
+    PairBuf &cur = pb[((S - 1) / 2) & 1], &nxt = pb[((S + 1) / 2) & 1];
+#if SB_ONE_WAIT // one s_waitcnt per pair: measured slower (the second half's reads are only one step old)
+    asm volatile("" ::"v"(cur.ud0.x), "v"(cur.A.x), "v"(cur.sm.x), "v"(cur.ud1.x), "v"(cur.lr1.x));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    load_first<NR, N, !last>(nxt, x, Areg);
+    __builtin_amdgcn_sched_barrier(0);
+    step<NR, S>(e, bk, cur.ud0, cur.lr0, cur.A.x, cur.sm.x, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_second<NR, N + 1>(nxt, x);
+    __builtin_amdgcn_sched_barrier(0);
+    step<NR, S + 1>(e, bk, cur.ud1, cur.lr1, cur.A.y, cur.sm.y, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    roll_pairs<NR, S + 2, S1, SNEXT>(e, bk, Areg, pb, x, acc);
+  }
+}
+
+template <int NR, int J>
+__device__ __forceinline__ void roll_back(double (&e)[NR], const double (&bk)[kWin]) {
+  if constexpr (J < kWin) {
+    e[J] = lanes_upto<J>() ? bk[J] : e[J];
+    roll_back<NR, J + 1>(e, bk);
+  }
+}
+
+// ---------------------------------------------------------------- tail rows
+// Rows 64.. of the trimmed grid (at most two) are finished after the wavefront's pass, lanes =
+// columns.  Along a row the Gauss-Seidel update is the first-order recurrence
+//     x_c = bL_c * x_{c-1} + q_c,    q_c = A + bD*D_old + bR*R_old + bU*U_new,
+// which an inclusive scan over the affine maps f_c(x) = bL_c x + q_c evaluates in log2(64) DPP
+// steps (F <- F o F_shifted; lanes without a source compose with the identity).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void scan_step(double &a, double &q) {
+  const double one = 1.0;
+  const int alo = __builtin_amdgcn_update_dpp(__double2loint(one), __double2loint(a), CTRL, ROW_MASK, 0xf, false);
+  const int ahi = __builtin_amdgcn_update_dpp(__double2hiint(one), __double2hiint(a), CTRL, ROW_MASK, 0xf, false);
+  const int qlo = __builtin_amdgcn_update_dpp(0, __double2loint(q), CTRL, ROW_MASK, 0xf, false);
+  const int qhi = __builtin_amdgcn_update_dpp(0, __double2hiint(q), CTRL, ROW_MASK, 0xf, false);
+  const double as = __hiloint2double(ahi, alo), qs = __hiloint2double(qhi, qlo);
+  q = fma(a, qs, q); // (a, q) o (as, qs) = (a*as, a*qs + q)
+  a = a * as;
+}
+__device__ __forceinline__ void affine_scan(double &a, double &q) {
+  scan_step<0x111, 0xf>(a, q); // row_shr:1,2,4,8: inclusive scan inside each row of 16 lanes
+  scan_step<0x112, 0xf>(a, q);
+  scan_step<0x114, 0xf>(a, q);
+  scan_step<0x118, 0xf>(a, q);
+  scan_step<0x142, 0xa>(a, q); // row_bcast:15 -> rows 1 and 3
+  scan_step<0x143, 0xc>(a, q); // row_bcast:31 -> rows 2 and 3
+}
+
+// A lane owns two neighbouring columns of a tail row: NR <= 128 columns are one 64-lane scan.
+__device__ __forceinline__ int tail_col(int lane, int k) { return 2 * lane + k; }
+
+// One Gauss-Seidel pass over the tail rows; returns the lane's max |delta|.
+// tE: [T][NR + 4] current values (column c at [2 + c]); r63: new values of row 63 by column.
+// The lane first composes the maps of its two columns (x_{2l+1} = bL1*(bL0*x + q0) + q1), the
+// scan runs over the 64 composed maps, and the even column follows from its left neighbour.
+// tset[t]: byte offsets of the lane's two cells' coefficient sets in the table (low / high half).
+template <int NR>
+__device__ __forceinline__ double tail_pass(int T, int lane, double *tE, const double *r63,
+                                            const int (&tset)[kTailMax], const double (&At)[kTailMax][2]) {
+  constexpr int kRow = tail_row(NR);
+  static_assert(NR % 2 == 0 && NR <= 128, "two columns per lane");
+  const bool active = 2 * lane < NR;
+  const int c0 = active ? 2 * lane : NR - 2;
+  double dmax = 0.0;
+#pragma unroll
+  for (int t = 0; t < kTailMax; ++t) {
+    if (t < T) {
+      double *row = tE + t * kRow + 2;
+      const lds_d2 s0 = (lds_d2)(unsigned)(tset[t] & 0xffff), s1 = (lds_d2)((unsigned)tset[t] >> 16);
+      const d2 ud0 = s0[0], lr0 = s0[1], ud1 = s1[0], lr1 = s1[1];
+      const d2 old = *(const d2 *)(row + c0); // 16-byte aligned: c0 even, row base even
+      const double R1 = row[c0 + 2];
+      const d2 Uv = *(const d2 *)((t == 0 ? r63 : row - kRow) + c0);
+      d2 Dv = d2{0.0, 0.0};
+      if (t + 1 < T) Dv = *(const d2 *)(row + kRow + c0);
+      const double q0 = fma(ud0.x, Uv.x, fma(lr0.y, old.y, fma(ud0.y, Dv.x, At[t][0]))); // right neighbour: not yet updated
+      const double q1 = fma(ud1.x, Uv.y, fma(lr1.y, R1, fma(ud1.y, Dv.y, At[t][1])));
+      double a = lr1.x * lr0.x, Q = fma(lr1.x, q0, q1);
+      affine_scan(a, Q); // Q: the odd column (the row starts from bL = 0: no carry-in)
+      const double xl = wave_shift1<0x138, false>(Q, 0.0); // column 2l - 1
+      const double x0 = fma(lr0.x, xl, q0);
+      __builtin_amdgcn_wave_barrier(); // every read of the row's old values is done
+      if (active) {
+        dmax = fmax(dmax, fmax(fabs(x0 - old.x), fabs(Q - old.y)));
+        *(d2 *)(row + c0) = d2{x0, Q};
+      }
+      __builtin_amdgcn_wave_barrier(); // the next row reads this one
+    }
+  }
+  return dmax;
+}
+
+extern __shared__ __attribute__((aligned(16))) double lds[];
+
+template <int NR>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_roll(Dev a) {
+  const int lane = threadIdx.x & 63;
+  constexpr int kASlots = (NR + 7) / 8, kZSlots = (NR + 3) / 4;
+  constexpr int kNL = lds_slots(NR), kAS = a_stride(NR), kNAR = NR - kNL > 0 ? NR - kNL : 2;
+  constexpr int kRow = tail_row(NR);
+
+  double *tabc = lds;                      // [kTS][4]: bU bD bL bR per coefficient set
+  double *tap = lds + 4 * kTS;             // [kTS] ap by class
+  double *gtab = lds + 5 * kTS;            // [kTS] g by class (this building)
+  double *seamD = lds + a.r_seam;          // [pad | r63: NR | pad][tE: T x (NR + 4)]
+  double *r63 = seamD + kSeamPad;          // new values of row 63, by column
+  double *tE = seamD + NR + 2 * kSeamPad;  // tail rows, column c at [t*(NR+4) + 2 + c]
+  double *A = lds + a.r_A;                 // [64][kAS]; after the sweeps: zone sums [Z+1][ZRS]
+  // every byte of LDS starts finite: reads next to the arrays' ends are multiplied by 0
+  for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < 4 * kTS; i += 64) tabc[i] = i < 4 * a.ncset ? a.csetab[i] : 0.0;
+  if (lane < kTS) tap[lane] = lane <= a.ncls ? a.ctab[lane * 8 + 4] : 0.0; // row `ncls` is the pad class
+  __builtin_amdgcn_wave_barrier();
+
+  const sb_params &p = a.p;
+  const int R = lane;
+  constexpr int RS = 64;
+  if ((unsigned)(size_t)(__attribute__((address_space(3))) double *)tabc != 0u) __builtin_trap(); // class words hold LDS addresses
+  Ctx<NR> x;
+  x.Arow = A + (size_t)R * kAS;
+  x.seam = tE + 2 - kWin; // lane 63 works on column s - 63 at step s
+  x.cmap = (const char *)a.cmapS;
+  x.voff = 0;
+  x.w = x.wn = x.wnn = 0;
+  // the lane's tail cells (static per floor plan): table offsets of their coefficient sets
+  // (two 16-bit halves) and of their classes (two bytes)
+  int tset[kTailMax], tcls8[kTailMax];
+#pragma unroll
+  for (int t = 0; t < kTailMax; ++t) {
+    tset[t] = 0;
+    tcls8[t] = (8 * a.ncls) | ((8 * a.ncls) << 8);
+    if (t < a.T) {
+      const int c0 = min(tail_col(lane, 0), NR - 1), c1 = min(tail_col(lane, 1), NR - 1);
+      tset[t] = ((int)a.tcset[t * NR + c0] << 2) | ((int)a.tcset[t * NR + c1] << 18); // set * 8 -> set * 32
+      tcls8[t] = (int)a.tcls[t * NR + c0] | ((int)a.tcls[t * NR + c1] << 8);
+    }
+  }
+  const unsigned long long *amap = a.amapS + lane;
+  const unsigned long long *zmap = a.zmapS + lane;
+
+// developer aid: cycle stamps of workgroup 0's 11th building (steady state, not the cold start)
+#define SB_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && iter == 10 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+
+  // The lane's row of the NEXT building is loaded while this building's row is stored, slot by
+  // slot, so the loop never waits on HBM latency; so are the building's small inputs.
+  double e[NR];
+  double nx_g = 0.0, nx_tail[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}, nx_tnow = 0.0, nx_lo = 0.0, nx_hi = 0.0;
+#define SB_LOAD_AUX(bb)                                                                         \
+  do {                                                                                          \
+    nx_tnow = a.bld[(bb)].t_now;                                                                \
+    nx_lo = a.scal[(size_t)(bb) * kNScal + 16];                                                 \
+    nx_hi = a.scal[(size_t)(bb) * kNScal + 17];                                                 \
+    nx_g = a.gtabg[(size_t)(bb) * kTS + (lane & (kTS - 1))];                                    \
+    const double *tt_ = a.temp + (size_t)(bb) * a.state_doubles + NR * 64;                      \
+    _Pragma("unroll") for (int t = 0; t < kTailMax; ++t)                                        \
+      _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
+        if (t < a.T) nx_tail[t][k] = tt_[t * NR + min(tail_col(lane, k), NR - 1)];              \
+  } while (0)
+  if ((int)blockIdx.x < a.B) {
+    const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      e[j] = tp_[R];
+      tp_ += RS;
+    }
+    SB_LOAD_AUX(blockIdx.x);
+  }
+  // Buildings need different numbers of sweeps: after its first building a workgroup draws the
+  // next one from a device counter (zeroed before every launch).
+  int iter = 0;
+  for (int b = blockIdx.x, bn = 0; b < a.B; b = bn, ++iter) {
+    {
+      int nb = 0;
+      if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
+      bn = __builtin_amdgcn_readfirstlane(nb);
+    }
+    SB_STAMP(0);
+    unsigned long long amapw[kASlots]; // issued here, used by the A pass: the setup hides the latency
+    {
+      const int o = opaque(0);
+#pragma unroll
+      for (int g = 0; g < kASlots; ++g) amapw[g] = amap[o + g * 64];
+      x.voff = (unsigned)opaque(lane * 8);
+      x.wn = class_word<NR>(x); // the first two class words of the ramp-up
+      x.voff += 512u;
+      x.wnn = class_word<NR>(x);
+    }
+    double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 64; // [T][NR]
+    __builtin_amdgcn_sched_barrier(0);
+    const double t_now = nx_tnow;
+    // exterior-space cells outside the trim box all become t_now in the first sweep
+    // (simulator.py:256-258); their largest |delta| follows from their extreme values
+    const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0;
+    if (lane < kTS) gtab[lane] = nx_g;
+#pragma unroll
+    for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (t < a.T && tail_col(lane, k) < NR) tE[t * kRow + 2 + tail_col(lane, k)] = nx_tail[t][k];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(1);
+    double At[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // A of the lane's tail cells
+#pragma unroll
+    for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (t < a.T) {
+          const double tp = tE[t * kRow + 2 + min(tail_col(lane, k), NR - 1)];
+          const int c8 = (tcls8[t] >> (8 * k)) & 0xff;
+          At[t][k] = fma(*(const double *)((const char *)tap + c8), tp, *(const double *)((const char *)gtab + c8));
+        }
+
+    // A = ap*Tprev + g for every cell of the lane's row (E = Tprev before the first sweep); slot j
+    // goes to position (j + 1) mod NR of the lane's row
+    double Areg[kNAR];
+    Areg[0] = 0.0;
+    {
+      const unsigned long long(&cwa)[kASlots] = amapw;
+      double *Aw = A + (size_t)R * kAS;
+      // groups of 8, software-pipelined: the table reads of group g+1 are issued before the A
+      // values of group g are written (the compiler cannot prove that A and the tables do not alias)
+      constexpr int kGroups = (NR + 7) / 8;
+      double ap[2][8], gg[2][8];
+      auto fetch = [&](int g, double (&pa)[8], double (&pg)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = min(8 * g + k, NR - 1);
+          const int c8 = (int)((cwa[j >> 3] >> (8 * (j & 7))) & 0xffull);
+          pa[k] = *(const double *)((const char *)tap + c8);
+          pg[k] = *(const double *)((const char *)gtab + c8);
+        }
+      };
+      fetch(0, ap[0], gg[0]);
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        if (g + 1 < kGroups) fetch(g + 1, ap[(g + 1) & 1], gg[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (8 * g + k < NR) {
+            const double av = fma(ap[g & 1][k], e[8 * g + k], gg[g & 1][k]);
+            const int q = (8 * g + k + 1) % NR;
+            if (q < kNL) Aw[q] = av;
+            else Areg[q - kNL] = av;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(2);
+
+    int n_sweeps = 0, converged = 0;
+    {
+      PairBuf pb[2];
+      Acc acc;
+      acc.cur = 0.0; acc.neg = 0.0; acc.sg = lane == 0 ? (int)0x80000000 : 0;
+      double bk[kWin];
+      // step 0 (lane 0, column 0) on its own: pairs start at odd steps
+      {
+        const lds_d2 ct = step_set<NR, 0>(x);
+        const d2 ud = ct[0], lr = ct[1];
+        load_first<NR, 1, true>(pb[0], x, Areg);
+        load_second<NR, 2>(pb[0], x);
+        step<NR, 0>(e, bk, ud, lr, x.Arow[1], 0.0, acc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      roll_pairs<NR, 1, kWin, kWin>(e, bk, Areg, pb, x, acc); // ramp-up; reads ahead for pair 63
+      pb[1].sm = *(const d2 *)(x.seam + kWin);
+#pragma nounroll
+      for (;;) { // simulator.py:348-368
+        __builtin_amdgcn_sched_barrier(0);
+#define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 10 && n_sweeps == 1 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+        SB_STAMP2(10);
+        roll_pairs<NR, kWin, NR + kWin, kWin>(e, bk, Areg, pb, x, acc);
+        SB_STAMP2(11);
+        if (lane == 63) { // row 63 is still in sweep k: its new values for the tail scan, column c in slot c + 63
+#pragma unroll
+          for (int c = 0; c < NR; ++c) r63[c] = e[(c + 63) % NR];
+        }
+        __builtin_amdgcn_wave_barrier();
+        SB_STAMP2(12);
+        const double dm = fmax(acc.cur, tail_pass<NR>(a.T, lane, tE, r63, tset, At));
+        SB_STAMP2(13);
+        double md = wave_max(dm);
+        if (n_sweeps == 0) md = fmax(md, ring_d);
+        SB_STAMP2(14);
+        ++n_sweeps;
+        converged = md <= p.conv_threshold;
+        if (converged || n_sweeps >= p.iter_limit) {
+          roll_back<NR, 0>(e, bk); // undo the started sweep
+          break;
+        }
+        pb[1].sm = *(const d2 *)(x.seam + kWin); // after the tail scan: the first tail row's new values
+        acc.cur = -acc.neg;
+        acc.neg = 0.0;
+        acc.sg = lane == 0 ? (int)0x80000000 : 0;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(3);
+    SB_STAMP(4);
+
+    // grid back to HBM.  Zone sums (A is dead now): every lane adds its cells into its own
+    // column of zs[zone][row]; row Z collects every cell outside a zone, so that the sum of all
+    // rows is the grid sum.
+    double *zs = A;
+    const int ZRS = a.ZRS;
+    {
+      unsigned long long zwv[kZSlots]; // zone-sum offsets: loaded while the row is stored
+      {
+        const int o = opaque(0);
+#pragma unroll
+        for (int g = 0; g < kZSlots; ++g) zwv[g] = zmap[o + g * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      double *tp = a.temp + (size_t)b * a.state_doubles;
+      for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + R] = 0.0;
+      __builtin_amdgcn_wave_barrier();
+      for (int t = 0; t < a.T; ++t) // the tail rows hold no zone cells (sb_create checks): all into row Z
+        for (int c = lane; c < NR; c += 64) {
+          const double tv = tE[t * kRow + 2 + c];
+          Ttail[t * NR + c] = tv;
+          __hip_atomic_fetch_add(zs + (size_t)a.Z * ZRS + lane, tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      const double *np_ = a.temp + (size_t)(bn < a.B ? bn : b) * a.state_doubles;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) { // store, zone add and the next building's load slot by slot
+        const unsigned off = (unsigned)((zwv[j >> 2] >> (16 * (j & 3))) & 0xffffull);
+        tp[R] = e[j];
+        tp += RS;
+        __hip_atomic_fetch_add((double *)((char *)zs + off), e[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        e[j] = np_[R];
+        np_ += RS;
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(5);
+    if (bn < a.B) SB_LOAD_AUX(bn);
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(6);
+    __builtin_amdgcn_wave_barrier();
+    SB_STAMP(7);
+
+    { // hand the zone sums, the grid sum and the sweep count to k_post
+      // 16 zones x 4 row groups per pass: lane (zone = lane & 15, group = lane >> 4) adds every
+      // fourth row of its zone, two xor-shuffles combine the groups
+      double gacc = 0.0;
+      for (int zb = 0; zb <= a.Z; zb += 16) {
+        const int zz = zb + (lane & 15), g = lane >> 4;
+        double v = 0.0;
+        if (zz <= a.Z)
+          for (int r = g; r < RS; r += 4) v += zs[(size_t)zz * ZRS + r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16 && zz < a.Z) a.zsum[(size_t)b * a.Z + zz] = v;
+        if (lane < 16 && zz <= a.Z) gacc += v;
+      }
+      const double gsum = wave_sum(gacc);
+      if (lane == 0) {
+        a.gsum[b] = gsum + (double)a.n_ring * t_now;
+        a.nsw[b] = n_sweeps | (converged << 16);
+      }
+      SB_STAMP(8);
+      if (a.dbg && blockIdx.x == 0 && iter == 10 && lane == 0) a.dbg[9] = n_sweeps;
+    }
+  }
+#undef SB_STAMP
+#undef SB_LOAD_AUX
+}
+
+} // namespace
+
+bool sweep_roll_supported(int NR) { return NR == 96; }
+int sweep_roll_lds_slots(int NR) { return lds_slots(NR); }
+int sweep_roll_a_stride(int NR) { return a_stride(NR); }
+int sweep_roll_seam_doubles(int NR, int T) { return (NR + 2 * kSeamPad + T * tail_row(NR) + 1) & ~1; }
+
+int prepare_sweep_roll(const Dev &d) {
+  if (d.NR != 96) return (int)hipErrorInvalidValue;
+  return (int)hipFuncSetAttribute((const void *)k_sweep_roll<96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  d.lds_reg_bytes);
+}
+
+int launch_sweep_roll(const Dev &d, hipStream_t stream) {
+  if (d.NR != 96) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((k_sweep_roll<96>), dim3(d.sweep_wgs), dim3(64), (size_t)d.lds_reg_bytes, stream, d);
+  return (int)hipGetLastError();
+}
+
+} // namespace sb
