@@ -266,6 +266,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
     r.r_xchg = off; off += 8;
     r.AS = AS;
     r.lds_bytes = off * 8;
+    if (const char *pad = getenv("SBSIM_DEBUG_LDS_PAD")) r.lds_bytes += atoi(pad); // developer knob: fewer buildings per CU
     // workgroups per CU: LDS, and the registers (4 SIMDs x wavefronts per SIMD / wavefronts per building)
     const int by_regs = P == 3 ? 4 : 4 * sweep_reg_waves_per_simd(NR, P) / (P == 2 ? 2 : 1);
     r.wg_per_cu = std::min(by_regs, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule));

@@ -32,7 +32,7 @@ namespace sb {
 namespace {
 
 #ifndef SB_ONE_WAIT
-#define SB_ONE_WAIT 0
+#define SB_ONE_WAIT 1
 #endif
 constexpr int kWin = 63;      // steps of a period in which the lanes are in two different sweeps
 constexpr int kTailMax = 2;
@@ -42,8 +42,8 @@ constexpr int kSeamPad = 8;
 // Slots of A = ap*Tprev + g kept in LDS (the rest: AGPRs).  70 of 96: a building needs 39.9 KB of
 // LDS, so four buildings -- one per SIMD -- share a CU.  Even (pairs), and the row stride
 // (= this) is 2 mod 4 doubles: rows are 16-byte aligned and 16 lanes' ds_read_b128 cover all banks.
-constexpr int lds_slots(int NR) { return NR == 96 ? 70 : ((NR / 2) % 2 ? NR : NR + 2); }
-constexpr int a_stride(int NR) { return NR == 96 ? 70 : ((NR / 2) % 2 ? NR : NR + 2); }
+constexpr int lds_slots(int NR) { return NR == 96 ? 74 : ((NR / 2) % 2 ? NR : NR + 2); }
+constexpr int a_stride(int NR) { return NR == 96 ? 74 : ((NR / 2) % 2 ? NR : NR + 2); }
 constexpr int tail_row(int NR) { return NR + 4; } // tail rows in LDS: column c at [2 + c], zero guards around
 
 __device__ __forceinline__ int opaque(int v) {
@@ -87,6 +87,10 @@ struct Acc {
   double cur; // max |delta| of the sweep the lanes are finishing
   double neg; // -(max |delta|) of the sweep the lanes have started (window steps)
   int sg;     // 0x80000000 in the lanes that have started the next sweep
+  // Row 63's new values on their way to the tail scan (lanes = columns there): lane 63's result of
+  // the previous step reaches lane 0 as its "upper neighbour" (wave_ror; row 0's bU is 0), from
+  // where two shift registers -- even / odd columns -- carry it one lane further per insertion.
+  double sre, sro;
 };
 
 
@@ -159,9 +163,13 @@ __device__ __forceinline__ void step(double (&e)[NR], double (&bk)[kWin], d2 ud,
   double t;
   asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t) : "v"(ud.y), "v"(Dn), "v"(A));
   t = fma(lr.y, e[rp], t);
-  const double U = wave_shift1<0x138, false>(e[rm], 0.0);
+  const double U = wave_shift1<0x13c, false>(e[rm], 0.0); // wave_ror:1: lane 0 sees row 63's latest value (times bU = 0)
   t = fma(lr.x, e[rm], t);
   const double nv = fma(ud.x, U, t);
+  if constexpr (S > kWin) { // lane 0's U is column S - 64 of row 63: into the shift register of its parity
+    double &sr = (S - kWin - 1) % 2 == 0 ? acc.sre : acc.sro;
+    sr = wave_shift1<0x138, true>(sr, U);
+  }
   if constexpr (S < kWin) {
     const double sel = lanes_upto<S>() ? nv : e[r];
     acc.cur = fmax(acc.cur, fabs(sel - e[r]));
@@ -185,22 +193,29 @@ __device__ __forceinline__ void step(double (&e)[NR], double (&bk)[kWin], d2 ud,
   }
 }
 
-// Pairs S, S + 2, .. < S1 (S odd).  While pair S runs, the LDS reads of pair S + 2 are issued in
-// two halves (the registers of step S are free for the second half); the last pair reads ahead for
-// pair SNEXT (its seam values are read by the caller, after the tail scan).  One s_waitcnt per
-// pair: it stands before the first half is issued and covers the previous pair's second half.
-template <int NR, int S, int S1, int SNEXT, int NAR>
+// Pairs S, S + 2, .. < S1 (S odd).  While pair S runs, the LDS reads of pair S + 2 * kDepth are
+// issued in two halves; in the main loop (WRAP) the last kDepth pairs read ahead for the next
+// period's first pairs (whose seam values the caller reads after the tail scan).
+#ifndef SB_DEPTH
+#define SB_DEPTH 1
+#endif
+constexpr int kDepth = SB_DEPTH;          // pairs between the LDS reads of a step and its arithmetic
+constexpr int kBufs = kDepth + 1;         // 48 pairs per period: kBufs must divide 48
+static_assert(48 % kBufs == 0, "pair buffers rotate through a whole period");
+constexpr int pair_buf(int S) { return ((S - 1) / 2) % kBufs; }
+
+template <int NR, int S, int S1, bool WRAP, int NAR>
 __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], const double (&Areg)[NAR],
-                                           PairBuf (&pb)[2], Ctx<NR> &x, Acc &acc) {
+                                           PairBuf (&pb)[kBufs], Ctx<NR> &x, Acc &acc) {
   if constexpr (S < S1) {
-    constexpr bool last = S + 2 >= S1;
-    constexpr int N = last ? SNEXT : S + 2;
-    PairBuf &cur = pb[((S - 1) / 2) & 1], &nxt = pb[((S + 1) / 2) & 1];
+    constexpr bool wrapped = WRAP && S + 2 * kDepth >= S1;
+    constexpr int N = wrapped ? S + 2 * kDepth - NR : S + 2 * kDepth;
+    PairBuf &cur = pb[pair_buf(S)], &nxt = pb[pair_buf(N)];
 #if SB_ONE_WAIT // one s_waitcnt per pair: measured slower (the second half's reads are only one step old)
     asm volatile("" ::"v"(cur.ud0.x), "v"(cur.A.x), "v"(cur.sm.x), "v"(cur.ud1.x), "v"(cur.lr1.x));
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    load_first<NR, N, !last>(nxt, x, Areg);
+    load_first<NR, N, !wrapped>(nxt, x, Areg);
     __builtin_amdgcn_sched_barrier(0);
     step<NR, S>(e, bk, cur.ud0, cur.lr0, cur.A.x, cur.sm.x, acc);
     __builtin_amdgcn_sched_barrier(0);
@@ -208,15 +223,29 @@ __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], 
     __builtin_amdgcn_sched_barrier(0);
     step<NR, S + 1>(e, bk, cur.ud1, cur.lr1, cur.A.y, cur.sm.y, acc);
     __builtin_amdgcn_sched_barrier(0);
-    roll_pairs<NR, S + 2, S1, SNEXT>(e, bk, Areg, pb, x, acc);
+    roll_pairs<NR, S + 2, S1, WRAP>(e, bk, Areg, pb, x, acc);
   }
 }
 
+// The end of a building's step, slot by slot: undo the started sweep (lanes <= J restore slot J
+// from the window's copies), store the slot, add it to its zone sum (LDS), load the same slot of
+// the next building.  The loop runs at the pace of the memory pipe; the restores cost nothing there.
+// zw: the zone-sum offsets, four slots per word, read kZA words (32 slots = 64 memory
+// operations) ahead: memory operations return in order, so waiting for a word that is only a few
+// slots old would drain the queue of row loads in front of it.
+constexpr int kZA = 8;
 template <int NR, int J>
-__device__ __forceinline__ void roll_back(double (&e)[NR], const double (&bk)[kWin]) {
-  if constexpr (J < kWin) {
-    e[J] = lanes_upto<J>() ? bk[J] : e[J];
-    roll_back<NR, J + 1>(e, bk);
+__device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kWin], unsigned long long (&zw)[kZA + 1],
+                                          const unsigned long long *zmap, double *tp, const double *np_, double *zs) {
+  if constexpr (J < NR) {
+    if constexpr (J % 4 == 0 && J / 4 + kZA < (NR + 3) / 4) zw[(J / 4 + kZA) % (kZA + 1)] = zmap[(J / 4 + kZA) * 64];
+    if constexpr (J < kWin) e[J] = lanes_upto<J>() ? bk[J] : e[J];
+    const unsigned off = (unsigned)((zw[(J / 4) % (kZA + 1)] >> (16 * (J & 3))) & 0xffffull);
+    tp[J * 64] = e[J];
+    __hip_atomic_fetch_add((double *)((char *)zs + off), e[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    e[J] = np_[J * 64];
+    if constexpr ((J & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    hand_over<NR, J + 1>(e, bk, zw, zmap, tp, np_, zs);
   }
 }
 
@@ -246,45 +275,47 @@ __device__ __forceinline__ void affine_scan(double &a, double &q) {
   scan_step<0x143, 0xc>(a, q); // row_bcast:31 -> rows 2 and 3
 }
 
-// A lane owns two neighbouring columns of a tail row: NR <= 128 columns are one 64-lane scan.
-__device__ __forceinline__ int tail_col(int lane, int k) { return 2 * lane + k; }
+// A lane owns two neighbouring columns of a tail row: NR <= 128 columns are one 64-lane scan.  The
+// columns sit in the TOP lanes (that is where the shift registers deliver row 63): lane l owns
+// columns 2 (l - L0), 2 (l - L0) + 1 with L0 = 64 - NR / 2.
+template <int NR>
+__device__ __forceinline__ int tail_col(int lane, int k) { return 2 * (lane - (64 - NR / 2)) + k; }
 
-// One Gauss-Seidel pass over the tail rows; returns the lane's max |delta|.
-// tE: [T][NR + 4] current values (column c at [2 + c]); r63: new values of row 63 by column.
-// The lane first composes the maps of its two columns (x_{2l+1} = bL1*(bL0*x + q0) + q1), the
-// scan runs over the 64 composed maps, and the even column follows from its left neighbour.
+// One Gauss-Seidel pass over the tail rows; returns the lane's max |delta|.  The rows' current
+// values live in registers (tv[t][k]: the lane's two cells of tail row t); U0 / U1: row 63's new
+// values above them; the first tail row also goes to LDS (tE0, by column: lane 63 reads it as its
+// lower neighbour during the next sweep).  The lane first composes the maps of its two columns
+// (x_{2l+1} = bL1*(bL0*x + q0) + q1), the scan runs over the 64 composed maps, and the even column
+// follows from its left neighbour.  Lanes without columns use the pad set (all zero).
 // tset[t]: byte offsets of the lane's two cells' coefficient sets in the table (low / high half).
 template <int NR>
-__device__ __forceinline__ double tail_pass(int T, int lane, double *tE, const double *r63,
-                                            const int (&tset)[kTailMax], const double (&At)[kTailMax][2]) {
-  constexpr int kRow = tail_row(NR);
+__device__ __forceinline__ double tail_pass(int T, bool active, double *tE0c, double U0, double U1,
+                                            double (&tv)[kTailMax][2], const int (&tset)[kTailMax],
+                                            const double (&At)[kTailMax][2]) {
   static_assert(NR % 2 == 0 && NR <= 128, "two columns per lane");
-  const bool active = 2 * lane < NR;
-  const int c0 = active ? 2 * lane : NR - 2;
   double dmax = 0.0;
 #pragma unroll
   for (int t = 0; t < kTailMax; ++t) {
     if (t < T) {
-      double *row = tE + t * kRow + 2;
       const lds_d2 s0 = (lds_d2)(unsigned)(tset[t] & 0xffff), s1 = (lds_d2)((unsigned)tset[t] >> 16);
       const d2 ud0 = s0[0], lr0 = s0[1], ud1 = s1[0], lr1 = s1[1];
-      const d2 old = *(const d2 *)(row + c0); // 16-byte aligned: c0 even, row base even
-      const double R1 = row[c0 + 2];
-      const d2 Uv = *(const d2 *)((t == 0 ? r63 : row - kRow) + c0);
-      d2 Dv = d2{0.0, 0.0};
-      if (t + 1 < T) Dv = *(const d2 *)(row + kRow + c0);
-      const double q0 = fma(ud0.x, Uv.x, fma(lr0.y, old.y, fma(ud0.y, Dv.x, At[t][0]))); // right neighbour: not yet updated
-      const double q1 = fma(ud1.x, Uv.y, fma(lr1.y, R1, fma(ud1.y, Dv.y, At[t][1])));
+      const double old0 = tv[t][0], old1 = tv[t][1];
+      const double R1 = wave_shift1<0x130, false>(old0, 0.0); // the next lane's first column (not yet updated)
+      const double D0 = t + 1 < T ? tv[t + 1 < kTailMax ? t + 1 : t][0] : 0.0, D1 = t + 1 < T ? tv[t + 1 < kTailMax ? t + 1 : t][1] : 0.0;
+      const double q0 = fma(ud0.x, U0, fma(lr0.y, old1, fma(ud0.y, D0, At[t][0]))); // right neighbour: not yet updated
+      const double q1 = fma(ud1.x, U1, fma(lr1.y, R1, fma(ud1.y, D1, At[t][1])));
       double a = lr1.x * lr0.x, Q = fma(lr1.x, q0, q1);
       affine_scan(a, Q); // Q: the odd column (the row starts from bL = 0: no carry-in)
-      const double xl = wave_shift1<0x138, false>(Q, 0.0); // column 2l - 1
+      const double xl = wave_shift1<0x138, false>(Q, 0.0); // the column to the left of the lane's first
       const double x0 = fma(lr0.x, xl, q0);
-      __builtin_amdgcn_wave_barrier(); // every read of the row's old values is done
       if (active) {
-        dmax = fmax(dmax, fmax(fabs(x0 - old.x), fabs(Q - old.y)));
-        *(d2 *)(row + c0) = d2{x0, Q};
+        dmax = fmax(dmax, fmax(fabs(x0 - old0), fabs(Q - old1)));
+        tv[t][0] = x0;
+        tv[t][1] = Q;
+        if (t == 0) *(d2 *)tE0c = d2{x0, Q}; // 16-byte aligned: even column, even row base
       }
-      __builtin_amdgcn_wave_barrier(); // the next row reads this one
+      U0 = x0; // the next tail row's upper neighbours
+      U1 = Q;
     }
   }
   return dmax;
@@ -297,14 +328,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const int lane = threadIdx.x & 63;
   constexpr int kASlots = (NR + 7) / 8, kZSlots = (NR + 3) / 4;
   constexpr int kNL = lds_slots(NR), kAS = a_stride(NR), kNAR = NR - kNL > 0 ? NR - kNL : 2;
-  constexpr int kRow = tail_row(NR);
 
   double *tabc = lds;                      // [kTS][4]: bU bD bL bR per coefficient set
   double *tap = lds + 4 * kTS;             // [kTS] ap by class
   double *gtab = lds + 5 * kTS;            // [kTS] g by class (this building)
-  double *seamD = lds + a.r_seam;          // [pad | r63: NR | pad][tE: T x (NR + 4)]
-  double *r63 = seamD + kSeamPad;          // new values of row 63, by column
-  double *tE = seamD + NR + 2 * kSeamPad;  // tail rows, column c at [t*(NR+4) + 2 + c]
+  double *tE0 = lds + a.r_seam + 2;        // the first tail row by column ([2 guards | NR | 2 guards]): lane 63's lower neighbours
   double *A = lds + a.r_A;                 // [64][kAS]; after the sweeps: zone sums [Z+1][ZRS]
   // every byte of LDS starts finite: reads next to the arrays' ends are multiplied by 0
   for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0;
@@ -319,19 +347,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   if ((unsigned)(size_t)(__attribute__((address_space(3))) double *)tabc != 0u) __builtin_trap(); // class words hold LDS addresses
   Ctx<NR> x;
   x.Arow = A + (size_t)R * kAS;
-  x.seam = tE + 2 - kWin; // lane 63 works on column s - 63 at step s
+  x.seam = tE0 - kWin; // lane 63 works on column s - 63 at step s
   x.cmap = (const char *)a.cmapS;
   x.voff = 0;
   x.w = x.wn = x.wnn = 0;
   // the lane's tail cells (static per floor plan): table offsets of their coefficient sets
   // (two 16-bit halves) and of their classes (two bytes)
+  const bool tactive = tail_col<NR>(lane, 0) >= 0; // the lane owns two tail columns
+  const int tc0 = tactive ? tail_col<NR>(lane, 0) : 0;
   int tset[kTailMax], tcls8[kTailMax];
 #pragma unroll
   for (int t = 0; t < kTailMax; ++t) {
-    tset[t] = 0;
+    tset[t] = (a.ncset - 1) * 32 * 0x10001; // the pad set (the table's last): no neighbour counts
     tcls8[t] = (8 * a.ncls) | ((8 * a.ncls) << 8);
-    if (t < a.T) {
-      const int c0 = min(tail_col(lane, 0), NR - 1), c1 = min(tail_col(lane, 1), NR - 1);
+    if (t < a.T && tactive) {
+      const int c0 = tc0, c1 = tc0 + 1;
       tset[t] = ((int)a.tcset[t * NR + c0] << 2) | ((int)a.tcset[t * NR + c1] << 18); // set * 8 -> set * 32
       tcls8[t] = (int)a.tcls[t * NR + c0] | ((int)a.tcls[t * NR + c1] << 8);
     }
@@ -355,7 +385,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     const double *tt_ = a.temp + (size_t)(bb) * a.state_doubles + NR * 64;                      \
     _Pragma("unroll") for (int t = 0; t < kTailMax; ++t)                                        \
       _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
-        if (t < a.T) nx_tail[t][k] = tt_[t * NR + min(tail_col(lane, k), NR - 1)];              \
+        if (t < a.T) nx_tail[t][k] = tt_[t * NR + tc0 + k];                                     \
   } while (0)
   if ((int)blockIdx.x < a.B) {
     const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles;
@@ -393,11 +423,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // (simulator.py:256-258); their largest |delta| follows from their extreme values
     const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0;
     if (lane < kTS) gtab[lane] = nx_g;
+    double tv[kTailMax][2]; // the lane's tail cells: current values
 #pragma unroll
     for (int t = 0; t < kTailMax; ++t)
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if (t < a.T && tail_col(lane, k) < NR) tE[t * kRow + 2 + tail_col(lane, k)] = nx_tail[t][k];
+      for (int k = 0; k < 2; ++k) tv[t][k] = nx_tail[t][k];
+    if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(1);
@@ -406,10 +437,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     for (int t = 0; t < kTailMax; ++t)
 #pragma unroll
       for (int k = 0; k < 2; ++k)
-        if (t < a.T) {
-          const double tp = tE[t * kRow + 2 + min(tail_col(lane, k), NR - 1)];
+        if (t < a.T && tactive) {
           const int c8 = (tcls8[t] >> (8 * k)) & 0xff;
-          At[t][k] = fma(*(const double *)((const char *)tap + c8), tp, *(const double *)((const char *)gtab + c8));
+          At[t][k] = fma(*(const double *)((const char *)tap + c8), tv[t][k], *(const double *)((const char *)gtab + c8));
         }
 
     // A = ap*Tprev + g for every cell of the lane's row (E = Tprev before the first sweep); slot j
@@ -453,47 +483,60 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     SB_STAMP(2);
 
     int n_sweeps = 0, converged = 0;
+    double bk[kWin]; // the window's copies: what the started sweep overwrote
     {
-      PairBuf pb[2];
+      PairBuf pb[kBufs];
       Acc acc;
       acc.cur = 0.0; acc.neg = 0.0; acc.sg = lane == 0 ? (int)0x80000000 : 0;
-      double bk[kWin];
+      acc.sre = acc.sro = 0.0;
       // step 0 (lane 0, column 0) on its own: pairs start at odd steps
       {
         const lds_d2 ct = step_set<NR, 0>(x);
         const d2 ud = ct[0], lr = ct[1];
-        load_first<NR, 1, true>(pb[0], x, Areg);
-        load_second<NR, 2>(pb[0], x);
+        load_first<NR, 1, true>(pb[pair_buf(1)], x, Areg);
+        load_second<NR, 2>(pb[pair_buf(1)], x);
+        if constexpr (kDepth > 1) {
+          load_first<NR, 3, true>(pb[pair_buf(3)], x, Areg);
+          load_second<NR, 4>(pb[pair_buf(3)], x);
+        }
+        static_assert(kDepth <= 2, "initial fill of the pair buffers");
         step<NR, 0>(e, bk, ud, lr, x.Arow[1], 0.0, acc);
       }
       __builtin_amdgcn_sched_barrier(0);
-      roll_pairs<NR, 1, kWin, kWin>(e, bk, Areg, pb, x, acc); // ramp-up; reads ahead for pair 63
-      pb[1].sm = *(const d2 *)(x.seam + kWin);
+      roll_pairs<NR, 1, kWin, false>(e, bk, Areg, pb, x, acc); // ramp-up; reads ahead for the first pairs of the period
 #pragma nounroll
       for (;;) { // simulator.py:348-368
         __builtin_amdgcn_sched_barrier(0);
 #define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 10 && n_sweeps == 1 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
         SB_STAMP2(10);
-        roll_pairs<NR, kWin, NR + kWin, kWin>(e, bk, Areg, pb, x, acc);
+        roll_pairs<NR, kWin, NR + kWin, true>(e, bk, Areg, pb, x, acc);
         SB_STAMP2(11);
-        if (lane == 63) { // row 63 is still in sweep k: its new values for the tail scan, column c in slot c + 63
-#pragma unroll
-          for (int c = 0; c < NR; ++c) r63[c] = e[(c + 63) % NR];
+        // row 63's last column (lane 63's result of the period's last step) enters its shift register;
+        // then both are reversed: lane l holds columns 2 (l - L0), 2 (l - L0) + 1, the tail scan's layout
+        double U0, U1;
+        {
+          constexpr int last = (NR + kWin - 1) % NR;
+          const double ul = wave_shift1<0x13c, false>(e[last], 0.0);
+          double &sr = (NR - 1) % 2 == 0 ? acc.sre : acc.sro;
+          sr = wave_shift1<0x138, true>(sr, ul);
+          const int rev = (63 - lane) * 4;
+          U0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(rev, __double2hiint(acc.sre)),
+                                __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sre)));
+          U1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(rev, __double2hiint(acc.sro)),
+                                __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sro)));
         }
-        __builtin_amdgcn_wave_barrier();
         SB_STAMP2(12);
-        const double dm = fmax(acc.cur, tail_pass<NR>(a.T, lane, tE, r63, tset, At));
+        const double dm = fmax(acc.cur, tail_pass<NR>(a.T, tactive, tE0 + tc0, U0, U1, tv, tset, At));
         SB_STAMP2(13);
         double md = wave_max(dm);
         if (n_sweeps == 0) md = fmax(md, ring_d);
         SB_STAMP2(14);
         ++n_sweeps;
         converged = md <= p.conv_threshold;
-        if (converged || n_sweeps >= p.iter_limit) {
-          roll_back<NR, 0>(e, bk); // undo the started sweep
-          break;
-        }
-        pb[1].sm = *(const d2 *)(x.seam + kWin); // after the tail scan: the first tail row's new values
+        if (converged || n_sweeps >= p.iter_limit) break; // the started sweep is undone while the row is stored
+        // after the tail scan: the first tail row's new values under lane 63, for the pairs already read ahead
+        pb[pair_buf(kWin)].sm = *(const d2 *)(x.seam + kWin);
+        if constexpr (kDepth > 1) pb[pair_buf(kWin + 2)].sm = *(const d2 *)(x.seam + kWin + 2);
         acc.cur = -acc.neg;
         acc.neg = 0.0;
         acc.sg = lane == 0 ? (int)0x80000000 : 0;
@@ -509,33 +552,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     double *zs = A;
     const int ZRS = a.ZRS;
     {
-      unsigned long long zwv[kZSlots]; // zone-sum offsets: loaded while the row is stored
-      {
-        const int o = opaque(0);
+      unsigned long long zw[kZA + 1]; // zone-sum offsets, four slots per word
+      const unsigned long long *zm = zmap + opaque(0);
 #pragma unroll
-        for (int g = 0; g < kZSlots; ++g) zwv[g] = zmap[o + g * 64];
-      }
+      for (int g = 0; g < kZA; ++g) zw[g] = zm[g * 64];
       __builtin_amdgcn_sched_barrier(0);
       double *tp = a.temp + (size_t)b * a.state_doubles;
       for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + R] = 0.0;
       __builtin_amdgcn_wave_barrier();
-      for (int t = 0; t < a.T; ++t) // the tail rows hold no zone cells (sb_create checks): all into row Z
-        for (int c = lane; c < NR; c += 64) {
-          const double tv = tE[t * kRow + 2 + c];
-          Ttail[t * NR + c] = tv;
-          __hip_atomic_fetch_add(zs + (size_t)a.Z * ZRS + lane, tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int t = 0; t < kTailMax; ++t) // the tail rows hold no zone cells (sb_create checks): all into row Z
+        if (t < a.T && tactive) {
+          *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
+          zs[(size_t)a.Z * ZRS + lane] += tv[t][0] + tv[t][1]; // the lane's own column of the scratch
         }
       const double *np_ = a.temp + (size_t)(bn < a.B ? bn : b) * a.state_doubles;
-#pragma unroll
-      for (int j = 0; j < NR; ++j) { // store, zone add and the next building's load slot by slot
-        const unsigned off = (unsigned)((zwv[j >> 2] >> (16 * (j & 3))) & 0xffffull);
-        tp[R] = e[j];
-        tp += RS;
-        __hip_atomic_fetch_add((double *)((char *)zs + off), e[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        e[j] = np_[R];
-        np_ += RS;
-        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-      }
+      static_assert(RS == 64, "hand_over: slot stride");
+      hand_over<NR, 0>(e, bk, zw, zm, tp + R, np_ + R, zs);
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(5);
@@ -577,7 +610,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 bool sweep_roll_supported(int NR) { return NR == 96; }
 int sweep_roll_lds_slots(int NR) { return lds_slots(NR); }
 int sweep_roll_a_stride(int NR) { return a_stride(NR); }
-int sweep_roll_seam_doubles(int NR, int T) { return (NR + 2 * kSeamPad + T * tail_row(NR) + 1) & ~1; }
+int sweep_roll_seam_doubles(int NR, int T) { (void)T; return tail_row(NR); } // the first tail row, by column
 
 int prepare_sweep_roll(const Dev &d) {
   if (d.NR != 96) return (int)hipErrorInvalidValue;
