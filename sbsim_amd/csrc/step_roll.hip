@@ -584,9 +584,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       double gacc = 0.0;
       for (int zb = 0; zb <= a.Z; zb += 16) {
         const int zz = zb + (lane & 15), g = lane >> 4;
+        const double *zr = zs + (size_t)(zz <= a.Z ? zz : a.Z) * ZRS + g;
+        double part[RS / 4];
+#pragma unroll
+        for (int k = 0; k < RS / 4; ++k) part[k] = zr[4 * k]; // sixteen independent reads, then one wait
         double v = 0.0;
-        if (zz <= a.Z)
-          for (int r = g; r < RS; r += 4) v += zs[(size_t)zz * ZRS + r];
+#pragma unroll
+        for (int k = 0; k < RS / 4; ++k) v += part[k];
+        if (zz > a.Z) v = 0.0;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (lane < 16 && zz < a.Z) a.zsum[(size_t)b * a.Z + zz] = v;
