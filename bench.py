@@ -20,6 +20,8 @@ import argparse
 import datetime as dt
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -120,6 +122,64 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
               single_thread_value=(nb * zones / float(min(single_times)) if single_times else None)), grids, n_steps, nb
 
 
+def launch_ranks_if_needed(args) -> None:
+  """`python bench.py --gpus N` outside torchrun: re-executes itself as N ranks under
+  torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and exits with the
+  launcher's status.  Under torchrun (WORLD_SIZE set) the world size must equal --gpus."""
+  world_env = os.environ.get("WORLD_SIZE")
+  if world_env is not None:
+    if int(world_env) != args.gpus:
+      raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+    return
+  if args.gpus <= 1:
+    return
+  with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+  raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def stub_rank(args) -> None:
+  """The launcher / barrier / max-over-ranks / return-gather plumbing with a stub step and the
+  gloo backend: what tests/test_bench_launcher.py runs on CPU (no GPU, no HIP library)."""
+  import torch.distributed as dist
+  rank, _, world = sd.env_rank_world()
+  distributed = sd.init_process_group("gloo")
+  if distributed:
+    assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+  dev = torch.device("cpu")
+  B, K, W = args.buildings, args.steps, args.warmup
+  lo, hi = sd.shard_range(world * B, rank, world)
+  returns = torch.zeros((B,), dtype=torch.float32)
+  for _ in range(W):
+    time.sleep(1e-3)
+  if distributed:
+    dist.barrier()
+  t0 = time.perf_counter()
+  for t in range(K):
+    time.sleep(1e-3)
+    returns += torch.arange(lo, hi, dtype=torch.float32)
+  if distributed:
+    dist.barrier()
+  elapsed = sd.max_over_ranks(time.perf_counter() - t0, dev)
+  g0 = time.perf_counter()
+  all_returns = sd.gather_returns(returns, world * B)
+  gather_ms = (time.perf_counter() - g0) * 1e3
+  ok = bool(torch.equal(all_returns, torch.arange(world * B, dtype=torch.float32) * K))
+  if rank == 0:
+    print(json.dumps({"metric": "stub", "value": world * B * K / elapsed, "unit": "env-steps/s", "n_gpus": world,
+                      "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stub",
+                      "return_gather_ms": gather_ms, "gathered_returns": int(all_returns.numel()),
+                      "gather_in_global_order": ok, "config": {"workload": "launcher plumbing test (stub step, gloo)"}}))
+  if distributed:
+    dist.destroy_process_group()
+
+
 def main() -> None:
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -130,13 +190,22 @@ def main() -> None:
   ap.add_argument("--iteration-limit", type=int, default=100,
                   help="Simulator.iteration_limit (100 = the reference's SB1 value; 1 is used only to "
                        "calibrate the PMC byte counters on a known traffic pattern)")
+  ap.add_argument("--stub-step", action="store_true",
+                  help="developer / CPU test: launcher, barrier and return-gather plumbing with a stub step (gloo)")
   args = ap.parse_args()
+  launch_ranks_if_needed(args)
+  if args.stub_step:
+    return stub_rank(args)
 
   rank, local_rank, world = sd.env_rank_world()
   torch.cuda.set_device(local_rank)
   distributed = sd.init_process_group("nccl")   # "nccl" is RCCL on ROCm
   if distributed:
     import torch.distributed as dist
+    if dist.get_world_size() != args.gpus:
+      raise SystemExit(f"bench.py: --gpus {args.gpus} but {dist.get_world_size()} ranks are running")
+  elif args.gpus != 1:
+    raise SystemExit(f"bench.py: --gpus {args.gpus} but only one rank is running")
   dev = torch.device("cuda", local_rank)
 
   B, K, W = args.buildings, args.steps, args.warmup
@@ -203,14 +272,15 @@ def main() -> None:
   post_ms = float(np.mean([e[1].elapsed_time(e[3]) for e in wev])) if W else None
 
   elapsed = sd.max_over_ranks(elapsed, dev)
-  gather_ms = 0.0
+  gather_ms, n_gathered = 0.0, B
   if distributed:
     torch.cuda.synchronize(dev)
     g0 = time.perf_counter()
     all_returns = sd.gather_returns(returns, world * B)   # end-of-rollout gather (RCCL / xGMI)
     torch.cuda.synchronize(dev)
     gather_ms = (time.perf_counter() - g0) * 1e3
-    assert all_returns.numel() == world * B
+    n_gathered = int(all_returns.numel())
+    assert n_gathered == world * B
 
   if rank == 0:
     li = env.sim.launch_info
@@ -224,6 +294,7 @@ def main() -> None:
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "env_steps_per_s": env_steps_per_s,
+        "return_gather_ms": gather_ms, "gathered_returns": n_gathered,   # end-of-rollout all_gather, outside the timed region
         "config": {"workload": "BASELINE.json configs[1]: 64k replicated SB1-physics buildings on floor plan R9 "
                                "(68x98 CVs, 9 zones), random setpoint actions, sinusoid weather",
                    "buildings_per_gpu": B, "grid": [H, Wd], "zones": Z,

@@ -44,8 +44,10 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 4
-#define SB_NUM_ACTIONS 2   /* boiler supply_water_setpoint, AHU supply_air_heating_temperature_setpoint */
+#define SB_ABI_VERSION 5
+#define SB_NUM_ACTIONS 2   /* the SB1 action set (sim_config.gin:239-242): boiler supply_water_setpoint, AHU
+                            * supply_air_heating_temperature_setpoint -- the default of sb_params.n_actions */
+#define SB_MAX_ACTIONS 16  /* settable fields an action vector may drive (sb_params.act_kind) */
 #define SB_NUM_AUX 7       /* hod cos/sin, dow cos/sin, comfort_now, comfort_soon, num_occupants */
 #define SB_INFO_STRIDE 24  /* floats per building in the optional info output */
 
@@ -57,6 +59,16 @@ typedef enum sb_status {
   SB_ERR_TOO_LARGE = -4,  /* one building does not fit the 160 KiB LDS of a CU */
   SB_ERR_UNSUPPORTED = -5 /* a reference option this library does not implement */
 } sb_status;
+
+/* The simulated devices' settable fields (environment.py:278-307,591-653 builds the action vector
+ * from ActionConfig over these): boiler.py:81-85, air_handler.py:97-104, vav.py:65-69. */
+typedef enum sb_action_kind {
+  SB_ACT_BOILER_SUPPLY_WATER_SETPOINT = 0,
+  SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT = 1,
+  SB_ACT_AHU_SUPPLY_AIR_COOLING_SETPOINT = 2,
+  SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND = 3 /* of zone act_zone[i]; outside [0, 1] the VAV raises: that action is
+                                            * rejected, the others apply, the step's reward is -inf */
+} sb_action_kind;
 
 typedef struct sb_handle sb_handle;
 
@@ -83,7 +95,13 @@ typedef struct sb_params {
   double comfort_lo, comfort_hi, eco_lo, eco_hi;               /* setpoint_schedule.py:51-84 */
   double max_prod, min_prod, max_elec, max_gas, prod_delta, prod_stiff; /* regret fn ctor */
   double w_prod, w_cost, w_carbon;
-  double act_lo[SB_NUM_ACTIONS], act_hi[SB_NUM_ACTIONS]; /* bounded_action_normalizer.py:73-98 */
+  /* the action vector: column i drives field act_kind[i] (of zone act_zone[i] for a VAV field) with
+   * native value (a + 1) / 2 * (act_hi[i] - act_lo[i]) + act_lo[i] (bounded_action_normalizer.py:73-98),
+   * rounded to the proto's float.  Applied in column order after the thermostats (simulator_building.py:204-263). */
+  int32_t n_actions;                 /* 1 .. SB_MAX_ACTIONS */
+  int32_t act_kind[SB_MAX_ACTIONS];  /* sb_action_kind */
+  int32_t act_zone[SB_MAX_ACTIONS];  /* zone index for SB_ACT_VAV_*; ignored otherwise */
+  double act_lo[SB_MAX_ACTIONS], act_hi[SB_MAX_ACTIONS];
 } sb_params;
 
 /* Observation vector layout (environment.py:543-553,783-813): the device fields in sorted
@@ -132,6 +150,13 @@ typedef struct sb_step_in {
   int32_t comfort_prev;    /* is_comfort_mode(previous thermostat timestamp); -1 = none */
   int32_t comfort_next;    /* is_comfort_mode(t+dt): setpoint window seen by the reward */
   int32_t has_action;      /* 0 = thermostat-only step (bare Simulator.step_sim) */
+  /* optional DEVICE [B] bytes: non-zero = this building REJECTED the step's action request (a
+   * RuntimeError out of BaseBuilding.request_action: environment.py:1266-1309,
+   * rejection_simulator_building.py:52-60).  Such a building skips setup_step_sim (its thermostats
+   * and setpoints stay as they are), steps and observes like the others, and returns reward -inf
+   * (environment.py:52).  With this pointer set, the "previous thermostat update" of comfort_prev is
+   * tracked per building on the device. */
+  const uint8_t *reject_dev;
   double occupancy;        /* average_zone_occupancy over [t+dt, t+2dt], all zones */
   const double *occupancy_dev; /* optional DEVICE [Z] per-zone occupancy; overrides */
   /* optional per-building occupancy (sb_occupancy_peek): overrides both of the above */
@@ -179,7 +204,7 @@ int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const do
 int sb_observe_occupancy(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
                          const float *num_occupants_dev, double occupancy_norm, float *obs_dev, void *stream);
 
-/* One Environment._step for every building.  actions_dev [B][2] fp32 in [-1,1] (or NULL
+/* One Environment._step for every building.  actions_dev [B][n_actions] fp32 in [-1,1] (or NULL
  * when in->has_action == 0); obs_dev [B][O] fp32; reward_dev [B] fp32; info_dev optional
  * [B][SB_INFO_STRIDE] fp32 = {blower W, air-conditioning W, gas W, pump W, sweeps,
  * converged, supply air K, reward before the fp32 store, then RewardResponse fields 2..17

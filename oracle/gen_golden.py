@@ -172,8 +172,14 @@ def obs_request(m, sb):
 
 
 def rollout_h2(m, sim, building, hvac, weather, schedule, n_steps, actions_norm, grid_steps,
-               label):
-  """Environment._step ordering without tf-agents (environment.py:1228-1309)."""
+               label, extra_actions=(), rejected_steps=()):
+  """Environment._step ordering without tf-agents (environment.py:1228-1309).
+
+  extra_actions: more columns of the action vector after the SB1 pair, as (device_id,
+  setpoint_name, (lo, hi)) -- actions_norm then has 2 + len(extra_actions) columns.
+  rejected_steps: steps at which the building rejects the whole request (a RuntimeError out of
+  request_action, rejection_simulator_building.py:52-60): Environment catches it, skips nothing
+  else, and returns reward -inf (environment.py:1266-1309)."""
   pb = m["smart_control_building_pb2"]
   cu = m["conversion_utils"]
   occ_cfg = SB1["occupancy"]
@@ -201,7 +207,7 @@ def rollout_h2(m, sim, building, hvac, weather, schedule, n_steps, actions_norm,
       "damper", "valve", "mode", "rates", "ri_zone_temp", "ri_heat_sp", "ri_cool_sp", "ri_occ",
       "reward", "rr_productivity", "rr_norm_prod_regret", "rr_norm_energy_cost",
       "rr_norm_carbon", "rr_elec_cost", "rr_gas_cost", "rr_carbon", "obs", "ts_seconds",
-      "num_occupants", "comfort_soon")}
+      "num_occupants", "comfort_soon", "rejected", "action_accepted", "action_native_all")}
   grids = {}
   # first observation at reset (environment.py:1165-1176)
   first = sb.request_observations(req)
@@ -221,8 +227,21 @@ def rollout_h2(m, sim, building, hvac, weather, schedule, n_steps, actions_norm,
     areq.single_action_requests.append(pb.SingleActionRequest(
         device_id="air_handler_id", setpoint_name="supply_air_heating_temperature_setpoint",
         continuous_value=float(native[1])))
-    resp = sb.request_action(areq)
-    assert all(r.response_type == 1 for r in resp.single_action_responses)
+    native_all = [float(native[0]), float(native[1])]
+    for j, (dev_id, sp_name, (x_lo, x_hi)) in enumerate(extra_actions):
+      v = np.float32((float(a[2 + j]) + 1.0) / 2.0 * (x_hi - x_lo) + x_lo)
+      native_all.append(float(v))
+      areq.single_action_requests.append(pb.SingleActionRequest(
+          device_id=dev_id, setpoint_name=sp_name, continuous_value=float(v)))
+    if step in rejected_steps:   # RejectionSimulatorBuilding.request_action raises before delegating
+      accepted = False
+    else:
+      resp = sb.request_action(areq)
+      accepted = all(r.response_type == 1 for r in resp.single_action_responses)   # environment.py:all_actions_accepted
+      assert accepted or extra_actions
+    rec["rejected"].append(int(step in rejected_steps))
+    rec["action_accepted"].append(int(accepted))
+    rec["action_native_all"].append(native_all)
     recirc_pre = building.temp.mean()
     t_amb_now = weather.get_current_temp(ts)
     t_sa = hvac.air_handler.get_supply_air_temp(recirc_pre, t_amb_now)
@@ -295,10 +314,13 @@ def rollout_h2(m, sim, building, hvac, weather, schedule, n_steps, actions_norm,
   out = {}
   f32 = {"rates", "ri_zone_temp", "ri_heat_sp", "ri_cool_sp", "ri_occ", "reward", "obs",
          "rr_productivity", "rr_norm_prod_regret", "rr_norm_energy_cost", "rr_norm_carbon",
-         "rr_elec_cost", "rr_gas_cost", "rr_carbon", "action_native"}
+         "rr_elec_cost", "rr_gas_cost", "rr_carbon", "action_native", "action_native_all"}
   ints = {"n_sweeps", "ahu_count", "blr_count", "mode", "comfort_now", "comfort_prev",
           "comfort_next", "comfort_soon", "hour_utc", "month", "is_workday", "ts_seconds",
-          "num_occupants"}
+          "num_occupants", "rejected", "action_accepted"}
+  if not extra_actions and not rejected_steps:   # the original fixtures keep their key set
+    for k in ("rejected", "action_accepted", "action_native_all"):
+      rec.pop(k)
   for k, v in rec.items():
     if k in f32:
       out[k] = np.asarray(v, dtype=np.float32)

@@ -67,7 +67,8 @@ class _State(C.Structure):
               ("blr_return_temp", C.c_double), ("blr_tank_temp", C.c_double),
               ("blr_tank_change", C.c_double), ("blr_last_duration", C.c_double),
               ("blr_count", C.c_int32), ("blr_has_action_ts", C.c_int32),
-              ("blr_action_ts", C.c_double), ("thermostat_has_prev", C.c_int32)]
+              ("blr_action_ts", C.c_double), ("thermostat_has_prev", C.c_int32),
+              ("thermostat_prev_comfort", C.c_int32), ("thermostat_skipped", C.c_int32)]
 
 
 class _StepIn(C.Structure):
@@ -77,7 +78,9 @@ class _StepIn(C.Structure):
               ("comfort_now", C.c_int32), ("comfort_prev", C.c_int32),
               ("comfort_next", C.c_int32), ("occupancy", _dp), ("observe", C.c_int32),
               ("e_price", C.c_double), ("e_carbon", C.c_double),
-              ("g_price", C.c_double), ("g_carbon", C.c_double)]
+              ("g_price", C.c_double), ("g_carbon", C.c_double),
+              ("reject", C.c_int32), ("has_cool_sp", C.c_int32), ("ahu_cool_sp", C.c_double),
+              ("damper_cmd", _dp)]
 
 
 class _StepOut(C.Structure):
@@ -88,7 +91,8 @@ class _StepOut(C.Structure):
               ("reward", C.c_float), ("reward_f64", C.c_double),
               ("productivity", C.c_double), ("norm_prod_regret", C.c_double),
               ("norm_energy_cost", C.c_double), ("norm_carbon", C.c_double),
-              ("zone_temp_pre", _dp), ("zone_temp_post", _dp), ("q_zone", _dp)]
+              ("zone_temp_pre", _dp), ("zone_temp_post", _dp), ("q_zone", _dp),
+              ("action_accepted", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -369,7 +373,8 @@ class OracleBuilding:
   def step(self, *, now_ts: float, t_amb_now: float, h_conv: float, t_amb_next: float,
            comfort_now: bool, comfort_prev: bool, comfort_next: bool, occupancy,
            e_price: float, e_carbon: float, g_price: float, g_carbon: float,
-           action: Optional[Sequence[float]] = None, observe: bool = True) -> dict:
+           action: Optional[Sequence[float]] = None, observe: bool = True, reject: bool = False,
+           cool_sp: Optional[float] = None, damper_cmd: Optional[Sequence[float]] = None) -> dict:
     """One Environment._step (H2 ordering).  ``action`` = (boiler supply-water setpoint,
     AHU heating setpoint) in native units as the proto would carry them (fp32)."""
     Z = self.plan.Z
@@ -385,6 +390,12 @@ class OracleBuilding:
     si.comfort_now, si.comfort_prev, si.comfort_next = int(comfort_now), int(comfort_prev), int(comfort_next)
     si.occupancy = _d(occ)
     si.observe = int(observe)
+    si.reject = int(reject)   # rejection_simulator_building.py:52-60
+    if cool_sp is not None:
+      si.has_cool_sp, si.ahu_cool_sp = 1, float(np.float32(cool_sp))
+    if damper_cmd is not None:
+      dc = np.ascontiguousarray(damper_cmd, dtype=np.float64)
+      si.damper_cmd = _d(dc)
     si.e_price, si.e_carbon, si.g_price, si.g_carbon = e_price, e_carbon, g_price, g_carbon
     so = _StepOut()
     so.zone_temp_pre, so.zone_temp_post, so.q_zone = _d(tz_pre), _d(tz_post), _d(qz)
@@ -392,7 +403,8 @@ class OracleBuilding:
                    C.byref(so))
     s = self._s
     return dict(
-        n_sweeps=so.n_sweeps, converged=bool(so.converged), t_supply_air=so.t_supply_air,
+        n_sweeps=so.n_sweeps, converged=bool(so.converged), action_accepted=bool(so.action_accepted),
+        t_supply_air=so.t_supply_air,
         recirc_pre=so.recirc_pre, zone_temp_pre=tz_pre, zone_temp_post=tz_post, q_zone=qz,
         blower_rate=so.blower_rate, ac_rate=so.ac_rate, gas_rate=so.gas_rate,
         pump_rate=so.pump_rate, reward=so.reward, reward_f64=so.reward_f64,

@@ -72,6 +72,17 @@ void sbo_zone_means(const sbo_plan *p, const double *temp, double *out) {
   for (int z = 0; z < p->Z; z++) out[z] = zone_mean(p, temp, z, buf);
 }
 
+/* ---- precision experiment (oracle/experiment_fp32_offset.py; SURVEY.md section 7, hard part 1,
+ *      option (b)): with mode 1 every control-volume temperature is STORED as a float32 offset
+ *      from t_ref (the arithmetic stays float64).  Mode 0, the default, is the reference's own
+ *      float64 state and the only mode the parity tests use. */
+static int32_t g_state_mode = 0;
+static double g_state_tref = 0.0;
+void sbo_set_state_mode(int32_t mode, double t_ref) {
+  g_state_mode = mode;
+  g_state_tref = t_ref;
+}
+
 /* ---- one in-place Gauss-Seidel sweep: simulator.py:278-316 ------------------------- */
 double sbo_sweep(const sbo_plan *p, const double *prev, double *est, const double *q,
                  double t_amb, double h, double dt) {
@@ -121,6 +132,7 @@ double sbo_sweep(const sbo_plan *p, const double *prev, double *est, const doubl
       double src = q[i] / k / p->zh;
       val = (s + src + retained) / den;
     }
+    if (g_state_mode == 1) val = g_state_tref + (double)(float)(val - g_state_tref);
     double d = fabs(val - est[i]);
     if (d > max_delta) max_delta = d; /* max(delta, max_delta) */
     est[i] = val;
@@ -384,13 +396,31 @@ void sbo_step(const sbo_plan *p, const sbo_params *prm, sbo_state *s, const sbo_
   double buf[N];
   double tz_pre[Z], tzs[Z];
 
-  sbo_setup_step(p, prm, s, in->comfort_now, in->comfort_prev);
-
-  if (in->has_action) { /* smart_device.py:170-201 set_action */
-    s->blr_setpoint = in->blr_setpoint;
-    s->blr_action_ts = in->now_ts;
-    s->blr_has_action_ts = 1;
-    s->ahu_heat_sp = in->ahu_heat_sp;
+  out->action_accepted = in->reject ? 0 : 1;
+  if (!in->reject) { /* simulator_building.py:204-263 request_action */
+    /* Thermostat._previous_timestamp is the last time update() ran (thermostat.py:88): the caller's
+     * comfort_prev is is_comfort_mode of the previous STEP, which is the same thing unless a request
+     * was rejected in between; then the value remembered here applies. */
+    const int32_t cprev = s->thermostat_skipped ? s->thermostat_prev_comfort : in->comfort_prev;
+    sbo_setup_step(p, prm, s, in->comfort_now, cprev);
+    s->thermostat_prev_comfort = in->comfort_now;
+    s->thermostat_skipped = 0;
+    if (in->has_action) { /* smart_device.py:170-201 set_action */
+      s->blr_setpoint = in->blr_setpoint;
+      s->blr_action_ts = in->now_ts;
+      s->blr_has_action_ts = 1;
+      s->ahu_heat_sp = in->ahu_heat_sp;
+      if (in->has_cool_sp) s->ahu_cool_sp = in->ahu_cool_sp;
+      if (in->damper_cmd)
+        for (int z = 0; z < Z; z++) {
+          const double c = in->damper_cmd[z];
+          if (c != c) continue;
+          if (c < 0 || c > 1) out->action_accepted = 0; /* vav.py:125-129 raises: this action is rejected */
+          else s->damper[z] = c;
+        }
+    }
+  } else {
+    s->thermostat_skipped = 1;
   }
 
   /* ---- execute_step_sim ---- */

@@ -79,6 +79,8 @@ typedef struct sbo_state {
   int32_t blr_has_action_ts;    /* SmartDevice._action_timestamp is not None */
   double blr_action_ts;         /* seconds on the harness clock */
   int32_t thermostat_has_prev;  /* Thermostat._previous_timestamp is not None */
+  int32_t thermostat_prev_comfort; /* is_comfort_mode(Thermostat._previous_timestamp), kept for rejected steps */
+  int32_t thermostat_skipped;      /* a rejected request skipped setup_step_sim since the last update */
 } sbo_state;
 
 /* Host-resolved inputs for one Environment._step (calendar, weather, tariffs). */
@@ -94,6 +96,13 @@ typedef struct sbo_step_in {
   int32_t observe;           /* replay one supply_water_temperature_sensor observation */
   double e_price, e_carbon;  /* electricity: USD/W/s and kg/W/s at start_time.hour */
   double g_price, g_carbon;  /* gas: USD/J and kg/J at start_time.month */
+  /* the rest of the settable fields and the rejection path (appended: older callers leave them 0) */
+  int32_t reject;            /* the building rejected the request (RuntimeError out of request_action,
+                              * rejection_simulator_building.py:52-60; environment.py:1266-1309): neither
+                              * setup_step_sim nor any set_action runs, the step goes on */
+  int32_t has_cool_sp;       /* air handler supply_air_cooling_temperature_setpoint (air_handler.py:101) */
+  double ahu_cool_sp;
+  const double *damper_cmd;  /* [Z] or NULL: VAV supply_air_damper_percentage_command (vav.py:66), NaN = none */
 } sbo_step_in;
 
 typedef struct sbo_step_out {
@@ -108,11 +117,15 @@ typedef struct sbo_step_out {
   double *zone_temp_pre;     /* [Z] or NULL */
   double *zone_temp_post;    /* [Z] or NULL */
   double *q_zone;            /* [Z] or NULL */
+  int32_t action_accepted;   /* environment.py: all_actions_accepted and no RuntimeError (else reward -inf) */
 } sbo_step_out;
 
 double sbo_pairwise_sum(const double *a, int64_t n);
 double sbo_np_mean(const double *a, int64_t n);
 void sbo_zone_means(const sbo_plan *p, const double *temp, double *out);
+/* precision experiment only (oracle/experiment_fp32_offset.py): 0 = float64 state (default, the
+ * reference's), 1 = temperatures stored as float32 offsets from t_ref */
+void sbo_set_state_mode(int32_t mode, double t_ref);
 double sbo_sweep(const sbo_plan *p, const double *prev, double *est, const double *q,
                  double t_amb, double h, double dt);
 int32_t sbo_fd_timestep(const sbo_plan *p, double *temp, double *scratch, const double *q,

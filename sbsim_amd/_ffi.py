@@ -10,9 +10,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SBSIM_LIB") or os.path.join(_HERE, "libsbsim_amd.so")
 
-SB_NUM_ACTIONS = 2
+SB_NUM_ACTIONS = 2     # the SB1 action set; sb_params.n_actions is the width of an action row
+SB_MAX_ACTIONS = 16
 SB_NUM_AUX = 7
-SB_ABI_VERSION = 4   # include/sbsim_amd.h
+SB_ABI_VERSION = 5   # include/sbsim_amd.h
+# sb_action_kind
+SB_ACT_BOILER_SUPPLY_WATER_SETPOINT, SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT = 0, 1
+SB_ACT_AHU_SUPPLY_AIR_COOLING_SETPOINT, SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND = 2, 3
 SB_INFO_STRIDE = 24
 SB_NUM_SCALARS = 16
 
@@ -42,7 +46,8 @@ PARAM_FIELDS = [
     ("max_prod", C.c_double), ("min_prod", C.c_double), ("max_elec", C.c_double),
     ("max_gas", C.c_double), ("prod_delta", C.c_double), ("prod_stiff", C.c_double),
     ("w_prod", C.c_double), ("w_cost", C.c_double), ("w_carbon", C.c_double),
-    ("act_lo", C.c_double * SB_NUM_ACTIONS), ("act_hi", C.c_double * SB_NUM_ACTIONS),
+    ("n_actions", C.c_int32), ("act_kind", C.c_int32 * SB_MAX_ACTIONS), ("act_zone", C.c_int32 * SB_MAX_ACTIONS),
+    ("act_lo", C.c_double * SB_MAX_ACTIONS), ("act_hi", C.c_double * SB_MAX_ACTIONS),
 ]
 
 
@@ -63,7 +68,7 @@ class StepIn(C.Structure):
               ("weather_times_dev", C.c_void_p), ("weather_tempf_dev", C.c_void_p), ("weather_offset_dev", C.c_void_p),
               ("weather_n", C.c_int32), ("weather_t_now", C.c_double), ("weather_t_next", C.c_double),
               ("comfort_now", C.c_int32), ("comfort_prev", C.c_int32),
-              ("comfort_next", C.c_int32), ("has_action", C.c_int32),
+              ("comfort_next", C.c_int32), ("has_action", C.c_int32), ("reject_dev", C.c_void_p),
               ("occupancy", C.c_double), ("occupancy_dev", C.c_void_p),
               ("occupancy_bz_dev", C.c_void_p), ("num_occupants_dev", C.c_void_p), ("occupancy_norm", C.c_double),
               ("e_price", C.c_double), ("e_carbon", C.c_double),
@@ -116,6 +121,9 @@ def load():
   L = C.CDLL(LIB_PATH)
   vp = C.c_void_p
   L.sb_abi_version.restype = C.c_int
+  if L.sb_abi_version() != SB_ABI_VERSION:   # a stale library would read these structs with another layout
+    raise SbsimError(f"{LIB_PATH} has ABI version {L.sb_abi_version()}, this package needs {SB_ABI_VERSION}: "
+                     "rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
   L.sb_last_error.restype = C.c_char_p
   L.sb_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(Params), C.POINTER(ObsLayout),
                           C.c_int32, C.c_int32, C.POINTER(vp)]

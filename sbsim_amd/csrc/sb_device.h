@@ -283,6 +283,9 @@ struct Bld {
   double ahu_flow, blr_flow, blr_return;
   int ahu_count, blr_count;
   double tank, tank_change, duration;
+  int rejected; // the action request was rejected (or one of its actions was): reward -inf
+  int comfort_seen;  // is_comfort_mode at the building's last thermostat update (-> scal[18])
+  double action_age; // steps since the boiler's last accepted action (-> scal[19])
 };
 
 // k_pre, one thread per building.  request_action: setup_step_sim (thermostats on the stored
@@ -331,10 +334,26 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
     v.t_next = in.t_amb_dev ? in.t_amb_dev[2 * b + 1] : in.t_amb_next;
   }
   v.heat_sp = S[0]; v.cool_sp = S[1]; v.blr_sp = S[4];
-  if (in.has_action) { // bounded_action_normalizer.py:73-98, then the proto float field
-    const double a0 = (double)s.actions[2 * b], a1 = (double)s.actions[2 * b + 1];
-    v.blr_sp = (double)(float)((a0 + 1.0) / 2.0 * (p.act_hi[0] - p.act_lo[0]) + p.act_lo[0]);
-    v.heat_sp = (double)(float)((a1 + 1.0) / 2.0 * (p.act_hi[1] - p.act_lo[1]) + p.act_lo[1]);
+  // a building that rejected the request (environment.py:1266-1309) runs neither setup_step_sim nor set_action
+  const bool rejected = in.reject_dev && in.reject_dev[b];
+  const bool acting = in.has_action && !rejected;
+  v.rejected = rejected;
+  double damper_cmd[SB_MAX_ACTIONS]; // agent damper commands of this step, by action column
+  unsigned damper_set = 0;           // bit i: column i carries an accepted damper command (no NaN sentinel: -fno-honor-nans)
+  bool boiler_action = false;
+  for (int i = 0; i < p.n_actions; ++i) {
+    damper_cmd[i] = 0.0;
+    if (!acting) continue; // bounded_action_normalizer.py:73-98, then the proto float field
+    const double ai = (double)s.actions[(size_t)b * p.n_actions + i];
+    const double native = (double)(float)((ai + 1.0) / 2.0 * (p.act_hi[i] - p.act_lo[i]) + p.act_lo[i]);
+    switch (p.act_kind[i]) {
+      case SB_ACT_BOILER_SUPPLY_WATER_SETPOINT: v.blr_sp = native; boiler_action = true; break;
+      case SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT: v.heat_sp = native; break;
+      case SB_ACT_AHU_SUPPLY_AIR_COOLING_SETPOINT: v.cool_sp = native; break;
+      default: // vav.py:125-129: the setter raises outside [0, 1] -> REJECTED_NOT_ENABLED_OR_AVAILABLE
+        if (native < 0.0 || native > 1.0) v.rejected = 1;
+        else { damper_cmd[i] = native; damper_set |= 1u << i; }
+    }
   }
   const double recirc = S[11];
   const double mixed = p.ahu_recirc * recirc + (1 - p.ahu_recirc) * v.t_now;
@@ -351,16 +370,24 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   }
   const double hsp = in.comfort_now ? p.comfort_lo : p.eco_lo;
   const double csp = in.comfort_now ? p.comfort_hi : p.eco_hi;
+  // Thermostat._previous_timestamp (thermostat.py:88): the host's value, or the building's own when
+  // buildings can skip thermostat updates (scal[18]: -1 none, else is_comfort_mode of the last update)
+  const int comfort_prev = in.reject_dev ? (int)S[18] : in.comfort_prev;
   double ahu_flow = 0.0, blr_flow = 0.0, num = 0.0, den = 0.0;
   int ahu_count = 0, blr_count = 0;
   for (int z = 0; z < a.Z; ++z) {
     const double tz = a.zmean[zb + z];  // pre-update zone mean (vav.zone_air_temperature)
     int mode = a.mode[zb + z];          // thermostat.py:114-148
-    if (in.comfort_now) mode = default_control(mode, tz, hsp, csp);
-    else if (in.comfort_prev == 1) mode = 3;
-    else if (!(mode == 3 && tz > hsp)) mode = default_control(mode, tz, hsp, csp);
-    a.mode[zb + z] = mode;
-    const double damper = (mode == 1 || mode == 2) ? 1.0 : 0.1; // vav.py:229-243
+    if (!rejected) {
+      if (in.comfort_now) mode = default_control(mode, tz, hsp, csp);
+      else if (comfort_prev == 1) mode = 3;
+      else if (!(mode == 3 && tz > hsp)) mode = default_control(mode, tz, hsp, csp);
+      a.mode[zb + z] = mode;
+    }
+    double damper = (mode == 1 || mode == 2) ? 1.0 : 0.1; // vav.py:229-243
+    if (rejected) damper = a.damper[zb + z];                // nobody touched the VAV: what it had
+    for (int i = 0; i < p.n_actions; ++i)                   // set_action after update_settings
+      if ((damper_set >> i & 1u) && p.act_zone[i] == z) damper = damper_cmd[i];
     const double valve = mode == 1 ? 1.0 : 0.0;
     const double reheat = valve * p.vav_max_water_flow;
     const double air = damper * p.vav_max_air_flow;
@@ -384,7 +411,19 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   v.blr_return = num / (den + 1e-6);
   // _get_observation: the boiler tank lag advances (boiler.py:158-217)
   v.tank = S[8]; v.tank_change = S[9]; v.duration = S[10];
-  if (in.has_action) v.duration = p.dt; // observation_ts - action_ts
+  // boiler.py:158-168 at this step's observation (Environment: one per step): with an action time stamp
+  // (smart_device.py:193; a rejected request leaves the old one) the duration is observation_ts -
+  // action_ts; without one the first observation becomes it and the duration keeps its value.
+  // scal[19]: (last observation - action time stamp) / dt, -1 = no action time stamp yet.
+  double age = S[19];
+  if (in.has_action) {
+    if (boiler_action) age = 1.0;
+    else if (age < 0.0) age = 0.0;
+    else age += 1.0;
+    if (boiler_action || S[19] >= 0.0) v.duration = age * p.dt;
+  }
+  v.action_age = age;
+  v.comfort_seen = rejected ? (int)S[18] : in.comfort_now;
   if (p.blr_cooling_rate > 0.0 && p.blr_heating_rate > 0.0) {
     const double begin = v.tank;
     if (v.blr_sp > begin) v.tank = fmin(begin + p.blr_heating_rate * v.duration / 60.0, v.blr_sp);
@@ -464,7 +503,8 @@ __device__ inline void post_building(const Dev &a, const StepArgs &s, int b) {
   S[12] += (double)blower * p.dt; S[13] += (double)ac * p.dt;
   S[14] += (double)gas * p.dt; S[15] += (double)pump * p.dt;
   S[16] = v.t_now; S[17] = v.t_now; // exterior-space cells now hold the ambient temperature
-  s.reward[b] = (float)reward;
+  S[18] = (double)v.comfort_seen; S[19] = v.action_age;
+  s.reward[b] = v.rejected ? -INFINITY : (float)reward; // environment.py:52,1301-1302
   if (s.info) {
     float *I = s.info + (size_t)b * SB_INFO_STRIDE;
     I[0] = blower; I[1] = ac; I[2] = gas; I[3] = pump;

@@ -27,7 +27,7 @@ constexpr int kGuardHost = 16; // must match kGuard in step_lds.hip
 
 // ---------------------------------------------------------------- kernels
 // Simulator.reset(): grid (either state layout), zone means, device scalars.
-__global__ void k_reset(Dev a, double initial_temp, const double *temps) {
+__global__ void k_reset(Dev a, double initial_temp, const double *temps, int first) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -85,7 +85,9 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps) {
       S[12] = S[13] = S[14] = S[15] = 0.0;
       S[16] = a.reg && a.n_ring > 0 ? rlo : 0.0; // extremes of the exterior-space ring (register path)
       S[17] = a.reg && a.n_ring > 0 ? rhi : 0.0;
-      S[18] = S[19] = 0.0;
+      // Thermostat._previous_timestamp and SmartDevice._action_timestamp are construction state:
+      // Simulator.reset() leaves them alone (thermostat.py:66-69, smart_device.py:71-72)
+      if (first) { S[18] = -1.0; S[19] = -1.0; }
     }
   }
 }
@@ -451,10 +453,10 @@ bool env_flag(const char *name) {
 }
 
 void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan &q, int n_obs, int cus,
-                      int n_buildings, sb_launch_info *out) {
+                      int n_buildings, sb_launch_info *out, int n_actions = SB_NUM_ACTIONS) {
   const int64_t N = (int64_t)plan->H * plan->W, Z = plan->Z;
-  out->algorithmic_bytes_per_env_step = 8ll * N + 24ll * Z + 4ll * SB_NUM_ACTIONS + 4ll * n_obs + 44;
-  const int64_t rest = (8 * 4 + 4 * 2) * Z + 16ll * kNScalOut + 4ll * SB_NUM_ACTIONS + 4ll * n_obs + 4;
+  out->algorithmic_bytes_per_env_step = 8ll * N + 24ll * Z + 4ll * n_actions + 4ll * n_obs + 44;
+  const int64_t rest = (8 * 4 + 4 * 2) * Z + 16ll * kNScalOut + 4ll * n_actions + 4ll * n_obs + 4;
   if (r.ok) {
     out->path = 1;
     out->waves_per_building = r.P == 2 ? 2 : 1;
@@ -508,6 +510,15 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     return fail(SB_ERR_INVALID, "sb_create: time_step_sec and iteration_limit must be positive");
   if (params->ahu_cool_sp <= params->ahu_heat_sp) // air_handler.py:60-64
     return fail(SB_ERR_INVALID, "cooling_air_temp_setpoint must greater than heating_air_temp_setpoint");
+  if (params->n_actions < 1 || params->n_actions > SB_MAX_ACTIONS)
+    return fail(SB_ERR_INVALID, "sb_create: n_actions must be in 1..SB_MAX_ACTIONS");
+  for (int i = 0; i < params->n_actions; ++i) {
+    const int k = params->act_kind[i];
+    if (k < SB_ACT_BOILER_SUPPLY_WATER_SETPOINT || k > SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND)
+      return fail(SB_ERR_INVALID, "sb_create: unknown action kind");
+    if (k == SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND && (params->act_zone[i] < 0 || params->act_zone[i] >= plan->Z))
+      return fail(SB_ERR_INVALID, "sb_create: VAV action for a zone the floor plan does not have");
+  }
   if (obs->n_obs < 1) return fail(SB_ERR_INVALID, "sb_create: empty observation layout");
   if (!obs->mean || !obs->sigma || (plan->Z > 0 && !obs->col_zone))
     return fail(SB_ERR_INVALID, "sb_create: null observation-layout table");
@@ -535,7 +546,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   d.ncls = plan->n_classes;
   d.p = *params;
   d.reg = r.ok ? 1 : 0;
-  fill_launch_info(plan, r, q, obs->n_obs, h->cus, n_buildings, &h->info);
+  fill_launch_info(plan, r, q, obs->n_obs, h->cus, n_buildings, &h->info, params->n_actions);
 
 #define SB_TRY(x) do { rc = (x); if (rc != SB_OK) { delete h; return rc; } } while (0)
   { // one extra row: the register path's pad class (T' = Tprev: ap = 1, everything else 0)
@@ -729,7 +740,8 @@ int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *s
   const int wpb = 4;
   const int blocks = std::min((h->d.B + wpb - 1) / wpb, 4096);
   hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(64 * wpb), 0, (hipStream_t)stream, h->d, initial_temp,
-                     temps_dev);
+                     temps_dev, h->was_reset ? 0 : 1);
+  h->was_reset = true;
   SB_HIP(hipGetLastError());
   return SB_OK;
 }

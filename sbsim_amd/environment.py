@@ -61,6 +61,14 @@ _VAV_FIELDS = ("supply_air_damper_percentage_command", "supply_air_flowrate_setp
 _AUX_FIELDS = ("hod_cos_000", "hod_sin_000", "dow_cos_000", "dow_sin_000",
                "comfort_mode_now", "comfort_mode_soon", "num_occupants")
 ACTION_NAMES = ("supply_water_setpoint", "supply_air_heating_temperature_setpoint")
+# settable fields of the simulated devices (boiler.py:81-85, air_handler.py:97-104, vav.py:65-69) -> sb_action_kind
+ACTION_KINDS = {
+    "supply_water_setpoint": _ffi.SB_ACT_BOILER_SUPPLY_WATER_SETPOINT,
+    "supply_air_heating_temperature_setpoint": _ffi.SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT,
+    "supply_air_cooling_temperature_setpoint": _ffi.SB_ACT_AHU_SUPPLY_AIR_COOLING_SETPOINT,
+    "supply_air_damper_percentage_command": _ffi.SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND,
+}
+ACTION_REJECTION_REWARD = float("-inf")   # environment.py:52
 
 
 @dataclasses.dataclass
@@ -115,6 +123,11 @@ class SimConfig:
   carbon_emission_weight: float = 0.4
   # action normalisation (bounded_action_normalizer.py; sim_config.gin:229-237)
   action_ranges: Tuple[Tuple[float, float], ...] = ((310.0, 355.0), (285.0, 300.0))
+  # the action vector (environment.py:278-307,591-653: one column per (device, setpoint) of the
+  # ActionConfig that has a normalizer): setpoint names, and the zone index for a VAV field.
+  # Default: the SB1 set of sim_config.gin:239-242.  `action_ranges[i]` is column i's native range.
+  action_names: Tuple[str, ...] = ACTION_NAMES
+  action_zones: Tuple[int, ...] = ()
 
   @staticmethod
   def sb1() -> "SimConfig":
@@ -149,7 +162,14 @@ class SimConfig:
     p.max_elec, p.max_gas = self.max_electricity_rate, self.max_natural_gas_rate
     p.prod_delta, p.prod_stiff = self.productivity_midpoint_delta, self.productivity_decay_stiffness
     p.w_prod, p.w_cost, p.w_carbon = self.productivity_weight, self.energy_cost_weight, self.carbon_emission_weight
-    for i, (lo, hi) in enumerate(self.action_ranges):
+    if len(self.action_names) != len(self.action_ranges) or not 1 <= len(self.action_names) <= _ffi.SB_MAX_ACTIONS:
+      raise ValueError("one native range per action, 1..%d actions" % _ffi.SB_MAX_ACTIONS)
+    p.n_actions = len(self.action_names)
+    for i, (name, (lo, hi)) in enumerate(zip(self.action_names, self.action_ranges)):
+      if name not in ACTION_KINDS:   # simulator_building.py:236-251: REJECTED_NOT_ENABLED_OR_AVAILABLE at run time
+        raise ValueError(f"{name!r} is not a settable field of the simulated devices")
+      p.act_kind[i] = ACTION_KINDS[name]
+      p.act_zone[i] = self.action_zones[i] if i < len(self.action_zones) else 0
       p.act_lo[i], p.act_hi[i] = lo, hi
     return p
 
@@ -241,6 +261,7 @@ class BatchedSimulator:
     if not torch.cuda.is_available():
       raise _ffi.SbsimError("sbsim_amd needs a HIP device (MI355X); there is no CPU path")
     self.plan, self.config, self.B, self.device = plan, config, int(n_buildings), int(device)
+    self.n_actions = len(config.action_names)
     H0, W0 = plan.shape
     if orientation not in ("auto", "rows", "columns"):
       raise ValueError("orientation must be 'auto', 'rows' or 'columns'")
@@ -390,8 +411,8 @@ class BatchedSimulator:
     three launches (1 = device algebra before the sweep, 2 = sweep kernel, 4 = reward /
     observation) -- a measurement aid; a step is complete once all three ran in order."""
     if actions is not None:
-      if actions.dtype != torch.float32 or tuple(actions.shape) != (self.B, _ffi.SB_NUM_ACTIONS):
-        raise ValueError(f"actions must be float32 [{self.B}, {_ffi.SB_NUM_ACTIONS}]")
+      if actions.dtype != torch.float32 or tuple(actions.shape) != (self.B, self.n_actions):
+        raise ValueError(f"actions must be float32 [{self.B}, {self.n_actions}]")
       if not actions.is_contiguous():
         actions = actions.contiguous()
     _ffi.check(self._lib.sb_step_phases(
@@ -477,7 +498,7 @@ class BatchedEnvironment:
     self._step_interval = dt.timedelta(seconds=self.config.time_step_sec)
     # environment.py:427-435
     self._num_timesteps_in_episode = int(dt.timedelta(days=num_days_in_episode) / self._step_interval)
-    self._action_spec = ArraySpec((_ffi.SB_NUM_ACTIONS,), np.dtype(np.float32), "action", -1.0, 1.0)
+    self._action_spec = ArraySpec((self.sim.n_actions,), np.dtype(np.float32), "action", -1.0, 1.0)
     self._observation_spec = ArraySpec((self.sim.O,), np.dtype(np.float32), "observation")
     self.field_names = self.sim.field_names
     dev = self.sim.tdev
@@ -597,11 +618,22 @@ class BatchedEnvironment:
     first = torch.full((self.batch_size,), STEP_FIRST, dtype=torch.int32, device=self.sim.tdev)
     return TimeStep(first, self._zero, torch.ones_like(self._discount), self._obs)
 
-  def step(self, action: torch.Tensor) -> TimeStep:
-    """environment.py:1228-1370."""
+  def step(self, action: torch.Tensor, rejected: Optional[torch.Tensor] = None) -> TimeStep:
+    """environment.py:1228-1370.  ``rejected``: optional bool / uint8 [B] on the device -- buildings
+    whose BaseBuilding.request_action raised (environment.py:1266-1309; RejectionSimulatorBuilding):
+    they skip setup_step_sim and the actions, step and observe like the others, and return the
+    reward ``ACTION_REJECTION_REWARD`` (-inf).
+
+    The returned TimeStep's tensors are the environment's own buffers: the next ``step`` / ``reset``
+    overwrites them (clone what you keep across steps)."""
     if self._needs_reset or self._episode_ended:
       return self.reset()
     si = self.make_step_in(self._now)
+    if rejected is not None:
+      if tuple(rejected.shape) != (self.batch_size,) or rejected.device != self.sim.tdev:
+        raise ValueError(f"rejected must be a [{self.batch_size}] tensor on {self.sim.tdev}")
+      self._rejected = rejected.to(torch.uint8).contiguous()
+      si.reject_dev = self._rejected.data_ptr()
     self.sim.step(action, si, self._obs, self._reward, self._info)
     self._prev_thermostat_ts = self._now
     self._now = self._now + self._step_interval

@@ -1,0 +1,46 @@
+"""bench.py --gpus N launches N ranks by itself (re-exec under torch.distributed.run) and the ranks
+agree on the world size; run here with a stub step on the gloo backend (no GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=300):
+  env = dict(os.environ)
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  env.update(env_extra or {})
+  return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                        timeout=timeout, env=env, cwd=ROOT)
+
+
+def _json_line(out):
+  lines = [l for l in out.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, out
+  return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_and_gathers_in_global_order():
+  r = _run(["--gpus", "2", "--stub-step", "--steps", "3", "--warmup", "1", "--buildings", "37"])
+  assert r.returncode == 0, r.stderr[-2000:]
+  d = _json_line(r.stdout)
+  assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+  assert d["gathered_returns"] == 74 and d["gather_in_global_order"] is True
+  assert d["return_gather_ms"] >= 0.0 and d["scaling"] == "weak"
+
+
+def test_gpus_1_runs_in_process():
+  r = _run(["--gpus", "1", "--stub-step", "--steps", "2", "--warmup", "0", "--buildings", "5"])
+  assert r.returncode == 0, r.stderr[-2000:]
+  d = _json_line(r.stdout)
+  assert d["n_gpus"] == 1 and d["gathered_returns"] == 5
+
+
+def test_world_size_mismatch_is_an_error():
+  r = _run(["--gpus", "4", "--stub-step"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+  assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
