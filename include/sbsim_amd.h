@@ -338,6 +338,32 @@ int sb_get_scalars(sb_handle *h, double *out_dev, void *stream);
 int sb_get_modes(sb_handle *h, int32_t *out_dev /* [B][Z] */, void *stream);
 int sb_get_zone_power(sb_handle *h, double *out_dev /* [B][Z] VAV power applied */, void *stream);
 
+/* Known-answer taps: the per-building device algebra of a step -- the very kernels sb_step launches
+ * before (k_pre) and after (k_post) the sweep -- on PRESCRIBED state of one building, so that the
+ * reference's own device and reward known answers (boiler_test.py, air_handler_test.py, vav_test.py,
+ * setpoint_energy_carbon_regret_test.py) can be asked of the HIP path itself.  HOST pointers;
+ * synchronous.  They overwrite that building's state: not for use inside a rollout. */
+typedef struct sb_tap_bld { /* what k_pre hands to k_post for one building */
+  double t_now, t_next;            /* ambient temperature at t and t + dt */
+  double heat_sp, cool_sp, blr_sp; /* AHU / boiler setpoints in force */
+  double t_sa;                     /* AHU supply air temperature (air_handler.py:204-233) */
+  double ahu_flow, blr_flow, blr_return; /* demand sums (air_handler.py:250-268, boiler.py:219-231), return water K */
+  int32_t ahu_count, blr_count;
+  double tank, tank_change, duration; /* boiler tank lag (boiler.py:158-217) */
+  int32_t rejected;
+} sb_tap_bld;
+/* setup_step_sim + set_action + the VAV / air-handler / boiler part of execute_step_sim on: the zone
+ * means `zone_temps` [Z], thermostat modes `modes` [Z] (NULL: keep), scalars `scalars` [16] in
+ * sb_get_scalars' order (NULL: keep; [11] = mean of the whole grid).  Outputs: `bld`, the VAV power
+ * `q_zone` [Z], `damper` [Z], `modes_out` [Z] (any may be NULL). */
+int sb_tap_pre(sb_handle *h, int32_t building, const double *zone_temps, const int32_t *modes,
+               const double *scalars, const float *actions /* [n_actions] or NULL */, const sb_step_in *in,
+               sb_tap_bld *bld, double *q_zone, double *damper, int32_t *modes_out);
+/* reward_info + compute_reward for a building whose step ended with `bld`, post-update zone means
+ * `zone_temps` [Z], grid mean `grid_mean`.  Outputs: reward, info [SB_INFO_STRIDE] (see sb_step). */
+int sb_tap_post(sb_handle *h, int32_t building, const sb_tap_bld *bld, const double *zone_temps,
+                double grid_mean, int32_t n_sweeps, const sb_step_in *in, float *reward, float *info);
+
 /* Developer aid: when SBSIM_PHASE_TIMING is set at sb_create, the step kernel stamps the
  * shader clock at its phase boundaries for building 0; copies 16 int64 to a HOST buffer. */
 int sb_debug_phase_cycles(sb_handle *h, long long *out_host);

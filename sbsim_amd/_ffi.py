@@ -83,6 +83,13 @@ class OccupancyConfig(C.Structure):
               ("seed", C.c_uint64), ("first_building", C.c_int64)]
 
 
+class TapBld(C.Structure):   # sb_tap_bld
+  _fields_ = [("t_now", C.c_double), ("t_next", C.c_double), ("heat_sp", C.c_double), ("cool_sp", C.c_double),
+              ("blr_sp", C.c_double), ("t_sa", C.c_double), ("ahu_flow", C.c_double), ("blr_flow", C.c_double),
+              ("blr_return", C.c_double), ("ahu_count", C.c_int32), ("blr_count", C.c_int32),
+              ("tank", C.c_double), ("tank_change", C.c_double), ("duration", C.c_double), ("rejected", C.c_int32)]
+
+
 class PbTime(C.Structure):
   _fields_ = [("seconds", C.c_int64), ("nanos", C.c_int32)]
 
@@ -100,7 +107,7 @@ EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_d
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles",
            "sb_floorplan_padded_shape", "sb_floorplan_preprocess", "sb_pb_reward_info", "sb_pb_reward_response",
            "sb_pb_observation_response", "sb_pb_action_response", "sb_shard_append", "sb_pb_device_info",
-           "sb_pb_zone_info", "sb_pb_variable_info", "sb_record_append")
+           "sb_pb_zone_info", "sb_pb_variable_info", "sb_record_append", "sb_tap_pre", "sb_tap_post")
 
 _lib = None
 
@@ -143,6 +150,8 @@ def load():
                "sb_get_zone_power"):
     getattr(L, name).argtypes = [vp, vp, vp]
   L.sb_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_longlong)]
+  L.sb_tap_pre.argtypes = [vp, C.c_int32, _dp, _ip, _dp, _fp, C.POINTER(StepIn), C.POINTER(TapBld), _dp, _dp, _ip]
+  L.sb_tap_post.argtypes = [vp, C.c_int32, C.POINTER(TapBld), _dp, C.c_double, C.c_int32, C.POINTER(StepIn), _fp, _fp]
   cpp, fp_ = C.POINTER(C.c_char_p), C.POINTER(C.c_float)
   L.sb_pb_reward_info.argtypes = [PbTime, PbTime, C.c_char_p, C.c_char_p, C.c_int32, cpp, fp_, C.c_int32, cpp, fp_,
                                   C.c_int32, cpp, fp_, vp, C.c_int64]

@@ -206,7 +206,7 @@ int sb_occupancy_attach(sb_handle *h, const sb_occupancy_config *cfg) {
                                 "(randomized_arrival_departure_occupancy.py:68-73)");
   if (!(cfg->time_step_sec > 0) || cfg->first_building < 0)
     return fail(SB_ERR_INVALID, "sb_occupancy_attach: time_step_sec must be positive, first_building >= 0");
-  SB_HIP(hipSetDevice(h->device));
+  SB_ON_DEVICE(h->device);
   if (!h->occ_state.p) {
     const int rc = alloc_zero(h->occ_state, (size_t)h->d.B * h->d.Z);
     if (rc != SB_OK) return rc;
@@ -222,7 +222,7 @@ int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, flo
   if (!h) return fail(SB_ERR_INVALID, "sb_occupancy_peek: null handle");
   if (!h->occ_attached) return fail(SB_ERR_INVALID, "sb_occupancy_peek: sb_occupancy_attach first");
   if (local_hour < 0 || local_hour > 23) return fail(SB_ERR_INVALID, "sb_occupancy_peek: hour must be 0..23");
-  SB_HIP(hipSetDevice(h->device));
+  SB_ON_DEVICE(h->device);
   const sb_occupancy_config &c = h->occ;
   OccArgs o;
   o.state = h->occ_state.p; o.B = h->d.B; o.Z = h->d.Z; o.n_occ = c.zone_assignment;
@@ -248,7 +248,7 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   if (distance < 0 || distance > 64)
     return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: distance must be 1..64 (distance = -1, the whole-room "
                                     "shuffle of stochastic_convection_simulator.py:80-99, is not implemented)");
-  SB_HIP(hipSetDevice(h->device));
+  SB_ON_DEVICE(h->device);
   const Dev &d = h->d;
   // :125-131: window [-distance, distance) in both directions, squared distance <= distance
   // (in the order of the caller's grid: the handle may hold the transposed floor plan)

@@ -28,6 +28,25 @@ inline int fail(int code, const std::string &msg) {
       return fail(SB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
   } while (0)
 
+// Entry points run on the handle's device and leave the calling thread's current device as
+// they found it (a handle on device 1 must not redirect the caller's later torch allocations).
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+    else if (err == hipSuccess) prev = -1; // nothing to restore
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define SB_ON_DEVICE(dev)                                                                    \
+  DeviceGuard device_guard_(dev);                                                            \
+  if (device_guard_.err != hipSuccess)                                                       \
+    return fail(SB_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_guard_.err))
+
 template <typename Tp>
 struct DevBuf {
   Tp *p = nullptr;

@@ -522,11 +522,20 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   if (obs->n_obs < 1) return fail(SB_ERR_INVALID, "sb_create: empty observation layout");
   if (!obs->mean || !obs->sigma || (plan->Z > 0 && !obs->col_zone))
     return fail(SB_ERR_INVALID, "sb_create: null observation-layout table");
+  { // every device field is written unguarded by write_obs: its index must be inside the row / the source table
+    const int n_fields = obs->n_src ? obs->n_src : obs->n_obs, n_ahu = params->ahu_has_weather ? 9 : 8;
+    bool ok = obs->col_ahu >= 0 && obs->col_ahu + n_ahu <= n_fields && obs->col_boiler >= 0 &&
+              obs->col_boiler + 3 <= n_fields && obs->col_aux >= 0 && obs->col_aux + SB_NUM_AUX <= obs->n_obs;
+    for (int z = 0; z < plan->Z; ++z) ok = ok && obs->col_zone[z] >= 0 && obs->col_zone[z] + 3 <= n_fields;
+    if (!ok) return fail(SB_ERR_INVALID, "sb_create: observation columns outside the observation row");
+  }
+  for (int z = 0; z < plan->Z; ++z) // building.py:579-587: the mean over a zone's air CVs
+    if (plan->zone_off[z + 1] == plan->zone_off[z]) return fail(SB_ERR_INVALID, "sb_create: a zone without cells");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(SB_ERR_NO_DEVICE, "sb_create: no HIP device visible (this library has no CPU path)");
   if (device < 0 || device >= ndev) return fail(SB_ERR_INVALID, "sb_create: bad device ordinal");
-  SB_HIP(hipSetDevice(device));
+  SB_ON_DEVICE(device);
   hipDeviceProp_t prop;
   SB_HIP(hipGetDeviceProperties(&prop, device));
 
@@ -718,13 +727,17 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     return fail(SB_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") +
                                 hipGetErrorString((hipError_t)e));
   }
+  rc = sb_reset(h, 0.0, nullptr, nullptr); // on the NULL stream ...
+  if (rc == SB_OK && hipStreamSynchronize(nullptr) != hipSuccess) // ... and complete before a caller's own stream touches the state
+    rc = fail(SB_ERR_HIP, "sb_create: the initial reset failed");
+  if (rc != SB_OK) { delete h; return rc; }
   *out = h;
-  return sb_reset(h, 0.0, nullptr, nullptr);
+  return SB_OK;
 }
 
 void sb_destroy(sb_handle *h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DeviceGuard guard(h->device);
   delete h;
 }
 
@@ -736,7 +749,7 @@ int sb_get_launch_info(const sb_handle *h, sb_launch_info *out) {
 
 int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *stream) {
   if (!h) return fail(SB_ERR_INVALID, "sb_reset: null handle");
-  SB_HIP(hipSetDevice(h->device));
+  SB_ON_DEVICE(h->device);
   const int wpb = 4;
   const int blocks = std::min((h->d.B + wpb - 1) / wpb, 4096);
   hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(64 * wpb), 0, (hipStream_t)stream, h->d, initial_temp,
@@ -749,7 +762,7 @@ int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *s
 int sb_observe_occupancy(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
                          const float *num_occupants_dev, double occupancy_norm, float *obs_dev, void *stream) {
   if (!h || !aux || !obs_dev) return fail(SB_ERR_INVALID, "sb_observe: null argument");
-  SB_HIP(hipSetDevice(h->device));
+  SB_ON_DEVICE(h->device);
   const int blocks = std::max(1, std::min((h->d.B + 63) / 64, 4096));
   hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->d, obs_dev, aux[0],
                      aux[1], aux[2], aux[3], aux[4], aux[5], aux[6], t_amb, t_amb_dev, num_occupants_dev,
@@ -767,7 +780,7 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
                    float *reward_dev, float *info_dev, void *stream, int32_t phases) {
   if (!h || !in || !reward_dev) return fail(SB_ERR_INVALID, "sb_step: null argument");
   if (in->has_action && !actions_dev) return fail(SB_ERR_INVALID, "sb_step: has_action set but actions_dev is NULL");
-  SB_HIP(hipSetDevice(h->device));
+  SB_ON_DEVICE(h->device);
   StepArgs s;
   s.actions = actions_dev; s.obs = obs_dev; s.reward = reward_dev; s.info = info_dev; s.in = *in;
   const Dev &d = h->d;
@@ -804,7 +817,7 @@ int sb_step(sb_handle *h, const float *actions_dev, const sb_step_in *in, float 
 
 int sb_get_temps(sb_handle *h, double *out_dev, void *stream) {
   if (!h || !out_dev) return fail(SB_ERR_INVALID, "sb_get_temps: null argument");
-  SB_HIP(hipSetDevice(h->device));
+  SB_ON_DEVICE(h->device);
   hipLaunchKernelGGL(k_copy_temps, dim3(2048), dim3(256), 0, (hipStream_t)stream, h->d, out_dev);
   SB_HIP(hipGetLastError());
   return SB_OK;
@@ -812,7 +825,7 @@ int sb_get_temps(sb_handle *h, double *out_dev, void *stream) {
 
 int sb_get_scalars(sb_handle *h, double *out_dev, void *stream) {
   if (!h || !out_dev) return fail(SB_ERR_INVALID, "sb_get_scalars: null argument");
-  SB_HIP(hipSetDevice(h->device));
+  SB_ON_DEVICE(h->device);
   hipLaunchKernelGGL(k_copy_scalars, dim3(256), dim3(256), 0, (hipStream_t)stream, h->d, out_dev);
   SB_HIP(hipGetLastError());
   return SB_OK;
@@ -821,7 +834,7 @@ int sb_get_scalars(sb_handle *h, double *out_dev, void *stream) {
 #define SB_COPY_OUT(name, src, count, type)                                                       \
   int name(sb_handle *h, type *out_dev, void *stream) {                                           \
     if (!h || !out_dev) return fail(SB_ERR_INVALID, #name ": null argument");                     \
-    SB_HIP(hipSetDevice(h->device));                                                              \
+    SB_ON_DEVICE(h->device);                                                              \
     SB_HIP(hipMemcpyAsync(out_dev, src, (size_t)(count) * sizeof(type), hipMemcpyDeviceToDevice,  \
                           (hipStream_t)stream));                                                  \
     return SB_OK;                                                                                 \
@@ -830,11 +843,87 @@ SB_COPY_OUT(sb_get_zone_temps, h->d.zmean, (size_t)h->d.B *h->d.Z, double)
 SB_COPY_OUT(sb_get_modes, h->d.mode, (size_t)h->d.B *h->d.Z, int32_t)
 SB_COPY_OUT(sb_get_zone_power, h->d.qz, (size_t)h->d.B *h->d.Z, double)
 
+/* ---- known-answer taps: k_pre / k_post on prescribed state of one building ---- */
+int sb_tap_pre(sb_handle *h, int32_t building, const double *zone_temps, const int32_t *modes,
+               const double *scalars, const float *actions, const sb_step_in *in, sb_tap_bld *bld,
+               double *q_zone, double *damper, int32_t *modes_out) {
+  if (!h || !zone_temps || !in) return fail(SB_ERR_INVALID, "sb_tap_pre: null argument");
+  const Dev &d = h->d;
+  if (building < 0 || building >= d.B) return fail(SB_ERR_INVALID, "sb_tap_pre: building out of range");
+  SB_ON_DEVICE(h->device);
+  SB_HIP(hipDeviceSynchronize());
+  const size_t zb = (size_t)building * d.Z;
+  SB_HIP(hipMemcpy(d.zmean + zb, zone_temps, sizeof(double) * d.Z, hipMemcpyHostToDevice));
+  if (modes) SB_HIP(hipMemcpy(d.mode + zb, modes, sizeof(int32_t) * d.Z, hipMemcpyHostToDevice));
+  if (scalars) SB_HIP(hipMemcpy(d.scal + (size_t)building * kNScal, scalars, sizeof(double) * kNScalOut, hipMemcpyHostToDevice));
+  DevBuf<float> act;
+  if (actions) {
+    std::vector<float> all((size_t)d.B * d.p.n_actions, 0.0f);
+    for (int i = 0; i < d.p.n_actions; ++i) all[(size_t)building * d.p.n_actions + i] = actions[i];
+    int rc = upload(act, all.data(), all.size());
+    if (rc != SB_OK) return rc;
+  } else if (in->has_action) {
+    return fail(SB_ERR_INVALID, "sb_tap_pre: has_action without actions");
+  }
+  StepArgs s{};
+  s.actions = act.p; s.in = *in;
+  const int blocks = std::max(1, std::min((d.B + 63) / 64, h->cus * 16));
+  hipLaunchKernelGGL(k_pre, dim3(blocks), dim3(64), 0, nullptr, d, s);
+  SB_HIP(hipGetLastError());
+  SB_HIP(hipDeviceSynchronize());
+  if (bld) {
+    Bld v;
+    SB_HIP(hipMemcpy(&v, d.bld + building, sizeof(Bld), hipMemcpyDeviceToHost));
+    *bld = sb_tap_bld{v.t_now, v.t_next, v.heat_sp, v.cool_sp, v.blr_sp, v.t_sa, v.ahu_flow, v.blr_flow, v.blr_return,
+                      v.ahu_count, v.blr_count, v.tank, v.tank_change, v.duration, v.rejected};
+  }
+  if (q_zone) SB_HIP(hipMemcpy(q_zone, d.qz + zb, sizeof(double) * d.Z, hipMemcpyDeviceToHost));
+  if (damper) SB_HIP(hipMemcpy(damper, d.damper + zb, sizeof(double) * d.Z, hipMemcpyDeviceToHost));
+  if (modes_out) SB_HIP(hipMemcpy(modes_out, d.mode + zb, sizeof(int32_t) * d.Z, hipMemcpyDeviceToHost));
+  return SB_OK;
+}
+
+int sb_tap_post(sb_handle *h, int32_t building, const sb_tap_bld *bld, const double *zone_temps,
+                double grid_mean, int32_t n_sweeps, const sb_step_in *in, float *reward, float *info) {
+  if (!h || !bld || !zone_temps || !in || !reward) return fail(SB_ERR_INVALID, "sb_tap_post: null argument");
+  const Dev &d = h->d;
+  if (building < 0 || building >= d.B) return fail(SB_ERR_INVALID, "sb_tap_post: building out of range");
+  SB_ON_DEVICE(h->device);
+  SB_HIP(hipDeviceSynchronize());
+  Bld v;
+  SB_HIP(hipMemcpy(&v, d.bld + building, sizeof(Bld), hipMemcpyDeviceToHost)); // keeps the fields the tap does not expose
+  v.t_now = bld->t_now; v.t_next = bld->t_next; v.heat_sp = bld->heat_sp; v.cool_sp = bld->cool_sp;
+  v.blr_sp = bld->blr_sp; v.t_sa = bld->t_sa; v.ahu_flow = bld->ahu_flow; v.blr_flow = bld->blr_flow;
+  v.blr_return = bld->blr_return; v.ahu_count = bld->ahu_count; v.blr_count = bld->blr_count;
+  v.tank = bld->tank; v.tank_change = bld->tank_change; v.duration = bld->duration; v.rejected = bld->rejected;
+  SB_HIP(hipMemcpy(d.bld + building, &v, sizeof(Bld), hipMemcpyHostToDevice));
+  std::vector<double> zs(d.Z);
+  for (int z = 0; z < d.Z; ++z) zs[z] = zone_temps[z] * (double)(h->h_zone_off[z + 1] - h->h_zone_off[z]);
+  SB_HIP(hipMemcpy(d.zsum + (size_t)building * d.Z, zs.data(), sizeof(double) * d.Z, hipMemcpyHostToDevice));
+  const double gs = grid_mean * (double)d.N;
+  const int nsw = n_sweeps | (1 << 16);
+  SB_HIP(hipMemcpy(d.gsum + building, &gs, sizeof(double), hipMemcpyHostToDevice));
+  SB_HIP(hipMemcpy(d.nsw + building, &nsw, sizeof(int), hipMemcpyHostToDevice));
+  DevBuf<float> rew, inf;
+  int rc = alloc_zero(rew, (size_t)d.B);
+  if (rc == SB_OK) rc = alloc_zero(inf, (size_t)d.B * SB_INFO_STRIDE);
+  if (rc != SB_OK) return rc;
+  StepArgs s{};
+  s.reward = rew.p; s.info = inf.p; s.in = *in;
+  const int blocks = std::max(1, std::min((d.B + 63) / 64, h->cus * 16));
+  hipLaunchKernelGGL(k_post, dim3(blocks), dim3(64), 0, nullptr, d, s);
+  SB_HIP(hipGetLastError());
+  SB_HIP(hipDeviceSynchronize());
+  SB_HIP(hipMemcpy(reward, rew.p + building, sizeof(float), hipMemcpyDeviceToHost));
+  if (info) SB_HIP(hipMemcpy(info, inf.p + (size_t)building * SB_INFO_STRIDE, sizeof(float) * SB_INFO_STRIDE, hipMemcpyDeviceToHost));
+  return SB_OK;
+}
+
 /* Developer aid (not part of the parity/bench path): 16 int64 cycle stamps, host pointer. */
 int sb_debug_phase_cycles(sb_handle *h, long long *out_host) {
   if (!h || !out_host) return fail(SB_ERR_INVALID, "sb_debug_phase_cycles: null argument");
   if (!h->d.dbg) return fail(SB_ERR_INVALID, "sb_debug_phase_cycles: set SBSIM_PHASE_TIMING=1 before sb_create");
-  SB_HIP(hipSetDevice(h->device));
+  SB_ON_DEVICE(h->device);
   SB_HIP(hipDeviceSynchronize());
   SB_HIP(hipMemcpy(out_host, h->d.dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost));
   return SB_OK;

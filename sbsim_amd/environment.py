@@ -69,6 +69,11 @@ ACTION_KINDS = {
     "supply_air_damper_percentage_command": _ffi.SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND,
 }
 ACTION_REJECTION_REWARD = float("-inf")   # environment.py:52
+# sim_config.gin:164: the SB1 configuration's clock starts at a tz-aware UTC time, which the schedule
+# converts to US/Pacific.  BatchedEnvironment's default start is the NAIVE 2023-07-06 07:00 of the
+# reference's test scenarios and of BASELINE.json configs[0..1]; a naive time stamp is taken as UTC
+# wall clock whatever `time_zone` says (setpoint_schedule.py:100-106).
+SB1_START_TIMESTAMP = dt.datetime(2023, 7, 6, 7, 0, 0, tzinfo=dt.timezone.utc)
 
 
 @dataclasses.dataclass
@@ -446,7 +451,11 @@ class BatchedSimulator:
 
 
 class BatchedEnvironment:
-  """B lock-stepped sbsim environments behind ``reset()`` / ``step(action)``."""
+  """B lock-stepped sbsim environments behind ``reset()`` / ``step(action)``.
+
+  ``start_timestamp``: naive by default (see SB1_START_TIMESTAMP for the SB1 configuration's own).
+  The TimeStep tensors returned by ``reset`` / ``step`` are the environment's own device buffers and
+  are overwritten by the next call: clone what must outlive a step (replay buffers, n-step returns)."""
 
   def __init__(self, plan: FloorPlan, n_buildings: int, config: Optional[SimConfig] = None,
                weather=None, occupancy=None, start_timestamp=dt.datetime(2023, 7, 6, 7, 0, 0),
