@@ -47,6 +47,7 @@ extern "C" {
 #define SB_ABI_VERSION 5
 #define SB_NUM_ACTIONS 2   /* the SB1 action set (sim_config.gin:239-242): boiler supply_water_setpoint, AHU
                             * supply_air_heating_temperature_setpoint -- the default of sb_params.n_actions */
+#define SB_ACTION_KEEP (-3.0e38f)
 #define SB_MAX_ACTIONS 16  /* settable fields an action vector may drive (sb_params.act_kind) */
 #define SB_NUM_AUX 7       /* hod cos/sin, dow cos/sin, comfort_now, comfort_soon, num_occupants */
 #define SB_INFO_STRIDE 24  /* floats per building in the optional info output */
@@ -157,6 +158,10 @@ typedef struct sb_step_in {
    * (environment.py:52).  With this pointer set, the "previous thermostat update" of comfort_prev is
    * tracked per building on the device. */
   const uint8_t *reject_dev;
+  /* non-zero: actions_dev holds NATIVE setpoint values (what SingleActionRequest.continuous_value
+   * carries, simulator_building.py:236-251) instead of normalised ones; a column holding a value
+   * <= SB_ACTION_KEEP leaves its field alone (a request that does not mention it) */
+  int32_t actions_native;
   double occupancy;        /* average_zone_occupancy over [t+dt, t+2dt], all zones */
   const double *occupancy_dev; /* optional DEVICE [Z] per-zone occupancy; overrides */
   /* optional per-building occupancy (sb_occupancy_peek): overrides both of the above */

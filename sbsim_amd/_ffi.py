@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SBSIM_LIB") or os.path.join(_HERE, "libsbsim_amd.so")
 
 SB_NUM_ACTIONS = 2     # the SB1 action set; sb_params.n_actions is the width of an action row
 SB_MAX_ACTIONS = 16
+SB_ACTION_KEEP = -3.0e38   # sb_step_in.actions_native: this column leaves its field alone
 SB_NUM_AUX = 7
 SB_ABI_VERSION = 5   # include/sbsim_amd.h
 # sb_action_kind
@@ -68,7 +69,7 @@ class StepIn(C.Structure):
               ("weather_times_dev", C.c_void_p), ("weather_tempf_dev", C.c_void_p), ("weather_offset_dev", C.c_void_p),
               ("weather_n", C.c_int32), ("weather_t_now", C.c_double), ("weather_t_next", C.c_double),
               ("comfort_now", C.c_int32), ("comfort_prev", C.c_int32),
-              ("comfort_next", C.c_int32), ("has_action", C.c_int32), ("reject_dev", C.c_void_p),
+              ("comfort_next", C.c_int32), ("has_action", C.c_int32), ("reject_dev", C.c_void_p), ("actions_native", C.c_int32),
               ("occupancy", C.c_double), ("occupancy_dev", C.c_void_p),
               ("occupancy_bz_dev", C.c_void_p), ("num_occupants_dev", C.c_void_p), ("occupancy_norm", C.c_double),
               ("e_price", C.c_double), ("e_carbon", C.c_double),

@@ -345,7 +345,8 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
     damper_cmd[i] = 0.0;
     if (!acting) continue; // bounded_action_normalizer.py:73-98, then the proto float field
     const double ai = (double)s.actions[(size_t)b * p.n_actions + i];
-    const double native = (double)(float)((ai + 1.0) / 2.0 * (p.act_hi[i] - p.act_lo[i]) + p.act_lo[i]);
+    if (in.actions_native && ai <= (double)SB_ACTION_KEEP) continue; // the request does not mention this field
+    const double native = in.actions_native ? ai : (double)(float)((ai + 1.0) / 2.0 * (p.act_hi[i] - p.act_lo[i]) + p.act_lo[i]);
     switch (p.act_kind[i]) {
       case SB_ACT_BOILER_SUPPLY_WATER_SETPOINT: v.blr_sp = native; boiler_action = true; break;
       case SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT: v.heat_sp = native; break;

@@ -108,3 +108,101 @@ def test_hip_action_set_and_rejections_against_reference_golden(path, monkeypatc
   sc = sim.scalars().cpu().numpy()
   assert np.allclose(sc[:4, 8], g["blr_tank_temp"][-1], atol=1e-9)
   sim.close()
+
+
+@pytest.mark.gpu
+def test_hip_simulator_building_replays_the_reference_rollout():
+  """``HipSimulatorBuilding`` -- BaseBuilding's request / response interface
+  (simulator_building.py:151-315) on the HIP library -- driven exactly like the harness that made
+  tests/golden/h2_sb1_r9_random.npz drove the reference's SimulatorBuilding: request_action ->
+  wait_time -> request_observations -> reward_info, one simulated day."""
+  torch = pytest.importorskip("torch")
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+  import datetime as dt
+  from sbsim_amd import building_adapter as ba
+  from tests.test_gpu_parity import _plan
+  g = load("h2_sb1_r9_random.npz")
+  start = dt.datetime.fromisoformat(str(g["start_timestamp"]))
+  b = ba.HipSimulatorBuilding(_plan(load("plan_r9_sb1.npz")), start_timestamp=start, holiday_calendar=None)
+  assert b.time_step_sec == 300.0 and b.current_timestamp == start and len(b.zones) == 9 and len(b.devices) == 11
+  req = b.observation_request_for_all_fields()
+  names = [f"{r.device_id}/{r.measurement_name}" for r in req.single_observation_requests]
+  assert [n.split("/")[1] for n in names] == [str(n).split("/")[-1] for n in g["obs_names"]]
+  first = b.request_observations(req)
+  assert np.allclose([r.continuous_value for r in first.single_observation_responses], g["obs_reset"], rtol=1e-6, atol=1e-6)
+  T = len(g["n_sweeps"])
+  for t in range(T):
+    assert int(b.current_timestamp.replace(tzinfo=dt.timezone.utc).timestamp()) == int(g["ts_seconds"][t])
+    areq = ba.ActionRequest(timestamp=b.current_timestamp, single_action_requests=[
+        ba.SingleActionRequest("boiler_id", "supply_water_setpoint", float(g["action_native"][t][0])),
+        ba.SingleActionRequest("air_handler_id", "supply_air_heating_temperature_setpoint", float(g["action_native"][t][1]))])
+    resp = b.request_action(areq)
+    assert all(r.response_type == ba.ActionResponseType.ACCEPTED for r in resp.single_action_responses)
+    b.wait_time()
+    obs = b.request_observations(req)
+    vals = np.array([r.continuous_value for r in obs.single_observation_responses])
+    assert all(r.observation_valid for r in obs.single_observation_responses)
+    assert np.allclose(vals, g["obs"][t], rtol=1e-6, atol=1e-6), t
+    ri = b.reward_info
+    zt = np.array([z.zone_air_temperature for z in ri.zone_reward_infos.values()])
+    assert np.abs(zt - g["ri_zone_temp"][t]).max() <= 4e-5, t   # fp32 fields of temperatures within 1e-8 K
+    assert np.allclose([z.heating_setpoint_temperature for z in ri.zone_reward_infos.values()], g["ri_heat_sp"][t])
+    assert np.allclose([z.cooling_setpoint_temperature for z in ri.zone_reward_infos.values()], g["ri_cool_sp"][t])
+    assert np.allclose([z.average_occupancy for z in ri.zone_reward_infos.values()], g["ri_occ"][t])
+    ah, bl = ri.air_handler_reward_infos["air_handler_id"], ri.boiler_reward_infos["boiler_id"]
+    rates = [ah.blower_electrical_energy_rate, ah.air_conditioning_electrical_energy_rate,
+             bl.natural_gas_heating_energy_rate, bl.pump_electrical_energy_rate]
+    assert np.allclose(rates, g["rates"][t].astype(np.float64), rtol=2e-6, atol=1e-6), t
+    assert abs(b.last_reward - float(g["reward"][t])) < 1e-6, t
+    assert b.num_occupants == int(g["num_occupants"][t]), t
+  # an unknown device, a field that is not settable, a damper command the handle does not drive
+  resp = b.request_action(ba.ActionRequest(single_action_requests=[
+      ba.SingleActionRequest("no_such_device", "supply_water_setpoint", 340.0),
+      ba.SingleActionRequest("boiler_id", "supply_water_temperature_sensor", 340.0),
+      ba.SingleActionRequest(b.devices[2].device_id, "supply_air_damper_percentage_command", 0.5)]))
+  assert [r.response_type for r in resp.single_action_responses] == [
+      ba.ActionResponseType.REJECTED_INVALID_DEVICE, ba.ActionResponseType.REJECTED_NOT_ENABLED_OR_AVAILABLE,
+      ba.ActionResponseType.REJECTED_NOT_ENABLED_OR_AVAILABLE]
+  bad = b.request_observations(ba.ObservationRequest(single_observation_requests=[ba.SingleObservationRequest("boiler_id", "nope")]))
+  assert not bad.single_observation_responses[0].observation_valid
+  b.close()
+
+
+@pytest.mark.gpu
+def test_hip_simulator_building_rejections_and_damper_commands():
+  """The same interface on the four-column action set of h2_sb1_r9_actions.npz: a step whose request
+  the building rejected is ``wait_time`` without ``request_action``; a damper command outside [0, 1]
+  comes back REJECTED_NOT_ENABLED_OR_AVAILABLE while the other setpoints apply."""
+  torch = pytest.importorskip("torch")
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+  import datetime as dt
+  from sbsim_amd import building_adapter as ba
+  from sbsim_amd.environment import SimConfig
+  from tests.test_gpu_parity import T_TOL, _plan
+  g = load("h2_sb1_r9_actions.npz")
+  cfg = SimConfig.sb1()
+  cfg.action_names = tuple(str(n) for n in g["action_names"])
+  cfg.action_zones = tuple(int(z) for z in g["action_zone"])
+  cfg.action_ranges = tuple((float(lo), float(hi)) for lo, hi in g["action_ranges"])
+  b = ba.HipSimulatorBuilding(_plan(load("plan_r9_sb1.npz")), config=cfg, holiday_calendar=None,
+                              start_timestamp=dt.datetime.fromisoformat(str(g["start_timestamp"])))
+  vav = b.devices[2 + int(g["action_zone"][3])].device_id
+  for t in range(len(g["n_sweeps"])):
+    nat = [float(x) for x in g["action_native_all"][t]]
+    if not g["rejected"][t]:
+      resp = b.request_action(ba.ActionRequest(timestamp=b.current_timestamp, single_action_requests=[
+          ba.SingleActionRequest("boiler_id", "supply_water_setpoint", nat[0]),
+          ba.SingleActionRequest("air_handler_id", "supply_air_heating_temperature_setpoint", nat[1]),
+          ba.SingleActionRequest("air_handler_id", "supply_air_cooling_temperature_setpoint", nat[2]),
+          ba.SingleActionRequest(vav, "supply_air_damper_percentage_command", nat[3])]))
+      ok = all(r.response_type == ba.ActionResponseType.ACCEPTED for r in resp.single_action_responses)
+      assert ok == bool(g["action_accepted"][t]), t
+      assert [r.response_type for r in resp.single_action_responses[:3]] == [ba.ActionResponseType.ACCEPTED] * 3
+    b.wait_time()
+    assert int(b._info_row[4]) == int(g["n_sweeps"][t]), t
+    zt = b.env.sim.zone_temps()[0].cpu().numpy()
+    assert np.abs(zt - g["zone_temp_post"][t]).max() < T_TOL, t
+    assert abs(b.last_reward - float(g["reward"][t])) < 1e-6, t
+  b.close()
