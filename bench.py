@@ -103,8 +103,9 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
     step_times.append(time.perf_counter() - t0)
     t_cpu += step_times[-1]
     sweeps += sum(outs[b].n_sweeps for b in range(nb))
-    # bounded sample: all of the timed steps unless the host is so busy that it would take long
-    if (t_cpu * threads >= target_cpu_seconds and len(step_times) >= 12) or t_cpu > 20.0:
+    # bounded sample: at least ~2.5 s of wall time (a sub-second sample on a shared host is noise),
+    # at most ~25 s
+    if (t_cpu >= 2.5 and t_cpu * threads >= target_cpu_seconds and len(step_times) >= 12) or t_cpu > 25.0:
       if threads == 1 or n_steps + 2 > max_steps:
         break
       n_now = 1
@@ -180,6 +181,91 @@ def stub_rank(args) -> None:
     dist.destroy_process_group()
 
 
+MIXED_CLASSES = [("R9", (3, 3), (20, 30)), ("SB2-synth", (8, 5), (12, 14)), ("SB1-synth", (14, 9), (8, 7))]
+
+
+def mixed_config(args) -> None:
+  """BASELINE.json configs[2] (SURVEY.md 8d "Config 3"): the batch split evenly over three floor-plan
+  classes -- R9 (9 zones), "SB2-synth" (8x5 rooms, 40 zones), "SB1-synth" (14x9 rooms, 126 zones, the
+  real SB1's VAV count; SB2 / SB3 do not exist in the reference) -- one handle per class, each on its
+  own HIP stream so that the classes' launches overlap, random setpoint actions.  One JSON line;
+  `roofline` sums the algorithmic bytes of the three sweep kernels over their summed durations."""
+  dev = torch.device("cuda", 0)
+  torch.cuda.set_device(0)
+  B_each, K, W = args.buildings // len(MIXED_CLASSES), args.steps, args.warmup
+  classes = []
+  for name, rooms, shape in MIXED_CLASSES:
+    plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+      env = BatchedEnvironment(plan, B_each, device=0, holiday_calendar="us", collect_info=True, num_days_in_episode=3)
+      rs = np.random.RandomState(7)
+      H, Wd = plan.shape
+      t_init = torch.tensor(np.clip(294.0 + rs.randn(B_each), 285.0, 305.0), dtype=torch.float64, device=dev)
+      env.reset()
+      env.sim.reset(temps=t_init[:, None].expand(B_each, H * Wd).contiguous())
+      gen = torch.Generator(device=dev)
+      gen.manual_seed(1234)
+      acts = torch.rand((W + K, B_each, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+    classes.append(dict(name=name, env=env, acts=acts, stream=stream, ev=[], sweeps=0.0))
+  torch.cuda.synchronize(dev)
+
+  def round_(t, timed):
+    for c in classes:
+      with torch.cuda.stream(c["stream"]):
+        env = c["env"]
+        si = env.make_step_in(env.current_simulation_timestamp)
+        a = (c["acts"][t], si, env._obs, env._reward, env._info)
+        env.sim.step(*a, phases=1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        env.sim.step(*a, phases=2)
+        e1.record()
+        env.sim.step(*a, phases=4)
+        env._prev_thermostat_ts = env._now
+        env._now = env._now + env._step_interval
+        if timed:
+          c["ev"].append((e0, e1))
+
+  for t in range(W):
+    round_(t, False)
+  torch.cuda.synchronize(dev)
+  t0 = time.perf_counter()
+  for t in range(W, W + K):
+    round_(t, True)
+  torch.cuda.synchronize(dev)
+  elapsed = time.perf_counter() - t0
+  per_class, alg_bytes, kern_s = {}, 0.0, 0.0
+  for c in classes:
+    env, li = c["env"], c["env"].sim.launch_info
+    ms = float(np.mean([a.elapsed_time(b) for a, b in c["ev"]]))
+    alg = li["algorithmic_bytes_per_env_step"] * env.sim.B
+    alg_bytes += alg
+    kern_s += ms * 1e-3
+    per_class[c["name"]] = {
+        "grid": list(env.sim.plan.shape), "zones": env.sim.Z, "buildings": env.sim.B,
+        "kernel": "k_sweep_roll / k_sweep_reg" if li["path"] == 1 else "k_sweep_lds",
+        "sweep_kernel_ms": ms, "mean_sweeps_per_env_step": float(env.info[:, 4].mean()),
+        "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launch": li}
+  zone_updates = sum(c["env"].sim.B * c["env"].sim.Z for c in classes) * K
+  env_steps = sum(c["env"].sim.B for c in classes) * K
+  achieved = alg_bytes / kern_s / 1e9
+  print(json.dumps({
+      "metric": "zone-updates/sec over three floor-plan classes (mixed zone counts), 1 MI355X",
+      "value": zone_updates / elapsed, "unit": "zone-updates/s", "n_gpus": 1, "steps": K, "warmup": W,
+      "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "dtype": "f64", "data": "synthetic", "env_steps_per_s": env_steps / elapsed,
+      "config": {"workload": "BASELINE.json configs[2]: %d buildings x 3 floor-plan classes (R9, SB2-synth 40 zones, "
+                             "SB1-synth 126 zones), random setpoint actions, one handle and one HIP stream per class" % B_each,
+                 "classes": per_class},
+      "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                   "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                   "note": "sum of the three sweep kernels' algorithmic bytes over the sum of their durations "
+                           "(the kernels overlap: wall time per round is ms_per_step)"}}))
+  for c in classes:
+    c["env"].close()
+
+
 def main() -> None:
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -190,12 +276,19 @@ def main() -> None:
   ap.add_argument("--iteration-limit", type=int, default=100,
                   help="Simulator.iteration_limit (100 = the reference's SB1 value; 1 is used only to "
                        "calibrate the PMC byte counters on a known traffic pattern)")
+  ap.add_argument("--config", choices=("replicated", "mixed"), default="replicated",
+                  help="replicated: BASELINE.json configs[1] (the metric's configuration, default); "
+                       "mixed: configs[2], three floor-plan classes on one GPU")
   ap.add_argument("--stub-step", action="store_true",
                   help="developer / CPU test: launcher, barrier and return-gather plumbing with a stub step (gloo)")
   args = ap.parse_args()
   launch_ranks_if_needed(args)
   if args.stub_step:
     return stub_rank(args)
+  if args.config == "mixed":
+    if args.gpus != 1:
+      raise SystemExit("bench.py --config mixed is a one-GPU configuration")
+    return mixed_config(args)
 
   rank, local_rank, world = sd.env_rank_world()
   torch.cuda.set_device(local_rank)
@@ -311,6 +404,10 @@ def main() -> None:
                      # steps run more sweeps: the start state is not an equilibrium); same quantity:
                      "avg_kernel_ms_all_launches_incl_warmup": float(np.mean(warm_ms + kernel_ms)),
                      "kernel_ms_timed": [round(x, 4) for x in kernel_ms],
+                     # sweeps-normalised cost (the timed window is a transient: sweeps per step fall from step to
+                     # step): what one of the chip's 1,024 SIMDs spends per building and sweep, everything included
+                     "simd_us_per_building_sweep": avg_kernel_s * 1e6 * 1024 / (B * (float(sweeps.item()) / (B * K))),
+                     "cell_sweeps_per_s": float(sweeps.item()) * H * Wd / (avg_kernel_s * K),
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "state_bytes_per_launch_fp64": li["state_bytes_per_env_step"] * B},
     }
@@ -322,7 +419,11 @@ def main() -> None:
       result["roofline"]["traffic_source"] = t.get("source")
     if world == 1 and not args.no_cpu_baseline:
       nb_s = 2048
-      acts_cpu = actions[:, :nb_s].cpu().numpy()
+      # the CPU leg goes on past the GPU's K timed steps (same action distribution, same generator)
+      # until its sample is a few seconds of wall time
+      more = torch.rand((400, nb_s, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+      actions = torch.cat([actions[:, :nb_s], more], dim=0)
+      acts_cpu = actions.cpu().numpy()
       base, grids, n_s, nb = cpu_baseline(env, plan, np.broadcast_to(t_init[:nb_s, None], (nb_s, H * Wd)).copy(),
                                           acts_cpu, W)
       # in-run parity: replay the same sample on the GPU and compare grids

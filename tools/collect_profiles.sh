@@ -2,7 +2,7 @@
 # Runs on the GPU box: rocprofv3 kernel-trace stats + HBM-traffic PMC passes for the bench command.
 # Outputs go to gpurun_out/profiles_<tag>/ (copy the summaries you want judged into profiles/).
 tag=${1:-r01}; shift
-STEPS=${STEPS:-12}; WARM=${WARM:-6}
+STEPS=${STEPS:-20}; WARM=${WARM:-5}   # the driver's bench command
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/profiles_$tag
 mkdir -p $out
