@@ -26,12 +26,40 @@ def offsets(distance: int):
           if dx * dx + dy * dy <= distance]
 
 
+def whole_room_permutation(n: int, gb: int, call: int, z: int, seed: int) -> np.ndarray:
+  """dest[r] of the device's whole-room shuffle (k_convect_all, generators.hip): a keyed bijection on
+  the ranks 0..n-1 of a room's cells in raster order -- three rounds of (odd multiply, add,
+  xor-shift) on k = ceil(log2 n) bits, cycle-walked into [0, n).  Keys: two Philox blocks with
+  counters (building lo, hi, call, 0x80000000 | 2 z [+ 1])."""
+  M = 0xFFFFFFFF
+  one = lambda v: np.array([v], dtype=np.uint64)
+  c = philox4x32_10(one(gb & M), one(gb >> 32), one(call), one(0x80000000 | (2 * z)), seed & M, (seed >> 32) & M)
+  d = philox4x32_10(one(gb & M), one(gb >> 32), one(call), one(0x80000000 | (2 * z + 1)), seed & M, (seed >> 32) & M)
+  k = max(1, int(n - 1).bit_length())
+  mask = (1 << k) - 1
+  s0, s1 = max(1, k // 2), max(1, (k + 1) // 3)
+  m = [int(c[0][0]) | 1, int(c[1][0]) | 1, int(c[2][0]) | 1]
+  a = [int(c[3][0]), int(d[0][0]), int(d[1][0])]
+  dest = np.zeros(n, dtype=np.int64)
+  for r in range(n):
+    x = r
+    while True:
+      x = ((x * m[0] + a[0]) & M) & mask; x ^= x >> s0
+      x = ((x * m[1] + a[1]) & M) & mask; x ^= x >> s1
+      x = ((x * m[2] + a[2]) & M) & mask; x ^= x >> s0
+      if x < n:
+        break
+    dest[r] = x
+  return dest
+
+
 class ConvectionOracle:
 
   def __init__(self, zone_cell_lists, H: int, W: int, p: float, distance: int, seed: int, first_building: int = 0):
     self.zones = [np.asarray(c, dtype=np.int64) for c in zone_cell_lists]
     self.H, self.W, self.p, self.seed, self.first = H, W, float(p), int(seed), int(first_building)
-    self.off = offsets(distance)
+    self.whole_room = distance == -1 and float(p) == 1.0   # stochastic_convection_simulator.py:78-99
+    self.off = [] if self.whole_room else offsets(distance)
     self.room = np.full(H * W, -1, dtype=np.int64)
     self.local = np.full(H * W, -1, dtype=np.int64)
     for z, cells in enumerate(self.zones):
@@ -70,6 +98,13 @@ class ConvectionOracle:
     for b in range(B):
       for z, cells in enumerate(self.zones):
         v = flat[b, cells].copy()
+        if self.whole_room:
+          order = np.argsort(cells, kind="stable")          # rank = position in raster order
+          dest = whole_room_permutation(len(cells), self.first + b, self.call, z, self.seed)
+          out = v.copy()
+          out[order[dest]] = v[order]                       # the value of rank r goes to rank dest[r]
+          flat[b, cells] = out
+          continue
         for i, o in self.swaps(b, z, self.call):
           v[i], v[o] = v[o], v[i]
         flat[b, cells] = v

@@ -21,7 +21,7 @@ from oracle import refshim
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 H, W = 16, 20
-CASES = [(1.0, 5), (0.5, 5), (1.0, 2)]
+CASES = [(1.0, 5), (0.5, 5), (1.0, 2), (1.0, -1)]   # the last: the whole-room shuffle (:78-99)
 TRIALS = 400
 
 
@@ -52,7 +52,8 @@ def main() -> None:
           fixed += int(dx == 0 and dy == 0)
           msd += dx * dx + dy * dy
           if 5 <= sx <= H - 6 and 5 <= sy <= W - 6:
-            hist[dx + 8, dy + 8] += 1
+            if abs(dx) <= 8 and abs(dy) <= 8:   # the whole-room shuffle moves values further: that mass stays outside
+              hist[dx + 8, dy + 8] += 1
             n_inner += 1
     out[f"hist_{ci}"] = hist / n_inner
     out[f"fixed_{ci}"] = np.array(fixed / (TRIALS * len(room)))

@@ -93,6 +93,25 @@ struct ConvArgs {
 };
 
 constexpr int kConvMaxThreads = 512, kConvMaxPerLane = 8;
+
+// The whole-room shuffle (distance = -1, p = 1: stochastic_convection_simulator.py:78-99,
+// _shuffle_no_max_dist): the values of a room's cells are permuted uniformly at random
+// (random.shuffle).  Here: a keyed bijection on the room's cells in the CALLER's raster order
+// (rank r of a cell = its position in the zone's cell list), dest = pi(r): three rounds of
+// (odd multiply, add, xor-shift) on k = ceil(log2 n) bits, walked until the result is < n (cycle
+// walking keeps it a bijection on [0, n)).  Keys: Philox4x32-10, key = seed, counters (global
+// building lo, hi, call number, 0x80000000 | 2 * room [+1]).  Not the Fisher-Yates of the reference --
+// no counter-based generator reproduces Python's global random -- but its displacement statistics
+// are the reference's (tests/test_convection.py).
+struct PermKeys { uint32_t m[3], a[3]; int k, s0, s1; uint32_t mask; };
+__host__ __device__ inline uint32_t perm_apply(const PermKeys &K, uint32_t x, uint32_t n) {
+  do {
+    x = (x * K.m[0] + K.a[0]) & K.mask; x ^= x >> K.s0;
+    x = (x * K.m[1] + K.a[1]) & K.mask; x ^= x >> K.s1;
+    x = (x * K.m[2] + K.a[2]) & K.mask; x ^= x >> K.s0;
+  } while (x >= n);
+  return x;
+}
 constexpr int kConvMaxRoom = 2047; // a cell's index in its room fits 11 bits next to the 20-bit grid index
 
 // A cell's own swap in LDS, one 16-byte read per visit: the random key of its time stamp; the
@@ -191,6 +210,60 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
   }
 }
 
+struct ConvAllArgs {
+  double *temp;
+  size_t stride;
+  const int *zone_off, *by_rank; // by_rank[zone_off[z] + r]: index (in the zone's ConvCell list) of the cell with rank r
+  const ConvCell *cells;         // .pad = the cell's rank
+  int B, Z;
+  uint64_t seed;
+  long long first_building;
+  uint32_t call;
+};
+
+// One workgroup per building at a time, room by room: read every value, barrier, write it to
+// its destination cell.
+__global__ void __launch_bounds__(256) k_convect_all(ConvAllArgs o) {
+  for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
+    double *st = o.temp + (size_t)b * o.stride;
+    const unsigned long long gb = (unsigned long long)(o.first_building + b);
+    for (int z = 0; z < o.Z; ++z) {
+      const int c0 = o.zone_off[z], n = o.zone_off[z + 1] - c0;
+      if (n < 2) continue;
+      PermKeys K;
+      uint32_t c[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, 0x80000000u | (uint32_t)(2 * z)};
+      uint32_t d[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, 0x80000000u | (uint32_t)(2 * z + 1)};
+      philox4x32_10(c, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
+      philox4x32_10(d, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
+      K.k = 32 - __clz(n - 1);
+      K.mask = K.k >= 32 ? 0xffffffffu : ((1u << K.k) - 1u);
+      K.s0 = max(1, K.k / 2); K.s1 = max(1, (K.k + 1) / 3);
+      K.m[0] = c[0] | 1u; K.m[1] = c[1] | 1u; K.m[2] = c[2] | 1u;
+      K.a[0] = c[3]; K.a[1] = d[0]; K.a[2] = d[1];
+      constexpr int kQ = 8; // cells per lane: rooms of up to 2048 cells (sb_convection_attach checks)
+      double val[kQ];
+      int dst[kQ];
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) {
+        const int i = threadIdx.x + q * blockDim.x;
+        if (i < n) {
+          const ConvCell cc = o.cells[c0 + i];
+          val[q] = st[cc.sidx];
+          const int j = o.by_rank[c0 + (int)perm_apply(K, (uint32_t)cc.pad, (uint32_t)n)];
+          dst[q] = o.cells[c0 + j].sidx;
+        }
+      }
+      __syncthreads(); // every value of the room is read before the first one is written
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) {
+        const int i = threadIdx.x + q * blockDim.x;
+        if (i < n) st[dst[q]] = val[q];
+      }
+      __syncthreads();
+    }
+  }
+}
+
 } // namespace
 
 extern "C" {
@@ -245,11 +318,13 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   if (!(p >= 0.0 && p <= 1.0)) return fail(SB_ERR_INVALID, "sb_convection_attach: p must be in [0, 1]");
   if (first_building < 0) return fail(SB_ERR_INVALID, "sb_convection_attach: first_building must be >= 0");
   if (p == 0.0 || distance == 0) { h->conv_attached = false; return SB_OK; } // stochastic_convection_simulator.py:70-71
-  if (distance < 0 || distance > 64)
-    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: distance must be 1..64 (distance = -1, the whole-room "
-                                    "shuffle of stochastic_convection_simulator.py:80-99, is not implemented)");
+  const bool whole_room = distance == -1 && p == 1.0; // stochastic_convection_simulator.py:78: the special case
+  if (!whole_room && (distance < 0 || distance > 64))
+    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: distance must be 1..64, or -1 with p = 1 (the whole-room "
+                                    "shuffle; distance = -1 with p < 1 is a 1000-cell window in the reference: not implemented)");
   SB_ON_DEVICE(h->device);
   const Dev &d = h->d;
+  if (whole_room) distance = 0; // no offset window
   // :125-131: window [-distance, distance) in both directions, squared distance <= distance
   // (in the order of the caller's grid: the handle may hold the transposed floor plan)
   if (d.N >= (1 << 20)) return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: more than 2^20 grid cells");
@@ -267,6 +342,7 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   for (int z = 0; z < d.Z; ++z)
     for (int i = h->h_zone_off[z]; i < h->h_zone_off[z + 1]; ++i) room[h->h_zone_cells[i]] = z;
   std::vector<ConvCell> cells(h->h_zone_cells.size());
+  std::vector<int> by_rank(h->h_zone_cells.size(), 0);
   int max_room = 1;
   for (int z = 0; z < d.Z; ++z) {
     const int c0 = h->h_zone_off[z], n = h->h_zone_off[z + 1] - c0;
@@ -275,11 +351,18 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
     for (int g : order)
       if (h->h_state_index[g] < 0) return fail(SB_ERR_INVALID, "sb_convection_attach: a zone cell lies in the exterior ring");
     std::sort(order.begin(), order.end(), [&](int a, int b) { return h->h_state_index[a] < h->h_state_index[b]; });
+    // rank of a cell in the CALLER's raster order (the whole-room shuffle permutes ranks)
+    std::vector<int> by_g0(order);
+    auto g0_of = [&](int g) { return transposed ? (g % d.W) * d.H + g / d.W : g; };
+    std::sort(by_g0.begin(), by_g0.end(), [&](int a, int b) { return g0_of(a) < g0_of(b); });
+    std::vector<int> rank_of((size_t)d.N, 0);
+    for (int r = 0; r < n; ++r) rank_of[by_g0[r]] = r;
     for (int i = 0; i < n; ++i) {
       const int g = order[i], x = g / d.W, y = g % d.W;
       local[g] = i;
+      by_rank[(size_t)c0 + rank_of[g]] = i;
       ConvCell &c = cells[(size_t)c0 + i];
-      c.gh = g; c.g0 = transposed ? y * d.H + x : g; c.sidx = h->h_state_index[g]; c.pad = 0; c.mask = 0;
+      c.gh = g; c.g0 = transposed ? y * d.H + x : g; c.sidx = h->h_state_index[g]; c.pad = rank_of[g]; c.mask = 0;
       for (size_t k = 0; k < offd.size(); ++k) {
         const int xx = x + odx[k], yy = y + ody[k];
         if (xx >= 0 && xx < d.H && yy >= 0 && yy < d.W && room[xx * d.W + yy] == z) c.mask |= 1ull << k;
@@ -288,7 +371,7 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   }
   if (max_room > kConvMaxRoom)
     return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: a room has more than 2047 cells");
-  for (DevBuf<int> *buf : {&h->conv_local, &h->conv_off}) {
+  for (DevBuf<int> *buf : {&h->conv_local, &h->conv_off, &h->conv_by_rank}) {
     if (buf->p) (void)hipFree(buf->p); // attached before: replace
     buf->p = nullptr;
   }
@@ -297,6 +380,8 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   if ((rc = upload(h->conv_local, local.data(), local.size())) != SB_OK) return rc;
   if ((rc = upload(h->conv_off, offd.data(), offd.size())) != SB_OK) return rc;
   if ((rc = upload(h->conv_cells, cells.data(), cells.size())) != SB_OK) return rc;
+  if ((rc = upload(h->conv_by_rank, by_rank.data(), by_rank.size())) != SB_OK) return rc;
+  h->conv_whole_room = whole_room;
   h->conv_p = p; h->conv_n_off = (int)offd.size(); h->conv_max_room = max_room;
   h->conv_seed = seed; h->conv_first = first_building; h->conv_calls = 0;
   h->conv_attached = true;
@@ -307,6 +392,15 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
 
 int sb_launch_convection(sb_handle *h, hipStream_t stream) {
   const Dev &d = h->d;
+  if (h->conv_whole_room) {
+    ConvAllArgs w;
+    w.temp = d.temp; w.stride = d.reg ? (size_t)d.state_doubles : (size_t)d.Np;
+    w.zone_off = h->zone_off.p; w.by_rank = h->conv_by_rank.p; w.cells = h->conv_cells.p;
+    w.B = d.B; w.Z = d.Z; w.seed = h->conv_seed; w.first_building = h->conv_first; w.call = h->conv_calls++;
+    hipLaunchKernelGGL(k_convect_all, dim3(std::max(1, std::min(d.B, h->cus * 8))), dim3(256), 0, stream, w);
+    SB_HIP(hipGetLastError());
+    return SB_OK;
+  }
   ConvArgs o;
   o.temp = d.temp; o.stride = d.reg ? (size_t)d.state_doubles : (size_t)d.Np;
   o.zone_off = h->zone_off.p; o.local = h->conv_local.p; o.off = h->conv_off.p; o.cells = h->conv_cells.p;

@@ -96,6 +96,8 @@ struct sb_handle {
   std::vector<int> h_zone_off, h_zone_cells, h_state_index; // state index of every grid cell (< 0: exterior ring)
   // sb_convection_attach
   DevBuf<int> conv_local, conv_off; // per grid cell: index in its room's list; the offset table as linear steps
+  DevBuf<int> conv_by_rank;         // whole-room shuffle: list index of the room's cell with raster rank r
+  bool conv_whole_room = false;
   DevBuf<ConvCell> conv_cells;
   double conv_p = 0.0;
   int conv_n_off = 0, conv_max_room = 0;

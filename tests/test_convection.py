@@ -17,7 +17,8 @@ def _stats(grids, H, W):
   room[1:H - 1, 1:W - 1] = True
   inner = room[None] & (sx >= 5) & (sx <= H - 6) & (sy >= 5) & (sy <= W - 6)
   hist = np.zeros((17, 17))
-  np.add.at(hist, (dx[inner] + 8, dy[inner] + 8), 1)
+  near = inner & (np.abs(dx) <= 8) & (np.abs(dy) <= 8)   # further moves (whole-room shuffle) stay outside the window
+  np.add.at(hist, (dx[near] + 8, dy[near] + 8), 1)
   n_room = B * room.sum()
   fixed = ((dx == 0) & (dy == 0) & room[None]).sum() / n_room
   msd = ((dx * dx + dy * dy) * room[None]).sum() / n_room
@@ -32,7 +33,7 @@ def test_offset_window_is_the_reference_one():
   assert len(offsets(2)) == 9 and offsets(1) == [(-1, 0), (0, -1), (0, 0)]    # the window is half-open: [-d, d)
 
 
-@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
 def test_restatement_matches_reference_displacement_statistics(case):
   """24,000 tracked values on each side.  Bin probabilities <= 0.25 -> sigma of a difference
   <= sqrt(2 * 0.25 * 0.75 / 24000) = 0.004; 0.02 is five sigma."""
@@ -78,11 +79,12 @@ def _need_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["reg", "lds"])
-def test_device_shuffle_equals_its_restatement_inside_a_rollout(kernel, monkeypatch):
-  """R9, SB1 physics, convection p = 1 / distance = 5 (sim_config.gin:36-39) after every FD
-  update: sweep counts, zone temperatures and the final grid against oracle twins whose grids
-  get the restatement's shuffle after every step."""
+@pytest.mark.parametrize("kernel,distance", [("reg", 5), ("lds", 5), ("reg", -1), ("lds-columns", -1)])
+def test_device_shuffle_equals_its_restatement_inside_a_rollout(kernel, distance, monkeypatch):
+  """R9, SB1 physics, convection p = 1 / distance = 5 (sim_config.gin:36-39) -- or the whole-room
+  shuffle, distance = -1 (stochastic_convection_simulator.py:78-99) -- after every FD update: sweep
+  counts, zone temperatures and the final grid against oracle twins whose grids get the
+  restatement's shuffle after every step."""
   _need_gpu()
   import torch
   from oracle import oracle as orc
@@ -90,7 +92,7 @@ def test_device_shuffle_equals_its_restatement_inside_a_rollout(kernel, monkeypa
   from sbsim_amd.environment import BatchedSimulator, SimConfig
   from tests.golden_util import oracle_params, oracle_plan
   from tests.test_gpu_parity import T_TOL, _plan, _step_in
-  if kernel == "lds":
+  if kernel.startswith("lds"):
     monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
   g = load("h2_sb1_r9_random.npz")
   p = load("plan_r9_sb1.npz")
@@ -99,11 +101,13 @@ def test_device_shuffle_equals_its_restatement_inside_a_rollout(kernel, monkeypa
   init = np.clip(294.0 + rs.randn(B, 1, 1) + 0.8 * rs.randn(B, 68, 98), 285.0, 305.0)
   acts = rs.uniform(-1, 1, size=(T, B, 2)).astype(np.float32)
   fp = _plan(p)
-  sim = BatchedSimulator(fp, SimConfig.sb1(), B, float(g["h_conv"]))
+  sim = BatchedSimulator(fp, SimConfig.sb1(), B, float(g["h_conv"]),
+                         orientation="columns" if kernel == "lds-columns" else "auto")
   assert sim.launch_info["path"] == (1 if kernel == "reg" else 0)
-  sim.convection_attach(1.0, 5, seed=4242, first_building=first)
+  assert sim.transposed or kernel != "lds-columns"     # the permutation is defined on the CALLER's raster order
+  sim.convection_attach(1.0, distance, seed=4242, first_building=first)
   sim.reset(temps=torch.tensor(init.reshape(B, -1), dtype=torch.float64, device="cuda"))
-  conv = ConvectionOracle(fp.zone_cell_lists(), 68, 98, 1.0, 5, seed=4242, first_building=first)
+  conv = ConvectionOracle(fp.zone_cell_lists(), 68, 98, 1.0, distance, seed=4242, first_building=first)
   plan, prm = oracle_plan(p), oracle_params(g["params_json"])
   twins = [orc.OracleBuilding(plan, prm, 0.0, reset_temps=init[b].reshape(-1)) for b in range(B)]
   obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
@@ -148,8 +152,9 @@ def test_convection_attach_argument_checks():
   sim = BatchedSimulator(fp, SimConfig.sb1(), 3, 100.0)
   sim.convection_attach(0.0, 5, seed=1)       # p == 0: the reference returns early -> detached
   sim.convection_attach(1.0, 0, seed=1)
+  sim.convection_attach(1.0, -1, seed=1)      # the whole-room shuffle (stochastic_convection_simulator.py:78)
   with pytest.raises(_ffi.SbsimError, match="whole-room"):
-    sim.convection_attach(1.0, -1, seed=1)
+    sim.convection_attach(0.5, -1, seed=1)    # distance = -1 with p < 1: the reference's 1000-cell window, not implemented
   with pytest.raises(_ffi.SbsimError, match=r"p must be in \[0, 1\]"):
     sim.convection_attach(1.5, 5, seed=1)
   sim.close()
