@@ -65,7 +65,7 @@ struct Dev {
   // ---- register path (step_reg.hip); reg == 0 when the floor plan is not eligible ----
   int reg;                 // 1: k_step_reg owns the step
   int NR;                  // slots per lane (>= trimmed width), one of the instantiated sizes
-  int P;                   // kernel mode: 1 / 2 wavefronts per building, 3 = 1 wavefront + tail rows
+  int P;                   // kernel mode: 1 / 2 wavefronts per building, 3 = 1 wavefront + tail rows, 4 = two rows per lane
   int T;                   // mode 3: rows 64..64+T-1 are finished by the tail scan (T <= 2)
   int state_doubles;       // doubles of HBM state per building
   const uint8_t *tcls;     // mode 3: [T][NR] classes of the tail cells (class * 8)
@@ -133,6 +133,14 @@ int sweep_reg_waves_per_simd(int NR, int P); // register budget of the instantia
 bool sweep_reg_overlaps_sweeps(int NR, int P); // a sweep costs NR steps (lanes start the next sweep while others finish)
 // step_roll.hip: mode 3 (one wavefront + tail rows, overlapped sweeps)
 int launch_sweep_roll(const Dev &d, hipStream_t stream);
+// step_two.hip: mode 4 (one wavefront, two rows per lane: 67..130 rows, <= 80 columns)
+int launch_sweep_two(const Dev &d, hipStream_t stream);
+int prepare_sweep_two(const Dev &d);
+bool sweep_two_supported(int NR);
+int sweep_two_lds_slots(int NR);
+int sweep_two_a_stride(int NR);
+int sweep_two_seam_doubles(int NR);
+int sweep_two_set_table();
 int prepare_sweep_roll(const Dev &d);
 bool sweep_roll_supported(int NR);
 int sweep_roll_lds_slots(int NR);            // slots of A in LDS

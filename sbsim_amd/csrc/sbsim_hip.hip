@@ -163,6 +163,118 @@ constexpr int kRegSlots[] = {32, 66, 96};
 // workgroup barrier between its write and its (2-steps-early) read, in both directions
 int seam_lag(int lw0) { return (lw0 + 8) / 8 + 1; }
 
+bool env_flag(const char *name) {
+  const char *e = getenv(name);
+  return e && e[0] == '1';
+}
+
+// Mode 4 (step_two.hip): one wavefront, two rows per lane, up to 128 + 2 rows and 80 columns
+// inside the exterior ring.  (x0, y0): the trim box's corner; zone_of: zone of every cell or -1.
+bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const std::vector<int> &zone_of, RegPlan &r) {
+  const int W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = plan->H * plan->W;
+  auto coef = [&](int c, int j) { return plan->class_coef[c * 8 + j]; };
+  int NR = 0;
+  for (int s : {76, 80})
+    if (!NR && s >= Ws && sweep_two_supported(s)) NR = s;
+  if (!NR || Hs > 128 + 2) return false;
+  const int T = std::max(0, Hs - 128), Hw = Hs - T, nl = (Hw + 1) / 2;
+  for (int x = x0 + Hw; x < x0 + Hs; ++x)
+    for (int y = y0; y < y0 + Ws; ++y)
+      if (zone_of[x * W + y] >= 0) return false; // the tail scan adds no zone sums
+  int ts = 32;
+  while (ts < ncls + 1) ts *= 2;
+  if (ts > 256) return false;
+  const int pad = ncls;
+  std::vector<int> set_of(ncls + 1, 0);
+  r.csetab.clear();
+  for (int c = 0; c < ncls; ++c) {
+    int found = -1;
+    for (size_t k = 0; k < r.csetab.size() / 4 && found < 0; ++k)
+      if (r.csetab[4 * k] == coef(c, 0) && r.csetab[4 * k + 1] == coef(c, 1) && r.csetab[4 * k + 2] == coef(c, 2) &&
+          r.csetab[4 * k + 3] == coef(c, 3)) found = (int)k;
+    if (found < 0) {
+      found = (int)r.csetab.size() / 4;
+      for (int j = 0; j < 4; ++j) r.csetab.push_back(coef(c, j));
+    }
+    set_of[c] = found;
+  }
+  set_of[pad] = (int)r.csetab.size() / 4; // the pad set: no neighbour counts
+  for (int j = 0; j < 4; ++j) r.csetab.push_back(0.0);
+  if ((int)r.csetab.size() / 4 > sweep_two_set_table()) { r.csetab.clear(); return false; }
+
+  const int AS = sweep_two_a_stride(NR), ZRS = 65, NE = 2 * NR;
+  if ((Z + 1) * ZRS > 64 * AS || (Z + 1) * ZRS > 65535) { r.csetab.clear(); return false; } // the zone-sum scratch aliases A
+  int off = 4 * sweep_two_set_table() + 2 * ts;
+  r.r_seam = off; off += sweep_two_seam_doubles(NR);
+  r.r_A = off; off += 64 * AS;
+  r.r_xchg = off; off += 8;
+  r.AS = AS;
+  r.lds_bytes = off * 8;
+  if (const char *padb = getenv("SBSIM_DEBUG_LDS_PAD")) r.lds_bytes += atoi(padb);
+  r.wg_per_cu = std::min(4, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule));
+  if (r.wg_per_cu < 1) { r.csetab.clear(); return false; }
+
+  r.NR = NR; r.P = 4; r.RS = 64; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
+  r.T = T; r.ts = ts;
+  r.state_doubles = NE * 64 + T * NR;
+  r.lw[0] = nl; r.l0[0] = 0; r.rowbase[0] = 0; r.nch[0] = 0;
+  r.lag = 0; r.nslots = 0;
+  r.steps = NR + nl - 1 + 4 * T;
+  auto cell_class = [&](int R, int col) { // trimmed coordinates
+    return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? (int)plan->cell_class[(x0 + R) * W + (y0 + col)] : pad;
+  };
+  const int NW = (NR + 63 + 1) / 2, NWD = (NE + 3) / 4;
+  r.cmapS.assign((size_t)NW * 64, 0);
+  r.amapS.assign((size_t)NWD * 64, 0);
+  r.zmapS.assign((size_t)NWD * 64, 0);
+  r.tcls.assign((size_t)std::max(T, 1) * NR, (uint8_t)pad);
+  r.tcset.assign((size_t)std::max(T, 1) * NR, (uint8_t)(8 * set_of[pad]));
+  for (int t = 0; t < T; ++t)
+    for (int c = 0; c < NR; ++c) {
+      r.tcls[(size_t)t * NR + c] = (uint8_t)cell_class(Hw + t, c);
+      r.tcset[(size_t)t * NR + c] = (uint8_t)(8 * set_of[cell_class(Hw + t, c)]);
+    }
+  for (int lane = 0; lane < 64; ++lane) {
+    auto row_class = [&](int k, int col) { // lower / upper cell of the lane at a column of the wavefront rows
+      const int R = 2 * lane + k;
+      return (R < Hw && col >= 0 && col < NR) ? cell_class(R, col) : pad;
+    };
+    for (int wd = 0; wd < NW; ++wd) { // two steps per word: (upper, lower) set offsets
+      unsigned long long word = 0;
+      for (int k = 0; k < 4; ++k) {
+        const int st = 2 * wd + k / 2, col = st - lane;
+        word |= (unsigned long long)(set_of[row_class(k & 1, col)] * 32) << (16 * k);
+      }
+      r.cmapS[(size_t)wd * 64 + lane] = word;
+    }
+    for (int g = 0; g < NWD; ++g) { // register J = 2 * slot + (row & 1)
+      unsigned long long aword = 0, zword = 0;
+      for (int k = 0; k < 4; ++k) {
+        const int J = 4 * g + k, j = J / 2, col = ((j - lane) % NR + NR) % NR, R = 2 * lane + (J & 1);
+        const bool cell = J < NE && R < Hw && col < Ws;
+        aword |= (unsigned long long)((cell ? cell_class(R, col) : pad) * 16) << (16 * k);
+        int z = Z; // dump row
+        if (cell && zone_of[(x0 + R) * W + (y0 + col)] >= 0) z = zone_of[(x0 + R) * W + (y0 + col)];
+        zword |= (unsigned long long)(z * ZRS + lane) << (16 * k);
+      }
+      r.amapS[(size_t)g * 64 + lane] = aword;
+      r.zmapS[(size_t)g * 64 + lane] = zword;
+    }
+  }
+  r.cell_state.assign(N, 0);
+  int ring = 0;
+  for (int x = 0; x < plan->H; ++x)
+    for (int y = 0; y < W; ++y) {
+      const int R = x - x0, col = y - y0;
+      if (R < 0 || R >= Hs || col < 0 || col >= Ws) { r.cell_state[x * W + y] = -(++ring); continue; }
+      if (R >= Hw) { r.cell_state[x * W + y] = NE * 64 + (R - Hw) * NR + col; continue; }
+      const int lane = R >> 1;
+      r.cell_state[x * W + y] = (2 * ((col + lane) % NR) + (R & 1)) * 64 + lane;
+    }
+  r.ok = true;
+  return true;
+}
+
 // lds_per_cu: buildings per CU the LDS-grid kernel would hold (0: the plan does not fit it).
 void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   const int H = plan->H, W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = H * W;
@@ -189,6 +301,8 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   std::vector<int> zone_of(N, -1);
   for (int z = 0; z < Z; ++z)
     for (int i = plan->zone_off[z]; i < plan->zone_off[z + 1]; ++i) zone_of[plan->zone_cells[i]] = z;
+  // mode 4: one wavefront, two rows per lane (67..130 rows, <= 80 columns)
+  if (Hs > 64 + 2 && !env_flag("SBSIM_NO_TWO_ROW_PATH") && plan_two(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   auto pick_slots = [&](int mode) { // narrowest instantiation that holds the width and the class count
     for (int s : kRegSlots) {
       if (mode == 3) {
@@ -445,11 +559,6 @@ int check_plan(const sb_plan_desc *plan) {
   for (int c = 0; c < plan->n_classes; ++c)
     if (plan->class_zone[c] >= plan->Z) return fail(SB_ERR_INVALID, "sb_create: class zone out of range");
   return SB_OK;
-}
-
-bool env_flag(const char *name) {
-  const char *e = getenv(name);
-  return e && e[0] == '1';
 }
 
 void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan &q, int n_obs, int cus,
@@ -720,7 +829,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     if (alloc_zero(h->dbg, 16) == SB_OK) d.dbg = h->dbg.p;
   }
 
-  const int e = d.reg ? (d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
+  const int e = d.reg ? (d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
                       : prepare_sweep_lds((size_t)h->info.lds_bytes_per_workgroup);
   if (e != (int)hipSuccess) {
     delete h;
@@ -792,7 +901,9 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   if (phases & SB_PHASE_SWEEP) {
     if (!(phases & SB_PHASE_PRE)) // k_pre zeroes the sweep kernel's draw counter; without it in this call:
       SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream));
-    const int e = d.reg ? (d.P == 3 ? launch_sweep_roll(d, (hipStream_t)stream) : launch_sweep_reg(d, h->cus, (hipStream_t)stream))
+    const int e = d.reg ? (d.P == 4   ? launch_sweep_two(d, (hipStream_t)stream)
+                       : d.P == 3 ? launch_sweep_roll(d, (hipStream_t)stream)
+                                  : launch_sweep_reg(d, h->cus, (hipStream_t)stream))
                         : launch_sweep_lds(d, h->info.workgroups, h->info.waves_per_workgroup,
                                            (size_t)h->info.lds_bytes_per_workgroup, (hipStream_t)stream);
     if (e != (int)hipSuccess)

@@ -1,0 +1,541 @@
+// step_two.hip -- the sweep kernel for floor plans of 67..130 rows and <= 80 columns inside their
+// exterior ring: one wavefront per building, the grid in registers, TWO rows per lane.
+// simulator.py:278-371.
+//
+// A 129 x 75 grid of doubles is 77 KB -- more than the LDS share of a building once A = ap*Tprev + g
+// (another 77 KB) sits there, but less than the 128 KB register file of one SIMD.  So the grid
+// lives in the registers of ONE wavefront: lane l owns rows 2l and 2l + 1, column c of both in
+// register slot (c + l) mod NR, and every lane works on slot s mod NR at step s of a sweep (the
+// anti-diagonal order of step_reg.hip / step_roll.hip, which reproduces the reference's row-major
+// in-place update).  Per step a lane updates two cells:
+//   row 2l   : U = lane l-1's row 2l-1 result of the previous step (DPP), D = own row 2l+1 (old)
+//   row 2l+1 : U = the value just computed, D = lane l+1's row 2l+2 (old, DPP)
+// -- two DPP exchanges per two cells where the one-row layout needs four.  Rows 128.. (at most two)
+// are finished by the affine scan of step_roll.hip (lanes = columns).  A lives in LDS as
+// [lane][slot][2 rows]: one ds_read_b128 per step; coefficient sets as in step_roll.hip (two
+// ds_read_b128 per cell, addressed by 16-bit LDS offsets that arrive in class words from L2).
+//
+// Sweeps are NOT overlapped here: the copies that undo a started sweep (step_roll.hip) would need
+// another 252 registers.  A sweep costs NR + lanes - 1 steps; the ramp steps select by lane mask.
+// Two buildings fit in a CU's LDS, so two of the four SIMDs run (the LDS-grid kernel: one).
+#include "sb_device.h"
+
+namespace sb {
+namespace {
+
+constexpr int kTailMax = 2;
+constexpr int kSets = 32;  // entries of the coefficient-set table (at LDS address 0)
+constexpr int kWA = 4;     // class words (two steps each) are read this many words ahead
+constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in the hand-over
+constexpr int kG = 4;      // per-class g: up to 4 x 64 classes
+
+// Slots of A kept in LDS (the rest in registers): with them a building needs < 80 KB of LDS -- two
+// per CU.  Row stride 2 * slots + 2 doubles: 2 mod 4, conflict-free ds_read_b128 across 16 lanes.
+constexpr int lds_slots(int NR) { return NR <= 76 ? 72 : 74; }
+constexpr int a_stride(int NR) { return 2 * lds_slots(NR) + 2; }
+constexpr int tail_row(int NR) { return NR + 4; } // first tail row in LDS: column c at [2 + c], zero guards
+
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+template <int J>
+__device__ __forceinline__ bool lanes_upto() { // lanes 0..J as a lane predicate: one SALU instruction
+  unsigned long long m;
+  asm volatile("s_bfm_b64 %0, %1, 0" : "=s"(m) : "n"(J + 1));
+  return __builtin_amdgcn_inverse_ballot_w64(m);
+}
+
+// lane l <- lane l-1 (CTRL 0x138, wave_shr:1) / lane l+1 (0x130, wave_shl:1) / rotate (0x13c,
+// wave_ror:1).  SEAM: the lane without a source keeps `old`; otherwise it reads 0.
+template <int CTRL, bool SEAM>
+__device__ __forceinline__ double wave_shift1(double x, double old) {
+  int lo, hi;
+  if (SEAM) {
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, 0xf, false);
+  } else {
+    lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  }
+  return __hiloint2double(hi, lo);
+}
+
+typedef double d2 __attribute__((ext_vector_type(2))); // two doubles = one ds_read_b128
+typedef const d2 __attribute__((address_space(3))) *lds_d2;
+
+struct StepBuf {         // LDS values of one step
+  d2 uda, lra, udb, lrb; // (bU, bD), (bL, bR) of the lane's upper / lower cell
+  d2 A;                  // A of the two cells
+  double sm;             // old value of the first tail row under lane 63's lower cell
+};
+
+struct Acc {
+  double cur;      // max |delta| of the sweep
+  double sre, sro; // the last wavefront row's new values on their way to the tail scan (even / odd columns)
+};
+
+struct Ctx {
+  const double *Arow; // the lane's row of A: the cell pair of slot j at [2 j]
+  const double *seam; // first tail row by step: the value under lane 63 at step s is seam[s]
+  const char *cmap;   // class words (uniform)
+  unsigned voff;      // byte offset of the lane's last-read class word: 8 * lane + 512 * word
+  unsigned long long w[kWA + 1];
+};
+
+// Class words: per step two 16-bit fields -- the LDS byte offsets (set * 32) of the coefficient
+// sets of the lane's upper and lower cell -- two steps per 64-bit word, read from global memory
+// (L2 hits) kWA words ahead.
+template <int NR>
+constexpr int words_per_sweep() { return (NR + 63 + 1) / 2; }
+__device__ __forceinline__ unsigned long long class_word(const Ctx &x) {
+  return *(const unsigned long long *)(x.cmap + x.voff);
+}
+__device__ __forceinline__ void first_words(Ctx &x, int lane) { // words 0 .. kWA-1 of a sweep
+  x.voff = (unsigned)opaque(lane * 8);
+#pragma unroll
+  for (int k = 0; k < kWA; ++k) {
+    x.w[k] = class_word(x);
+    if (k + 1 < kWA) x.voff += 512u;
+  }
+}
+
+template <int NR, int S, bool TAIL, int NAR>
+__device__ __forceinline__ void load_step(StepBuf &p, Ctx &x, const double (&Areg)[NAR]) {
+  if constexpr (S % 2 == 0 && S / 2 + kWA < words_per_sweep<NR>()) {
+    x.voff += 512u;
+    asm volatile("" : "+v"(x.voff)); // a running offset: nothing for the compiler to hoist
+    x.w[(S / 2 + kWA) % (kWA + 1)] = class_word(x);
+  }
+  const unsigned long long wd = x.w[(S / 2) % (kWA + 1)];
+  const unsigned h = S % 2 == 0 ? (unsigned)wd : (unsigned)(wd >> 32);
+  const lds_d2 sa = (lds_d2)(h & 0xffffu), sb = (lds_d2)(h >> 16);
+  p.uda = sa[0];
+  p.lra = sa[1];
+  p.udb = sb[0];
+  p.lrb = sb[1];
+  constexpr int r = S % NR, NL = lds_slots(NR);
+  if constexpr (r < NL) p.A = *(const d2 *)(x.Arow + 2 * r);
+  else p.A = d2{Areg[2 * (r - NL)], Areg[2 * (r - NL) + 1]};
+  if constexpr (TAIL && S >= 63) p.sm = x.seam[S];
+  else p.sm = 0.0;
+}
+
+// One Gauss-Seidel update of every lane's two current cells at step S of a sweep:
+//   S < 63             ramp-up: lanes > S have not started
+//   63 <= S < NR       all 64 lanes
+//   NR <= S < NR + 63  ramp-down: lanes <= S - NR have finished
+// Association order of the four products as in step_lds.hip / step_reg.hip / step_roll.hip.
+template <int NR, int S, bool TAIL>
+__device__ __forceinline__ void step(double (&e)[2 * NR], const StepBuf &p, Acc &acc) {
+  constexpr int r = S % NR, rm = (S + NR - 1) % NR, rp = (S + 1) % NR;
+  const double U = wave_shift1<0x13c, false>(e[2 * rm + 1], 0.0); // lane 0 sees the last row's latest value (times bU = 0)
+  const double Dn = wave_shift1<0x130, true>(e[2 * rp], p.sm);
+  double t, t2;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t) : "v"(p.uda.y), "v"(e[2 * r + 1]), "v"(p.A.x));
+  t = fma(p.lra.y, e[2 * rp], t);
+  t = fma(p.lra.x, e[2 * rm], t);
+  const double nva = fma(p.uda.x, U, t);
+  asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t2) : "v"(p.udb.y), "v"(Dn), "v"(p.A.y));
+  t2 = fma(p.lrb.y, e[2 * rp + 1], t2);
+  t2 = fma(p.lrb.x, e[2 * rm + 1], t2);
+  const double nvb = fma(p.udb.x, nva, t2);
+  if constexpr (TAIL && S > 63) { // lane 0's U is column S - 64 of the last row: into the shift register of its parity
+    double &sr = (S - 64) % 2 == 0 ? acc.sre : acc.sro;
+    sr = wave_shift1<0x138, true>(sr, U);
+  }
+  double sa = nva, sb = nvb;
+  if constexpr (S < 63) {
+    const bool m = lanes_upto<S>();
+    sa = m ? nva : e[2 * r];
+    sb = m ? nvb : e[2 * r + 1];
+  } else if constexpr (S >= NR) {
+    const bool m = lanes_upto<S - NR>();
+    sa = m ? e[2 * r] : nva;
+    sb = m ? e[2 * r + 1] : nvb;
+  }
+  acc.cur = fmax(acc.cur, fabs(sa - e[2 * r]));
+  acc.cur = fmax(acc.cur, fabs(sb - e[2 * r + 1]));
+  e[2 * r] = sa;
+  e[2 * r + 1] = sb;
+}
+
+// Steps S .. NR + 62; the LDS reads of step S + 1 are issued before the arithmetic of step S.
+// last_step: the step at which the last lane that owns a row finishes (NR + lanes - 2).
+template <int NR, int S, bool TAIL, int NAR>
+__device__ __forceinline__ void sweep_steps(double (&e)[2 * NR], const double (&Areg)[NAR], StepBuf (&pb)[2], Ctx &x,
+                                            Acc &acc, int last_step) {
+  if constexpr (S < NR + 63) {
+    if constexpr (S >= NR && (S - NR) % 4 == 0)
+      if (S > last_step) return; // uniform: only lanes without rows are left
+    if constexpr (S + 1 < NR + 63) load_step<NR, S + 1, TAIL>(pb[(S + 1) & 1], x, Areg);
+    __builtin_amdgcn_sched_barrier(0);
+    step<NR, S, TAIL>(e, pb[S & 1], acc);
+    __builtin_amdgcn_sched_barrier(0);
+    sweep_steps<NR, S + 1, TAIL>(e, Areg, pb, x, acc, last_step);
+  }
+}
+
+// A = ap*Tprev + g for the lane's cells (e = Tprev before the first sweep): the pair of slot j to
+// [2 j] of the lane's A row or to the registers.  aw: class offsets into the (ap, g) table, four
+// cells per word.
+template <int NR, int NAR>
+__device__ __forceinline__ void a_pass(const double (&e)[2 * NR], double (&Areg)[NAR], double *Aw, const char *tapg,
+                                       const unsigned long long *amap) {
+  constexpr int NL = lds_slots(NR), NWD = (2 * NR + 3) / 4;
+  unsigned long long aw[NWD];
+  {
+    const int o = opaque(0);
+#pragma unroll
+    for (int g = 0; g < NWD; ++g) aw[g] = amap[o + g * 64];
+  }
+#pragma unroll
+  for (int j0 = 0; j0 < NR; j0 += 4) {
+    d2 pg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int J = 2 * j0 + k < 2 * NR ? 2 * j0 + k : 2 * NR - 1;
+      const unsigned off = (unsigned)((aw[J >> 2] >> (16 * (J & 3))) & 0xffffull);
+      pg[k] = *(const d2 *)(tapg + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const int j = j0 + k / 2;
+      if (j < NR) {
+        const double av0 = fma(pg[k].x, e[2 * j], pg[k].y), av1 = fma(pg[k + 1].x, e[2 * j + 1], pg[k + 1].y);
+        if (j < NL) *(d2 *)(Aw + 2 * j) = d2{av0, av1};
+        else {
+          Areg[2 * (j - NL)] = av0;
+          Areg[2 * (j - NL) + 1] = av1;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The end of a building's step, register by register: store it, add it to its zone sum (LDS),
+// load the same register of the next building.  zw: zone-sum offsets (in doubles), four registers
+// per word, read kZA words ahead (memory operations return in order: waiting for a young word
+// would drain the queue of row loads in front of it).
+template <int NE, int J>
+__device__ __forceinline__ void hand_over(double (&e)[NE], unsigned long long (&zw)[kZA + 1], const unsigned long long *zmap,
+                                          double *tp, const double *np_, double *zs) {
+  if constexpr (J < NE) {
+    if constexpr (J % 4 == 0 && J / 4 + kZA < (NE + 3) / 4) zw[(J / 4 + kZA) % (kZA + 1)] = zmap[(J / 4 + kZA) * 64];
+    const unsigned idx = (unsigned)((zw[(J / 4) % (kZA + 1)] >> (16 * (J & 3))) & 0xffffull);
+    tp[J * 64] = e[J];
+    __hip_atomic_fetch_add(zs + idx, e[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    e[J] = np_[J * 64];
+    if constexpr ((J & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    hand_over<NE, J + 1>(e, zw, zmap, tp, np_, zs);
+  }
+}
+
+// ---------------------------------------------------------------- tail rows (as in step_roll.hip)
+// Along a row the Gauss-Seidel update is x_c = bL_c * x_{c-1} + q_c: an inclusive scan over the
+// affine maps f_c(x) = bL_c x + q_c in log2(64) DPP steps.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void scan_step(double &a, double &q) {
+  const double one = 1.0;
+  const int alo = __builtin_amdgcn_update_dpp(__double2loint(one), __double2loint(a), CTRL, ROW_MASK, 0xf, false);
+  const int ahi = __builtin_amdgcn_update_dpp(__double2hiint(one), __double2hiint(a), CTRL, ROW_MASK, 0xf, false);
+  const int qlo = __builtin_amdgcn_update_dpp(0, __double2loint(q), CTRL, ROW_MASK, 0xf, false);
+  const int qhi = __builtin_amdgcn_update_dpp(0, __double2hiint(q), CTRL, ROW_MASK, 0xf, false);
+  const double as = __hiloint2double(ahi, alo), qs = __hiloint2double(qhi, qlo);
+  q = fma(a, qs, q);
+  a = a * as;
+}
+__device__ __forceinline__ void affine_scan(double &a, double &q) {
+  scan_step<0x111, 0xf>(a, q);
+  scan_step<0x112, 0xf>(a, q);
+  scan_step<0x114, 0xf>(a, q);
+  scan_step<0x118, 0xf>(a, q);
+  scan_step<0x142, 0xa>(a, q);
+  scan_step<0x143, 0xc>(a, q);
+}
+
+// A lane owns two neighbouring columns of a tail row, in the TOP lanes (where the reversed shift
+// registers deliver the last wavefront row): lane l owns columns 2 (l - L0), 2 (l - L0) + 1, L0 = 64 - NR / 2.
+template <int NR>
+__device__ __forceinline__ int tail_col(int lane, int k) { return 2 * (lane - (64 - NR / 2)) + k; }
+
+// One Gauss-Seidel pass over the tail rows; returns the lane's max |delta|.  tv: the lane's cells;
+// U0 / U1: the row above; the first tail row also goes to LDS (lane 63's lower neighbours during
+// the next sweep).  tset[t]: LDS offsets of the two cells' coefficient sets (low / high half).
+template <int NR>
+__device__ __forceinline__ double tail_pass(int T, bool active, double *tE0c, double U0, double U1,
+                                            double (&tv)[kTailMax][2], const int (&tset)[kTailMax],
+                                            const double (&At)[kTailMax][2]) {
+  static_assert(NR % 2 == 0 && NR <= 128, "two columns per lane");
+  double dmax = 0.0;
+#pragma unroll
+  for (int t = 0; t < kTailMax; ++t) {
+    if (t < T) {
+      const lds_d2 s0 = (lds_d2)(unsigned)(tset[t] & 0xffff), s1 = (lds_d2)((unsigned)tset[t] >> 16);
+      const d2 ud0 = s0[0], lr0 = s0[1], ud1 = s1[0], lr1 = s1[1];
+      const double old0 = tv[t][0], old1 = tv[t][1];
+      const double R1 = wave_shift1<0x130, false>(old0, 0.0); // the next lane's first column (not yet updated)
+      const double D0 = t + 1 < T ? tv[t + 1 < kTailMax ? t + 1 : t][0] : 0.0, D1 = t + 1 < T ? tv[t + 1 < kTailMax ? t + 1 : t][1] : 0.0;
+      const double q0 = fma(ud0.x, U0, fma(lr0.y, old1, fma(ud0.y, D0, At[t][0])));
+      const double q1 = fma(ud1.x, U1, fma(lr1.y, R1, fma(ud1.y, D1, At[t][1])));
+      double a = lr1.x * lr0.x, Q = fma(lr1.x, q0, q1);
+      affine_scan(a, Q);
+      const double xl = wave_shift1<0x138, false>(Q, 0.0);
+      const double x0 = fma(lr0.x, xl, q0);
+      if (active) {
+        dmax = fmax(dmax, fmax(fabs(x0 - old0), fabs(Q - old1)));
+        tv[t][0] = x0;
+        tv[t][1] = Q;
+        if (t == 0) *(d2 *)tE0c = d2{x0, Q};
+      }
+      U0 = x0;
+      U1 = Q;
+    }
+  }
+  return dmax;
+}
+
+extern __shared__ __attribute__((aligned(16))) double lds[];
+
+template <int NR, bool TAIL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_two(Dev a) {
+  const int lane = threadIdx.x & 63;
+  constexpr int kNL = lds_slots(NR), kAS = a_stride(NR), kNAR = 2 * (NR - kNL), NE = 2 * NR;
+  constexpr int kZW = (NE + 3) / 4;
+
+  double *tabc = lds;                        // [kSets][4]: bU bD bL bR per coefficient set
+  double *tapg = lds + 4 * kSets;            // [ts][2]: (ap, g) per class; g of this building
+  double *tE0 = lds + a.r_seam + 2;          // the first tail row by column ([2 guards | NR | 2 guards])
+  double *A = lds + a.r_A;                   // [64][kAS]; after the sweeps: zone sums [Z + 1][ZRS]
+  for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0; // every byte starts finite
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < 4 * kSets; i += 64) tabc[i] = i < 4 * a.ncset ? a.csetab[i] : 0.0;
+  for (int c = lane; c < a.ts; c += 64) tapg[2 * c] = c <= a.ncls ? a.ctab[c * 8 + 4] : 0.0; // row `ncls`: the pad class
+  __builtin_amdgcn_wave_barrier();
+
+  const sb_params &p = a.p;
+  if ((unsigned)(size_t)(__attribute__((address_space(3))) double *)tabc != 0u) __builtin_trap(); // class words hold LDS addresses
+  Ctx x;
+  x.Arow = A + (size_t)lane * kAS;
+  x.seam = tE0 - 63; // lane 63 works on column s - 63 at step s
+  x.cmap = (const char *)a.cmapS;
+  x.voff = 0;
+  const int last_step = NR + a.lw[0] - 2; // a.lw[0]: lanes that own rows
+  // the lane's tail cells (static per floor plan): LDS offsets of their coefficient sets (two
+  // 16-bit halves) and of their (ap, g) entries
+  const bool tactive = TAIL && tail_col<NR>(lane, 0) >= 0;
+  const int tc0 = tactive ? tail_col<NR>(lane, 0) : 0;
+  int tset[kTailMax], tcls[kTailMax];
+#pragma unroll
+  for (int t = 0; t < kTailMax; ++t) {
+    tset[t] = (a.ncset - 1) * 32 * 0x10001; // the pad set (the table's last)
+    tcls[t] = (16 * a.ncls) * 0x10001;
+    if (TAIL && t < a.T && tactive) {
+      tset[t] = ((int)a.tcset[t * NR + tc0] << 2) | ((int)a.tcset[t * NR + tc0 + 1] << 18); // set * 8 -> set * 32
+      tcls[t] = ((int)a.tcls[t * NR + tc0] << 4) | ((int)a.tcls[t * NR + tc0 + 1] << 20);   // class -> class * 16
+    }
+  }
+  const unsigned long long *amap = a.amapS + lane;
+  const unsigned long long *zmap = a.zmapS + lane;
+
+#define SB_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+
+  // The lane's registers of the NEXT building are loaded while this building's are stored; so are
+  // the building's small inputs.
+  double e[NE];
+  double nx_g[kG] = {0.0, 0.0, 0.0, 0.0}, nx_tail[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}, nx_tnow = 0.0, nx_lo = 0.0, nx_hi = 0.0;
+#define SB_LOAD_AUX(bb)                                                                         \
+  do {                                                                                          \
+    nx_tnow = a.bld[(bb)].t_now;                                                                \
+    nx_lo = a.scal[(size_t)(bb) * kNScal + 16];                                                 \
+    nx_hi = a.scal[(size_t)(bb) * kNScal + 17];                                                 \
+    _Pragma("unroll") for (int k = 0; k < kG; ++k)                                              \
+      if (k * 64 < a.ts) nx_g[k] = a.gtabg[(size_t)(bb) * a.ts + ((k * 64 + lane) & (a.ts - 1))]; \
+    const double *tt_ = a.temp + (size_t)(bb) * a.state_doubles + NE * 64;                      \
+    _Pragma("unroll") for (int t = 0; t < kTailMax; ++t)                                        \
+      _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
+        if (TAIL && t < a.T) nx_tail[t][k] = tt_[t * NR + tc0 + k];                             \
+  } while (0)
+  if ((int)blockIdx.x < a.B) {
+    const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles + lane;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) e[j] = tp_[j * 64];
+    SB_LOAD_AUX(blockIdx.x);
+  }
+  int iter = 0;
+  for (int b = blockIdx.x, bn = 0; b < a.B; b = bn, ++iter) {
+    {
+      int nb = 0;
+      if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
+      bn = __builtin_amdgcn_readfirstlane(nb);
+    }
+    SB_STAMP(0);
+    first_words(x, lane);
+    double *Ttail = a.temp + (size_t)b * a.state_doubles + NE * 64; // [T][NR]
+    const double t_now = nx_tnow;
+    // exterior-space cells outside the trim box all become t_now in the first sweep
+    // (simulator.py:256-258); their largest |delta| follows from their extreme values
+    const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0;
+#pragma unroll
+    for (int k = 0; k < kG; ++k)
+      if (k * 64 + lane < a.ts) tapg[2 * (k * 64 + lane) + 1] = nx_g[k];
+    double tv[kTailMax][2];
+#pragma unroll
+    for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) tv[t][k] = nx_tail[t][k];
+    if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(1);
+    double At[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // A of the lane's tail cells
+#pragma unroll
+    for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (TAIL && t < a.T && tactive) {
+          const d2 pg = *(const d2 *)((const char *)tapg + ((tcls[t] >> (16 * k)) & 0xffff));
+          At[t][k] = fma(pg.x, tv[t][k], pg.y);
+        }
+    double Areg[kNAR];
+    a_pass<NR>(e, Areg, A + (size_t)lane * kAS, (const char *)tapg, amap);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(2);
+
+    int n_sweeps = 0, converged = 0;
+    {
+      StepBuf pb[2];
+      Acc acc;
+      acc.sre = acc.sro = 0.0;
+#pragma nounroll
+      for (;;) { // simulator.py:348-368
+        __builtin_amdgcn_sched_barrier(0);
+#define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && n_sweeps == 1 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+        SB_STAMP2(10);
+        acc.cur = 0.0;
+        load_step<NR, 0, TAIL>(pb[0], x, Areg);
+        sweep_steps<NR, 0, TAIL>(e, Areg, pb, x, acc, last_step);
+        __builtin_amdgcn_sched_barrier(0);
+        first_words(x, lane); // the next sweep's first class words
+        SB_STAMP2(11);
+        double dm = acc.cur;
+        if constexpr (TAIL) {
+          // the last row's last column enters its shift register; then both are reversed: lane l
+          // holds columns 2 (l - L0), 2 (l - L0) + 1, the tail scan's layout
+          constexpr int last = (NR + 62) % NR;
+          const double ul = wave_shift1<0x13c, false>(e[2 * last + 1], 0.0);
+          double &sr = (NR - 1) % 2 == 0 ? acc.sre : acc.sro;
+          sr = wave_shift1<0x138, true>(sr, ul);
+          const int rev = (63 - lane) * 4;
+          const double U0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(rev, __double2hiint(acc.sre)),
+                                             __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sre)));
+          const double U1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(rev, __double2hiint(acc.sro)),
+                                             __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sro)));
+          SB_STAMP2(12);
+          dm = fmax(dm, tail_pass<NR>(a.T, tactive, tE0 + tc0, U0, U1, tv, tset, At));
+        }
+        SB_STAMP2(13);
+        double md = wave_max(dm);
+        if (n_sweeps == 0) md = fmax(md, ring_d);
+        SB_STAMP2(14);
+        ++n_sweeps;
+        converged = md <= p.conv_threshold;
+        if (converged || n_sweeps >= p.iter_limit) break;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(3);
+
+    // grid back to HBM.  Zone sums (A is dead now): every lane adds its cells into its own column
+    // of zs[zone]; row Z collects every cell outside a zone, so that the sum of all rows is the grid sum.
+    double *zs = A;
+    const int ZRS = a.ZRS;
+    {
+      unsigned long long zw[kZA + 1];
+      const unsigned long long *zm = zmap + opaque(0);
+#pragma unroll
+      for (int g = 0; g < kZA; ++g) zw[g] = zm[g * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      double *tp = a.temp + (size_t)b * a.state_doubles;
+      for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + lane] = 0.0;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < kTailMax; ++t) // the tail rows hold no zone cells (sb_create checks): all into row Z
+        if (TAIL && t < a.T && tactive) {
+          *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
+          zs[(size_t)a.Z * ZRS + lane] += tv[t][0] + tv[t][1]; // the lane's own column of the scratch
+        }
+      const double *np_ = a.temp + (size_t)(bn < a.B ? bn : b) * a.state_doubles;
+      hand_over<NE, 0>(e, zw, zm, tp + lane, np_ + lane, zs);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(4);
+    if (bn < a.B) SB_LOAD_AUX(bn);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_wave_barrier();
+
+    { // hand the zone sums, the grid sum and the sweep count to k_post
+      // 16 zones x 4 column groups per pass: lane (zone = lane & 15, group = lane >> 4) adds every
+      // fourth column of its zone, two xor-shuffles combine the groups
+      double gacc = 0.0;
+      for (int zb = 0; zb <= a.Z; zb += 16) {
+        const int zz = zb + (lane & 15), g = lane >> 4;
+        const double *zr = zs + (size_t)(zz <= a.Z ? zz : a.Z) * ZRS + g;
+        double part[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) part[k] = zr[4 * k]; // sixteen independent reads, then one wait
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += part[k];
+        if (zz > a.Z) v = 0.0;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16 && zz < a.Z) a.zsum[(size_t)b * a.Z + zz] = v;
+        if (lane < 16 && zz <= a.Z) gacc += v;
+      }
+      const double gsum = wave_sum(gacc);
+      if (lane == 0) {
+        a.gsum[b] = gsum + (double)a.n_ring * t_now;
+        a.nsw[b] = n_sweeps | (converged << 16);
+      }
+      SB_STAMP(5);
+      if (a.dbg && blockIdx.x == 0 && iter == 3 && lane == 0) a.dbg[9] = n_sweeps;
+    }
+    __builtin_amdgcn_wave_barrier(); // the zone sums are read: A may be written again
+  }
+#undef SB_STAMP
+#undef SB_STAMP2
+#undef SB_LOAD_AUX
+}
+
+template <int NR, bool TAIL>
+int launch(const Dev &d, hipStream_t stream, bool prepare) {
+  if (prepare)
+    return (int)hipFuncSetAttribute((const void *)k_sweep_two<NR, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    d.lds_reg_bytes);
+  hipLaunchKernelGGL((k_sweep_two<NR, TAIL>), dim3(d.sweep_wgs), dim3(64), (size_t)d.lds_reg_bytes, stream, d);
+  return (int)hipGetLastError();
+}
+
+int dispatch(const Dev &d, hipStream_t stream, bool prepare) {
+  const bool tail = d.T > 0;
+  if (d.NR == 76) return tail ? launch<76, true>(d, stream, prepare) : launch<76, false>(d, stream, prepare);
+  if (d.NR == 80) return tail ? launch<80, true>(d, stream, prepare) : launch<80, false>(d, stream, prepare);
+  return (int)hipErrorInvalidValue;
+}
+
+} // namespace
+
+bool sweep_two_supported(int NR) { return NR == 76 || NR == 80; }
+int sweep_two_lds_slots(int NR) { return lds_slots(NR); }
+int sweep_two_a_stride(int NR) { return a_stride(NR); }
+int sweep_two_seam_doubles(int NR) { return tail_row(NR); }
+int sweep_two_set_table() { return kSets; }
+int prepare_sweep_two(const Dev &d) { return dispatch(d, nullptr, true); }
+int launch_sweep_two(const Dev &d, hipStream_t stream) { return dispatch(d, stream, false); }
+
+} // namespace sb

@@ -556,6 +556,10 @@ def _oracle_twin(plan, cfg, init_flat):
     ((2, 3), (30, 30), "rows", 1),     # 65x96 -> registers, 1 wave + ONE tail row
     ((4, 5), (10, 8), "rows", 1),      # 47x48, 20 zones -> registers, zone reduce in two 16-zone passes
     ((4, 2), (30, 17), "columns", 0),  # the same family on the LDS-grid kernel, lanes = columns
+    ((8, 5), (12, 14), "auto", 1),     # "SB2-synth" 107x78 inside the ring -> registers, two rows per lane (54 lanes, the last with one row), 80 slots
+    ((14, 9), (8, 7), "auto", 1),      # "SB1-synth" 129x75, 137 cell classes -> two rows per lane + ONE tail row, 76 slots
+    ((5, 3), (24, 24), "rows", 1),     # 128x78: two rows per lane, all 64 lanes, no tail row
+    ((4, 4), (15, 17), "rows", 1),     # 67x75: two rows per lane, 34 lanes (the sweep ends early)
 ])
 def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, monkeypatch):
   """BASELINE.json configs[2] semantics: other floor-plan classes (different H x W and zone
