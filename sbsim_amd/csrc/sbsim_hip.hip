@@ -242,7 +242,9 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
     for (int wd = 0; wd < NW; ++wd) { // two steps per word: (upper, lower) set offsets
       unsigned long long word = 0;
       for (int k = 0; k < 4; ++k) {
-        const int st = 2 * wd + k / 2, col = st - lane;
+        const int st = 2 * wd + k / 2;
+        int col = st - lane;
+        if (col >= NR) col -= NR; // rolling periods: the lane is in its next sweep
         word |= (unsigned long long)(set_of[row_class(k & 1, col)] * 32) << (16 * k);
       }
       r.cmapS[(size_t)wd * 64 + lane] = word;

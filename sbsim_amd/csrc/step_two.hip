@@ -15,9 +15,19 @@
 // [lane][slot][2 rows]: one ds_read_b128 per step; coefficient sets as in step_roll.hip (two
 // ds_read_b128 per cell, addressed by 16-bit LDS offsets that arrive in class words from L2).
 //
-// Sweeps are NOT overlapped here: the copies that undo a started sweep (step_roll.hip) would need
-// another 252 registers.  A sweep costs NR + lanes - 1 steps; the ramp steps select by lane mask.
-// Two buildings fit in a CU's LDS, so two of the four SIMDs run (the LDS-grid kernel: one).
+// Sweeps are overlapped in BLOCKS (step_roll.hip overlaps all of them, undoing the started sweep from
+// copies -- another 252 registers here).  A block of m sweeps is a ramp-up (63 steps, lanes > s
+// masked), m - 1 rolling periods of NR steps (lanes <= s - NR already in the next sweep) and a final
+// period whose lanes <= s - NR are masked: it stops after exactly m sweeps, and costs 63 + m NR
+// steps instead of m (NR + 63).  Whether sweep k was the last one (simulator.py:360) is known only
+// after its period, so m comes from a prediction (the decay of max|delta| over the last two
+// sweeps, rounded towards fewer sweeps): the grid is stored before a block, and a block that finds
+// max|delta| <= threshold before its last sweep is run again from the stored grid with m = that
+// sweep -- the iterates and the sweep count are always those of the plain schedule; the prediction
+// only decides the speed.  max|delta| of the two sweeps in flight is separated by its sign as in
+// step_roll.hip.  Two buildings fit in a CU's LDS, so two of the four SIMDs run (LDS-grid kernel: one).
+#include <type_traits>
+
 #include "sb_device.h"
 
 namespace sb {
@@ -72,17 +82,101 @@ struct StepBuf {         // LDS values of one step
 };
 
 struct Acc {
-  double cur;      // max |delta| of the sweep
+  double cur;      // max |delta| of the sweep the lanes are finishing
+  double neg;      // -(max |delta|) of the sweep the lanes have started (rolling periods)
+  int sg;          // 0x80000000 in the lanes that have started the next sweep
   double sre, sro; // the last wavefront row's new values on their way to the tail scan (even / odd columns)
 };
 
 struct Ctx {
-  const double *Arow; // the lane's row of A: the cell pair of slot j at [2 j]
-  const double *seam; // first tail row by step: the value under lane 63 at step s is seam[s]
+  unsigned arow;      // LDS byte address of the lane's row of A: the cell pair of slot j at [2 j]
+  unsigned seam;      // LDS byte address of the first tail row by step: the value under lane 63 at step s is [s]
   const char *cmap;   // class words (uniform)
   unsigned voff;      // byte offset of the lane's last-read class word: 8 * lane + 512 * word
   unsigned long long w[kWA + 1];
 };
+
+// The lane's 2 NR grid registers: register J = 2 * slot + (row & 1).  The first 2 * kNV live in
+// VGPRs, the rest in AGPRs -- by hand: left to the register allocator, every register of the unrolled
+// sweep goes through an AGPR (and some through scratch).  VALU instructions cannot read AGPRs, so a
+// step reads the slot it needs next (v_accvgpr_read) and writes its results back once.
+template <int NR>
+struct Grid {
+#ifndef SB_TWO_NV
+#define SB_TWO_NV 24
+#endif
+  static constexpr int kNV = SB_TWO_NV; // slots homed in VGPRs
+  static constexpr int NE = 2 * NR, NVE = 2 * kNV;
+  double v[NVE];
+  int a[2 * (NE - NVE)];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < 2 * (NE - NVE); ++k) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(a[k]));
+#pragma unroll
+    for (int k = 0; k < NVE; ++k) v[k] = 0.0;
+  }
+  template <int J>
+  __device__ __forceinline__ double get() const {
+    static_assert(J >= 0 && J < NE, "grid register");
+    if constexpr (J < NVE) return v[J];
+    else {
+      int lo, hi;
+      asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(a[2 * (J - NVE)]));
+      asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(a[2 * (J - NVE) + 1]));
+      return __hiloint2double(hi, lo);
+    }
+  }
+  // Register J <- *(base + off) (bytes) without waiting for it: the AGPR homes are loaded directly
+  // (two global_load_dword the compiler does not track), so settle() must come before any get().
+  template <int J>
+  __device__ __forceinline__ void load_async(const double *base, unsigned off) {
+    off += (unsigned)J * 512u;
+    if constexpr (J < NVE) v[J] = *(const double *)((const char *)base + off);
+    else {
+      asm volatile("global_load_dword %0, %2, %3" : "=a"(a[2 * (J - NVE)]) : "0"(a[2 * (J - NVE)]), "v"(off), "s"(base) : "memory");
+      asm volatile("global_load_dword %0, %2, %3 offset:4"
+                   : "=a"(a[2 * (J - NVE) + 1])
+                   : "0"(a[2 * (J - NVE) + 1]), "v"(off), "s"(base)
+                   : "memory");
+    }
+  }
+  // uniform base + 32-bit byte offset (the lane's, made opaque by the caller inside its loop: the
+  // 2 NR addresses are not loop invariants the compiler could hoist -- and spill)
+  template <int J>
+  __device__ __forceinline__ void store(double *base, unsigned off) const {
+    *(double *)((char *)base + (off + (unsigned)J * 512u)) = get<J>();
+  }
+  __device__ __forceinline__ void settle() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 2 * (NE - NVE); ++k) asm volatile("" : "+a"(a[k])); // later reads depend on the wait
+  }
+  template <int J>
+  __device__ __forceinline__ void set(double x) {
+    static_assert(J >= 0 && J < NE, "grid register");
+    if constexpr (J < NVE) v[J] = x;
+    else {
+      // the old value as a tied input: every version of a register keeps the same AGPR (left free,
+      // the allocator fragments the 200+ long-lived values over the loop and spills them)
+      asm("v_accvgpr_write_b32 %0, %2" : "=a"(a[2 * (J - NVE)]) : "0"(a[2 * (J - NVE)]), "v"(__double2loint(x)));
+      asm("v_accvgpr_write_b32 %0, %2" : "=a"(a[2 * (J - NVE) + 1]) : "0"(a[2 * (J - NVE) + 1]), "v"(__double2hiint(x)));
+    }
+  }
+};
+
+// The three slots a step touches, in VGPRs: the previous slot's new values and the current slot's
+// old values (the next slot's are read by the step itself).
+struct Win {
+  double pa, pb, ca, cb;
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 // Class words: per step two 16-bit fields -- the LDS byte offsets (set * 32) of the coefficient
 // sets of the lane's upper and lower cell -- two steps per 64-bit word, read from global memory
@@ -101,6 +195,16 @@ __device__ __forceinline__ void first_words(Ctx &x, int lane) { // words 0 .. kW
   }
 }
 
+// A rolling period starts at step 63 = the odd half of word 31; load_step<64> continues with word 36.
+__device__ __forceinline__ void period_words(Ctx &x, int lane) {
+  x.voff = (unsigned)opaque(lane * 8 + 31 * 512);
+#pragma unroll
+  for (int k = 0; k <= kWA; ++k) {
+    x.w[(31 + k) % (kWA + 1)] = class_word(x);
+    if (k < kWA) x.voff += 512u;
+  }
+}
+
 template <int NR, int S, bool TAIL, int NAR>
 __device__ __forceinline__ void load_step(StepBuf &p, Ctx &x, const double (&Areg)[NAR]) {
   if constexpr (S % 2 == 0 && S / 2 + kWA < words_per_sweep<NR>()) {
@@ -116,121 +220,156 @@ __device__ __forceinline__ void load_step(StepBuf &p, Ctx &x, const double (&Are
   p.udb = sb[0];
   p.lrb = sb[1];
   constexpr int r = S % NR, NL = lds_slots(NR);
-  if constexpr (r < NL) p.A = *(const d2 *)(x.Arow + 2 * r);
+  if constexpr (r < NL) p.A = *(lds_d2)(x.arow + 16u * r);
   else p.A = d2{Areg[2 * (r - NL)], Areg[2 * (r - NL) + 1]};
-  if constexpr (TAIL && S >= 63) p.sm = x.seam[S];
+  if constexpr (TAIL && S >= 63) p.sm = *(const double __attribute__((address_space(3))) *)(x.seam + 8u * S);
   else p.sm = 0.0;
 }
 
-// One Gauss-Seidel update of every lane's two current cells at step S of a sweep:
-//   S < 63             ramp-up: lanes > S have not started
-//   63 <= S < NR       all 64 lanes
-//   NR <= S < NR + 63  ramp-down: lanes <= S - NR have finished
+// One Gauss-Seidel update of every lane's two current cells at step S:
+//   S < 63             ramp-up of a block's first sweep: lanes > S have not started
+//   63 <= S < NR       all 64 lanes are in the same sweep
+//   NR <= S < NR + 63  ROLL: lanes <= S - NR are in the next sweep; else they have finished (masked)
 // Association order of the four products as in step_lds.hip / step_reg.hip / step_roll.hip.
-template <int NR, int S, bool TAIL>
-__device__ __forceinline__ void step(double (&e)[2 * NR], const StepBuf &p, Acc &acc) {
-  constexpr int r = S % NR, rm = (S + NR - 1) % NR, rp = (S + 1) % NR;
-  const double U = wave_shift1<0x13c, false>(e[2 * rm + 1], 0.0); // lane 0 sees the last row's latest value (times bU = 0)
-  const double Dn = wave_shift1<0x130, true>(e[2 * rp], p.sm);
+template <int NR, int S, bool TAIL, bool ROLL>
+__device__ __forceinline__ void step(Grid<NR> &g, Win &w, const StepBuf &p, Acc &acc) {
+  constexpr int r = S % NR, rp = (S + 1) % NR;
+  const double na = g.template get<2 * rp>(), nb = g.template get<2 * rp + 1>(); // old values one column ahead
+  const double U = wave_shift1<0x13c, false>(w.pb, 0.0); // lane 0 sees the last row's latest value (times bU = 0)
+  const double Dn = wave_shift1<0x130, true>(na, p.sm);
   double t, t2;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t) : "v"(p.uda.y), "v"(e[2 * r + 1]), "v"(p.A.x));
-  t = fma(p.lra.y, e[2 * rp], t);
-  t = fma(p.lra.x, e[2 * rm], t);
+  asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t) : "v"(p.uda.y), "v"(w.cb), "v"(p.A.x));
+  t = fma(p.lra.y, na, t);
+  t = fma(p.lra.x, w.pa, t);
   const double nva = fma(p.uda.x, U, t);
   asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t2) : "v"(p.udb.y), "v"(Dn), "v"(p.A.y));
-  t2 = fma(p.lrb.y, e[2 * rp + 1], t2);
-  t2 = fma(p.lrb.x, e[2 * rm + 1], t2);
+  t2 = fma(p.lrb.y, nb, t2);
+  t2 = fma(p.lrb.x, w.pb, t2);
   const double nvb = fma(p.udb.x, nva, t2);
   if constexpr (TAIL && S > 63) { // lane 0's U is column S - 64 of the last row: into the shift register of its parity
     double &sr = (S - 64) % 2 == 0 ? acc.sre : acc.sro;
     sr = wave_shift1<0x138, true>(sr, U);
   }
   double sa = nva, sb = nvb;
-  if constexpr (S < 63) {
-    const bool m = lanes_upto<S>();
-    sa = m ? nva : e[2 * r];
-    sb = m ? nvb : e[2 * r + 1];
-  } else if constexpr (S >= NR) {
-    const bool m = lanes_upto<S - NR>();
-    sa = m ? e[2 * r] : nva;
-    sb = m ? e[2 * r + 1] : nvb;
+  if constexpr (ROLL && S >= NR) {
+    constexpr int J = S - NR;
+    const double da = nva - w.ca, db = nvb - w.cb;
+    // +|d| in the lanes still in sweep k, -|d| in the lanes already in sweep k+1
+    const double sda = __hiloint2double((__double2hiint(da) & 0x7fffffff) | acc.sg, __double2loint(da));
+    const double sdb = __hiloint2double((__double2hiint(db) & 0x7fffffff) | acc.sg, __double2loint(db));
+    acc.cur = fmax(acc.cur, sda);
+    acc.neg = fmin(acc.neg, sda);
+    acc.cur = fmax(acc.cur, sdb);
+    acc.neg = fmin(acc.neg, sdb);
+    asm volatile("" : "+v"(acc.neg)); // here: sunk below the period's exit, the minima keep every sd of the period alive
+    if constexpr (J + 1 < 63) // lane J + 1 starts its next sweep at the next step (lane 0 keeps its bit)
+      acc.sg = __builtin_amdgcn_update_dpp(acc.sg, acc.sg, 0x138, 0xf, 0xf, false);
+  } else {
+    if constexpr (S < 63) {
+      const bool m = lanes_upto<S>();
+      sa = m ? nva : w.ca;
+      sb = m ? nvb : w.cb;
+    } else if constexpr (S >= NR) {
+      const bool m = lanes_upto<S - NR>();
+      sa = m ? w.ca : nva;
+      sb = m ? w.cb : nvb;
+    }
+    acc.cur = fmax(acc.cur, fabs(sa - w.ca));
+    acc.cur = fmax(acc.cur, fabs(sb - w.cb));
   }
-  acc.cur = fmax(acc.cur, fabs(sa - e[2 * r]));
-  acc.cur = fmax(acc.cur, fabs(sb - e[2 * r + 1]));
-  e[2 * r] = sa;
-  e[2 * r + 1] = sb;
+  asm volatile("" : "+v"(acc.cur)); // here, not after the sweep (the maxima would keep every delta of the sweep alive)
+  g.template set<2 * r>(sa);
+  g.template set<2 * r + 1>(sb);
+  w.pa = sa;
+  w.pb = sb;
+  w.ca = na;
+  w.cb = nb;
 }
 
-// Steps S .. NR + 62; the LDS reads of step S + 1 are issued before the arithmetic of step S.
+// Steps S .. S1 - 1; the LDS reads of step S + 1 are issued before the arithmetic of step S (the
+// caller issues those of the first step; a period's last step reads nothing ahead).
 // last_step: the step at which the last lane that owns a row finishes (NR + lanes - 2).
-template <int NR, int S, bool TAIL, int NAR>
-__device__ __forceinline__ void sweep_steps(double (&e)[2 * NR], const double (&Areg)[NAR], StepBuf (&pb)[2], Ctx &x,
-                                            Acc &acc, int last_step) {
-  if constexpr (S < NR + 63) {
-    if constexpr (S >= NR && (S - NR) % 4 == 0)
+template <int NR, int S, int S1, bool TAIL, bool ROLL, int NAR>
+__device__ __forceinline__ void run_steps(Grid<NR> &g, Win &w, const double (&Areg)[NAR], StepBuf (&pb)[2], Ctx &x,
+                                          Acc &acc, int last_step) {
+  if constexpr (S < S1) {
+    if constexpr (!ROLL && S >= NR && (S - NR) % 4 == 0)
       if (S > last_step) return; // uniform: only lanes without rows are left
     if constexpr (S + 1 < NR + 63) load_step<NR, S + 1, TAIL>(pb[(S + 1) & 1], x, Areg);
     __builtin_amdgcn_sched_barrier(0);
-    step<NR, S, TAIL>(e, pb[S & 1], acc);
+    step<NR, S, TAIL, ROLL>(g, w, pb[S & 1], acc);
     __builtin_amdgcn_sched_barrier(0);
-    sweep_steps<NR, S + 1, TAIL>(e, Areg, pb, x, acc, last_step);
+    run_steps<NR, S + 1, S1, TAIL, ROLL>(g, w, Areg, pb, x, acc, last_step);
   }
+}
+
+// Sweeps to run overlapped before the next look at max|delta|: d1 -> d0 over the last sweep, the
+// threshold `thr`, `room` sweeps to the iteration limit.  Assumes a decay 1.25 x as fast (in the
+// exponent) as the last one and stops one sweep short of where that would converge.
+__device__ __forceinline__ int predict_block(float d1, float d0, float thr, int room) {
+  int m = 1;
+  if (d0 < d1 && d0 > thr && thr > 0.0f) {
+    const float r = __log2f(thr / d0) / (1.25f * __log2f(d0 / d1));
+    m = r < 40.0f ? (int)r - 1 : 32;
+  }
+  m = min(min(m, 32), room);
+  return m < 2 ? 1 : m;
 }
 
 // A = ap*Tprev + g for the lane's cells (e = Tprev before the first sweep): the pair of slot j to
 // [2 j] of the lane's A row or to the registers.  aw: class offsets into the (ap, g) table, four
 // cells per word.
 template <int NR, int NAR>
-__device__ __forceinline__ void a_pass(const double (&e)[2 * NR], double (&Areg)[NAR], double *Aw, const char *tapg,
+__device__ __forceinline__ void a_pass(const Grid<NR> &g, double (&Areg)[NAR], double *Aw, const char *tapg,
                                        const unsigned long long *amap) {
   constexpr int NL = lds_slots(NR), NWD = (2 * NR + 3) / 4;
-  unsigned long long aw[NWD];
-  {
-    const int o = opaque(0);
+  static_assert(NR % 4 == 0, "a_pass: four slots per group");
+  amap += opaque(0);
+  constexpr int kAA = 8; // words (four registers each) read ahead
+  unsigned long long aw[kAA + 2];
 #pragma unroll
-    for (int g = 0; g < NWD; ++g) aw[g] = amap[o + g * 64];
-  }
+  for (int k = 0; k < kAA; ++k) aw[k] = amap[k * 64];
+  static_for<0, NR / 4>([&](auto gc) {
+    constexpr int j0 = 4 * decltype(gc)::value, W0 = j0 / 2;
 #pragma unroll
-  for (int j0 = 0; j0 < NR; j0 += 4) {
+    for (int k = 0; k < 2; ++k)
+      if (W0 + kAA + k < NWD) aw[(W0 + kAA + k) % (kAA + 2)] = amap[(W0 + kAA + k) * 64];
+    const unsigned long long w0 = aw[W0 % (kAA + 2)], w1 = aw[(W0 + 1) % (kAA + 2)]; // eight registers' class offsets
     d2 pg[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int J = 2 * j0 + k < 2 * NR ? 2 * j0 + k : 2 * NR - 1;
-      const unsigned off = (unsigned)((aw[J >> 2] >> (16 * (J & 3))) & 0xffffull);
-      pg[k] = *(const d2 *)(tapg + off);
-    }
+    for (int k = 0; k < 8; ++k) pg[k] = *(const d2 *)(tapg + (unsigned)(((k < 4 ? w0 : w1) >> (16 * (k & 3))) & 0xffffull));
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-      const int j = j0 + k / 2;
-      if (j < NR) {
-        const double av0 = fma(pg[k].x, e[2 * j], pg[k].y), av1 = fma(pg[k + 1].x, e[2 * j + 1], pg[k + 1].y);
-        if (j < NL) *(d2 *)(Aw + 2 * j) = d2{av0, av1};
-        else {
-          Areg[2 * (j - NL)] = av0;
-          Areg[2 * (j - NL) + 1] = av1;
-        }
+    static_for<0, 4>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, j = j0 + k;
+      const double av0 = fma(pg[2 * k].x, g.template get<2 * j>(), pg[2 * k].y);
+      const double av1 = fma(pg[2 * k + 1].x, g.template get<2 * j + 1>(), pg[2 * k + 1].y);
+      if constexpr (j < NL) *(d2 *)(Aw + 2 * j) = d2{av0, av1};
+      else {
+        Areg[2 * (j - NL)] = av0;
+        Areg[2 * (j - NL) + 1] = av1;
       }
-    }
+    });
     __builtin_amdgcn_sched_barrier(0);
-  }
+  });
 }
 
 // The end of a building's step, register by register: store it, add it to its zone sum (LDS),
 // load the same register of the next building.  zw: zone-sum offsets (in doubles), four registers
 // per word, read kZA words ahead (memory operations return in order: waiting for a young word
 // would drain the queue of row loads in front of it).
-template <int NE, int J>
-__device__ __forceinline__ void hand_over(double (&e)[NE], unsigned long long (&zw)[kZA + 1], const unsigned long long *zmap,
-                                          double *tp, const double *np_, double *zs) {
+template <int NR, int J>
+__device__ __forceinline__ void hand_over(Grid<NR> &g, unsigned long long (&zw)[kZA + 1], const unsigned long long *zmap,
+                                          double *tp, const double *np_, int lane_off, double *zs) {
+  constexpr int NE = 2 * NR;
   if constexpr (J < NE) {
     if constexpr (J % 4 == 0 && J / 4 + kZA < (NE + 3) / 4) zw[(J / 4 + kZA) % (kZA + 1)] = zmap[(J / 4 + kZA) * 64];
     const unsigned idx = (unsigned)((zw[(J / 4) % (kZA + 1)] >> (16 * (J & 3))) & 0xffffull);
-    tp[J * 64] = e[J];
-    __hip_atomic_fetch_add(zs + idx, e[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    e[J] = np_[J * 64];
+    const double v = g.template get<J>();
+    *(double *)((char *)tp + ((unsigned)lane_off + (unsigned)J * 512u)) = v;
+    __hip_atomic_fetch_add(zs + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    g.template load_async<J>(np_, (unsigned)lane_off);
     if constexpr ((J & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-    hand_over<NE, J + 1>(e, zw, zmap, tp, np_, zs);
+    hand_over<NR, J + 1>(g, zw, zmap, tp, np_, lane_off, zs);
   }
 }
 
@@ -319,8 +458,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const sb_params &p = a.p;
   if ((unsigned)(size_t)(__attribute__((address_space(3))) double *)tabc != 0u) __builtin_trap(); // class words hold LDS addresses
   Ctx x;
-  x.Arow = A + (size_t)lane * kAS;
-  x.seam = tE0 - 63; // lane 63 works on column s - 63 at step s
+  x.arow = (unsigned)((a.r_A + lane * kAS) * 8);
+  x.seam = (unsigned)((a.r_seam + 2 - 63) * 8); // lane 63 works on column s - 63 at step s
   x.cmap = (const char *)a.cmapS;
   x.voff = 0;
   const int last_step = NR + a.lw[0] - 2; // a.lw[0]: lanes that own rows
@@ -345,7 +484,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
   // The lane's registers of the NEXT building are loaded while this building's are stored; so are
   // the building's small inputs.
-  double e[NE];
+  Grid<NR> g;
+  g.init();
+  Win w;
   double nx_g[kG] = {0.0, 0.0, 0.0, 0.0}, nx_tail[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}, nx_tnow = 0.0, nx_lo = 0.0, nx_hi = 0.0;
 #define SB_LOAD_AUX(bb)                                                                         \
   do {                                                                                          \
@@ -360,9 +501,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         if (TAIL && t < a.T) nx_tail[t][k] = tt_[t * NR + tc0 + k];                             \
   } while (0)
   if ((int)blockIdx.x < a.B) {
-    const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles + lane;
-#pragma unroll
-    for (int j = 0; j < NE; ++j) e[j] = tp_[j * 64];
+    const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles;
+    const unsigned lo8 = (unsigned)opaque(lane * 8);
+    static_for<0, NE>([&](auto Jc) { g.template load_async<decltype(Jc)::value>(tp_, lo8); });
+    g.settle();
     SB_LOAD_AUX(blockIdx.x);
   }
   int iter = 0;
@@ -401,7 +543,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           At[t][k] = fma(pg.x, tv[t][k], pg.y);
         }
     double Areg[kNAR];
-    a_pass<NR>(e, Areg, A + (size_t)lane * kAS, (const char *)tapg, amap);
+    a_pass<NR>(g, Areg, A + (size_t)lane * kAS, (const char *)tapg, amap);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(2);
@@ -411,23 +553,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       StepBuf pb[2];
       Acc acc;
       acc.sre = acc.sro = 0.0;
-#pragma nounroll
-      for (;;) { // simulator.py:348-368
-        __builtin_amdgcn_sched_barrier(0);
-#define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && n_sweeps == 1 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
-        SB_STAMP2(10);
-        acc.cur = 0.0;
-        load_step<NR, 0, TAIL>(pb[0], x, Areg);
-        sweep_steps<NR, 0, TAIL>(e, Areg, pb, x, acc, last_step);
-        __builtin_amdgcn_sched_barrier(0);
-        first_words(x, lane); // the next sweep's first class words
-        SB_STAMP2(11);
+      double *tp = a.temp + (size_t)b * a.state_doubles;
+      // the end of a sweep: the tail rows, then max |delta| over the wavefront (uniform)
+      auto sweep_end = [&]() -> double {
         double dm = acc.cur;
         if constexpr (TAIL) {
           // the last row's last column enters its shift register; then both are reversed: lane l
           // holds columns 2 (l - L0), 2 (l - L0) + 1, the tail scan's layout
           constexpr int last = (NR + 62) % NR;
-          const double ul = wave_shift1<0x13c, false>(e[2 * last + 1], 0.0);
+          const double ul = wave_shift1<0x13c, false>(w.pb, 0.0); // slot `last`'s new value: the window's previous slot
+          (void)last;
           double &sr = (NR - 1) % 2 == 0 ? acc.sre : acc.sro;
           sr = wave_shift1<0x138, true>(sr, ul);
           const int rev = (63 - lane) * 4;
@@ -435,14 +570,93 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                                              __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sre)));
           const double U1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(rev, __double2hiint(acc.sro)),
                                              __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sro)));
-          SB_STAMP2(12);
           dm = fmax(dm, tail_pass<NR>(a.T, tactive, tE0 + tc0, U0, U1, tv, tset, At));
         }
-        SB_STAMP2(13);
         double md = wave_max(dm);
         if (n_sweeps == 0) md = fmax(md, ring_d);
-        SB_STAMP2(14);
         ++n_sweeps;
+        return md;
+      };
+      const float thr = (float)p.conv_threshold;
+      float d1 = 0.0f, d0 = 0.0f; // max |delta| of the last two sweeps
+#pragma nounroll
+      for (;;) { // simulator.py:348-368
+        // a block of m sweeps: overlapped, stopping after exactly m
+        int m = n_sweeps >= 2 ? predict_block(d1, d0, thr, p.iter_limit - n_sweeps) : 1;
+        m = __builtin_amdgcn_readfirstlane(m);
+        const int n0 = n_sweeps;
+        if (m > 1 && n0 > 0) { // the grid as of n0 sweeps, should the block overrun (before any sweep: Tprev is still there)
+          const unsigned lo8 = (unsigned)opaque(lane * 8);
+          static_for<0, NE>([&](auto Jc) { g.template store<decltype(Jc)::value>(tp, lo8); });
+#pragma unroll
+          for (int t = 0; t < kTailMax; ++t)
+            if (TAIL && t < a.T && tactive) *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
+        }
+        double md = 0.0;
+#pragma nounroll
+        for (;;) { // at most twice: the second time with m = the sweep that converged
+          __builtin_amdgcn_sched_barrier(0);
+#define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && n_sweeps == 4 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+          SB_STAMP2(10);
+          acc.cur = 0.0;
+          acc.neg = 0.0;
+          acc.sg = lane == 0 ? (int)0x80000000 : 0;
+          load_step<NR, 0, TAIL>(pb[0], x, Areg);
+          w.pa = g.template get<NE - 2>();
+          w.pb = g.template get<NE - 1>();
+          w.ca = g.template get<0>();
+          w.cb = g.template get<1>();
+          run_steps<NR, 0, 63, TAIL, false>(g, w, Areg, pb, x, acc, last_step); // ramp-up; reads ahead for step 63
+          bool overrun = false;
+#pragma nounroll
+          for (int q = 1; q < m; ++q) {
+            // A does not change during the sweeps: unless its address does (as far as the compiler can
+            // tell), every ds_read of the period is hoisted out of this loop -- into scratch
+            asm volatile("" : "+v"(x.arow), "+v"(x.seam));
+            __builtin_amdgcn_sched_barrier(0);
+            run_steps<NR, 63, NR + 63, TAIL, true>(g, w, Areg, pb, x, acc, last_step);
+            __builtin_amdgcn_sched_barrier(0);
+            period_words(x, lane);
+            md = sweep_end();
+            d1 = d0;
+            d0 = (float)md;
+            if (md <= p.conv_threshold) { // sweep n0 + q was the last one, and the next has been started
+              overrun = true;
+              m = q;
+              break;
+            }
+            acc.cur = -acc.neg;
+            acc.neg = 0.0;
+            acc.sg = lane == 0 ? (int)0x80000000 : 0;
+            load_step<NR, 63, TAIL>(pb[1], x, Areg); // after the tail scan: lane 63's lower neighbour is new
+          }
+          if (!overrun) break;
+          // back to the stored grid; this time the block ends with sweep n0 + m
+          if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + 15, 1ull);
+          n_sweeps = n0;
+          {
+            const unsigned lo8 = (unsigned)opaque(lane * 8);
+            static_for<0, NE>([&](auto Jc) { g.template load_async<decltype(Jc)::value>(tp, lo8); });
+            g.settle();
+          }
+#pragma unroll
+          for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (TAIL && t < a.T) tv[t][k] = Ttail[t * NR + tc0 + k];
+          if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
+          first_words(x, lane);
+          __builtin_amdgcn_wave_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        run_steps<NR, 63, NR + 63, TAIL, false>(g, w, Areg, pb, x, acc, last_step); // the block's last sweep
+        __builtin_amdgcn_sched_barrier(0);
+        first_words(x, lane); // the next block's first class words
+        SB_STAMP2(11);
+        md = sweep_end();
+        SB_STAMP2(12);
+        d1 = d0;
+        d0 = (float)md;
         converged = md <= p.conv_threshold;
         if (converged || n_sweeps >= p.iter_limit) break;
       }
@@ -470,7 +684,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           zs[(size_t)a.Z * ZRS + lane] += tv[t][0] + tv[t][1]; // the lane's own column of the scratch
         }
       const double *np_ = a.temp + (size_t)(bn < a.B ? bn : b) * a.state_doubles;
-      hand_over<NE, 0>(e, zw, zm, tp + lane, np_ + lane, zs);
+      hand_over<NR, 0>(g, zw, zm, tp, np_, opaque(lane * 8), zs);
+      g.settle();
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(4);
@@ -523,8 +738,12 @@ int launch(const Dev &d, hipStream_t stream, bool prepare) {
 
 int dispatch(const Dev &d, hipStream_t stream, bool prepare) {
   const bool tail = d.T > 0;
+#ifdef SB_TWO_ONLY // developer builds: one instantiation
+  if (d.NR == 76 && tail) return launch<76, true>(d, stream, prepare);
+#else
   if (d.NR == 76) return tail ? launch<76, true>(d, stream, prepare) : launch<76, false>(d, stream, prepare);
   if (d.NR == 80) return tail ? launch<80, true>(d, stream, prepare) : launch<80, false>(d, stream, prepare);
+#endif
   return (int)hipErrorInvalidValue;
 }
 
