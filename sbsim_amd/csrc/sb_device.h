@@ -80,6 +80,8 @@ struct Dev {
   int lw[2], l0[2], rowbase[2], nch[2]; // per wave: rows, first lane, first row, 8-step chunks
   int lag;                 // wave 1 runs `lag` chunk slots behind wave 0
   int nslots;              // chunk slots (barriers) per sweep
+  float pred_haste;        // mode 4: block-length prediction (step_two.hip predict_block)
+  int pred_margin;
   int lds_reg_bytes;       // dynamic LDS per workgroup (one building)
   int wg_per_cu;
   int r_seam, r_A, r_zscr, r_xchg, r_zoff, r_zmode; // LDS offsets in doubles

@@ -304,13 +304,14 @@ __device__ __forceinline__ void run_steps(Grid<NR> &g, Win &w, const double (&Ar
 }
 
 // Sweeps to run overlapped before the next look at max|delta|: d1 -> d0 over the last sweep, the
-// threshold `thr`, `room` sweeps to the iteration limit.  Assumes a decay 1.25 x as fast (in the
-// exponent) as the last one and stops one sweep short of where that would converge.
-__device__ __forceinline__ int predict_block(float d1, float d0, float thr, int room) {
+// threshold `thr`, `room` sweeps to the iteration limit.  Assumes a decay `haste` x as fast (in the
+// exponent) as the last one and stops `margin` sweeps short of where that would converge
+// (Dev::pred_haste, Dev::pred_margin: 1.0, 0 -- the decay slows down as the fast modes die out).
+__device__ __forceinline__ int predict_block(float d1, float d0, float thr, int room, float haste, int margin) {
   int m = 1;
   if (d0 < d1 && d0 > thr && thr > 0.0f) {
-    const float r = __log2f(thr / d0) / (1.25f * __log2f(d0 / d1));
-    m = r < 40.0f ? (int)r - 1 : 32;
+    const float r = __log2f(thr / d0) / (haste * __log2f(d0 / d1));
+    m = r < 40.0f ? (int)r - margin : 32;
   }
   m = min(min(m, 32), room);
   return m < 2 ? 1 : m;
@@ -582,9 +583,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma nounroll
       for (;;) { // simulator.py:348-368
         // a block of m sweeps: overlapped, stopping after exactly m
-        int m = n_sweeps >= 2 ? predict_block(d1, d0, thr, p.iter_limit - n_sweeps) : 1;
+        int m = n_sweeps >= 2 ? predict_block(d1, d0, thr, p.iter_limit - n_sweeps, a.pred_haste, a.pred_margin) : 1;
         m = __builtin_amdgcn_readfirstlane(m);
         const int n0 = n_sweeps;
+        if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + (m > 1 ? 13 : 14), 1ull); // developer aid: blocks / single sweeps
         if (m > 1 && n0 > 0) { // the grid as of n0 sweeps, should the block overrun (before any sweep: Tprev is still there)
           const unsigned lo8 = (unsigned)opaque(lane * 8);
           static_for<0, NE>([&](auto Jc) { g.template store<decltype(Jc)::value>(tp, lo8); });

@@ -56,7 +56,7 @@ def _step_in(g, t, has_action=True, occupancy=None):
 
 
 @pytest.mark.parametrize("tag,kernel", [("random", "reg"), ("const", "reg-pair"), ("const", "lds"),
-                                        ("random", "lds-columns")])
+                                        ("random", "lds-columns"), ("random", "reg-two")])
 def test_one_day_rollout_against_reference_golden(tag, kernel, monkeypatch):
   """BASELINE.json configs[0] semantics on the GPU: SB1 physics on R9, 288 steps."""
   _need_gpu()
@@ -66,13 +66,17 @@ def test_one_day_rollout_against_reference_golden(tag, kernel, monkeypatch):
   # owns rows 0..63 and the last two (wall) rows are finished by a scan; "reg-pair": columns as
   # lanes, two wavefronts per building exchanging their seam rows through LDS; "lds": rows as
   # lanes on the LDS-grid kernel (two bands + seam); "lds-columns": the LDS-grid kernel on the
-  # transposed grid.  All four wavefront schedules are checked against the reference.
+  # transposed grid; "reg-two": columns as lanes, one wavefront, two columns per lane, sweeps
+  # overlapped in predicted blocks (step_two.hip).  All five wavefront schedules are checked
+  # against the reference.
   if kernel.startswith("lds"):
     monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
+  if kernel == "reg-pair":
+    monkeypatch.setenv("SBSIM_NO_TWO_ROW_PATH", "1")   # the library's own choice for 96 x 66 is "reg-two"
   sim = BatchedSimulator(_plan(load("plan_r9_sb1.npz")), SimConfig.sb1(), B, float(g["h_conv"]),
                          orientation={"reg": "auto", "reg-pair": "columns", "lds": "rows",
-                                      "lds-columns": "columns"}[kernel])
-  assert sim.transposed == (kernel in ("reg-pair", "lds-columns"))
+                                      "lds-columns": "columns", "reg-two": "columns"}[kernel])
+  assert sim.transposed == (kernel in ("reg-pair", "lds-columns", "reg-two"))
   assert sim.launch_info["path"] == (1 if kernel.startswith("reg") else 0)
   assert sim.launch_info["waves_per_building"] == (2 if kernel == "reg-pair" else 1)
   sim.reset()
@@ -564,10 +568,29 @@ def _oracle_twin(plan, cfg, init_flat):
 def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, monkeypatch):
   """BASELINE.json configs[2] semantics: other floor-plan classes (different H x W and zone
   counts) through the same C ABI, each checked against its CPU-oracle twin."""
-  _need_gpu()
   from sbsim_amd.floorplan import rectangular_floor_plan
+  _check_plan_against_oracle(rectangular_floor_plan(rooms, room_shape), rooms[0] * rooms[1], orientation, path, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("haste,margin", [(1.0, 0), (0.3, -3)])
+def test_two_rows_kernel_tail_rows_and_overrun_blocks(haste, margin, monkeypatch):
+  """step_two.hip: a 130-row plan (SB1-synth with a 3-CV wall at the bottom: TWO tail rows), and the
+  block-length prediction pushed far too high: most blocks overrun and are run again from the
+  stored grid -- sweep counts and temperatures must not notice."""
+  from sbsim_amd.floorplan import rectangular_floor_plan
+  fp = rectangular_floor_plan((14, 9), (8, 7))
+  fp = np.insert(fp, fp.shape[0] - 2, fp[-2], axis=0)
+  assert fp.shape == (132, 77)
+  monkeypatch.setenv("SBSIM_DEBUG_PRED_HASTE", str(haste))
+  monkeypatch.setenv("SBSIM_DEBUG_PRED_MARGIN", str(margin))
+  _check_plan_against_oracle(fp, 126, "rows", 1, monkeypatch, expect_steps=76 + 64 - 1 + 8)
+
+
+def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatch, expect_steps=None):
+  _need_gpu()
   g = load("h2_sb1_r9_random.npz")
-  plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, room_shape), Materials.sb1(), 10.0, 300.0)
+  plan = FloorPlan.from_file_input(file_plan, Materials.sb1(), 10.0, 300.0)
   H, W = plan.shape
   B, T = 6, 14
   rs = np.random.RandomState(11)
@@ -580,7 +603,9 @@ def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, 
   if path == 0:
     monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
   sim = BatchedSimulator(plan, cfg, B, float(g["h_conv"]), orientation=orientation)
-  assert sim.Z == rooms[0] * rooms[1] and sim.launch_info["path"] == path
+  assert sim.Z == n_zones and sim.launch_info["path"] == path
+  if expect_steps is not None:
+    assert sim.launch_info["sweep_steps"] == expect_steps   # the two-rows kernel with two tail rows
   sim.reset(temps=torch.tensor(init, dtype=torch.float64, device="cuda"))
   twins = [_oracle_twin(plan, cfg, init[b]) for b in range(B)]
   obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
