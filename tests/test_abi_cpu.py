@@ -61,18 +61,24 @@ def _plan_info(fp, n_obs=46, n_buildings=1024):
 def test_plan_info_picks_the_step_kernel_without_a_gpu():
   """Host-only launch planning (sb_plan_info): R9 (68x98, 66x96 inside the exterior ring) runs
   on the register path either way -- lanes = rows: one wavefront owns rows 0..63 and the two
-  remaining wall rows are finished by a scan; lanes = columns: two wavefronts per building --
-  and three buildings fit a CU's LDS; a small plan uses one wavefront per building."""
+  remaining wall rows are finished by a scan (four buildings per CU); lanes = columns: one
+  wavefront, two columns per lane, two buildings per CU; a 129-row plan: two rows per lane + one
+  tail row; a small plan uses one wavefront per building."""
   from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
   r9 = FloorPlan.from_file_input(rectangular_floor_plan((3, 3), (20, 30)), Materials.sb1(), 10.0, 300.0)
   rc, rows = _plan_info(r9)
   assert rc == 0 and rows["path"] == 1 and rows["waves_per_building"] == 1
-  assert 3 * ((rows["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
+  assert 4 * ((rows["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
   rc, cols = _plan_info(r9.transposed())
-  assert rc == 0 and cols["path"] == 1 and cols["waves_per_building"] == 2
-  assert rows["sweep_steps"] < cols["sweep_steps"]
-  assert 3 * ((cols["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024   # three buildings per CU
+  assert rc == 0 and cols["path"] == 1 and cols["waves_per_building"] == 1
+  assert cols["sweep_steps"] == 76 + 48 - 1            # step_two.hip: 66 columns -> 76 slots, 96 rows -> 48 lanes
+  assert 2 * ((cols["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024   # two buildings per CU
   assert cols["algorithmic_bytes_per_env_step"] == 53764
+  sb1 = FloorPlan.from_file_input(rectangular_floor_plan((14, 9), (8, 7)), Materials.sb1(), 10.0, 300.0)
+  rc, big = _plan_info(sb1)
+  assert rc == 0 and big["path"] == 1 and big["waves_per_building"] == 1
+  assert big["sweep_steps"] == 76 + 64 - 1 + 4         # 129 x 75 inside the ring: 64 lanes + one tail row
+  assert 2 * ((big["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
   small = FloorPlan.from_file_input(rectangular_floor_plan((1, 2), (6, 8)), Materials.sb1(), 10.0, 300.0)
   rc, one = _plan_info(small)
   assert rc == 0 and one["path"] == 1 and one["waves_per_building"] == 1
