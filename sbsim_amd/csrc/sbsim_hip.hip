@@ -501,7 +501,9 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
       if (P == 3 && R >= 64) { r.cell_state[x * W + y] = NR * 64 + (R - 64) * NR + col; continue; }
       const int w = (P == 2 && R >= r.lw[0]) ? 1 : 0;
       const int lp = R - r.rowbase[w];
-      r.cell_state[x * W + y] = ((col + lp) % NR) * RS + R; // state layout [NR][RS]
+      const int slot = (col + lp) % NR;
+      if (P == 3) r.cell_state[x * W + y] = (slot / 2) * 128 + R * 2 + (slot & 1); // step_roll.hip: [NR / 2][64][2]
+      else r.cell_state[x * W + y] = slot * RS + R;                                   // state layout [NR][RS]
     }
   r.ok = true;
 }

@@ -234,18 +234,27 @@ __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], 
 // operations) ahead: memory operations return in order, so waiting for a word that is only a few
 // slots old would drain the queue of row loads in front of it.
 constexpr int kZA = 8;
+// HBM state layout: [NR / 2][64 lanes][2] -- a lane's two neighbouring slots are 16 bytes, so the
+// loop moves a building with NR / 2 stores and NR / 2 loads of 16 bytes per lane (a wavefront has
+// at most 63 memory operations in flight: the count of operations, not their size, paces the loop).
 template <int NR, int J>
 __device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kWin], unsigned long long (&zw)[kZA + 1],
                                           const unsigned long long *zmap, double *tp, const double *np_, double *zs) {
+  static_assert(NR % 2 == 0, "slot pairs");
   if constexpr (J < NR) {
     if constexpr (J % 4 == 0 && J / 4 + kZA < (NR + 3) / 4) zw[(J / 4 + kZA) % (kZA + 1)] = zmap[(J / 4 + kZA) * 64];
     if constexpr (J < kWin) e[J] = lanes_upto<J>() ? bk[J] : e[J];
-    const unsigned off = (unsigned)((zw[(J / 4) % (kZA + 1)] >> (16 * (J & 3))) & 0xffffull);
-    tp[J * 64] = e[J];
-    __hip_atomic_fetch_add((double *)((char *)zs + off), e[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    e[J] = np_[J * 64];
-    if constexpr ((J & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-    hand_over<NR, J + 1>(e, bk, zw, zmap, tp, np_, zs);
+    if constexpr (J + 1 < kWin) e[J + 1] = lanes_upto<J + 1>() ? bk[J + 1] : e[J + 1];
+    const unsigned long long w = zw[(J / 4) % (kZA + 1)];
+    const unsigned off0 = (unsigned)((w >> (16 * (J & 3))) & 0xffffull), off1 = (unsigned)((w >> (16 * ((J + 1) & 3))) & 0xffffull);
+    *(d2 *)(tp + J * 64) = d2{e[J], e[J + 1]};
+    __hip_atomic_fetch_add((double *)((char *)zs + off0), e[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add((double *)((char *)zs + off1), e[J + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const d2 nv = *(const d2 *)(np_ + J * 64);
+    e[J] = nv.x;
+    e[J + 1] = nv.y;
+    if constexpr ((J & 7) == 6) __builtin_amdgcn_sched_barrier(0);
+    hand_over<NR, J + 2>(e, bk, zw, zmap, tp, np_, zs);
   }
 }
 
@@ -390,9 +399,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   if ((int)blockIdx.x < a.B) {
     const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles;
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      e[j] = tp_[R];
-      tp_ += RS;
+    for (int j = 0; j < NR; j += 2) { // state layout [NR / 2][64][2]
+      const d2 v = *(const d2 *)(tp_ + j * 64 + 2 * R);
+      e[j] = v.x;
+      e[j + 1] = v.y;
     }
     SB_LOAD_AUX(blockIdx.x);
   }
@@ -568,7 +578,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         }
       const double *np_ = a.temp + (size_t)(bn < a.B ? bn : b) * a.state_doubles;
       static_assert(RS == 64, "hand_over: slot stride");
-      hand_over<NR, 0>(e, bk, zw, zm, tp + R, np_ + R, zs);
+      hand_over<NR, 0>(e, bk, zw, zm, tp + 2 * R, np_ + 2 * R, zs);
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(5);

@@ -37,7 +37,6 @@ constexpr int kTailMax = 2;
 constexpr int kSets = 32;  // entries of the coefficient-set table (at LDS address 0)
 constexpr int kWA = 4;     // class words (two steps each) are read this many words ahead
 constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in the hand-over
-constexpr int kG = 4;      // per-class g: up to 4 x 64 classes
 
 // Slots of A kept in LDS (the rest in registers): with them a building needs < 80 KB of LDS -- two
 // per CU.  Row stride 2 * slots + 2 doubles: 2 mod 4, conflict-free ds_read_b128 across 16 lanes.
@@ -465,18 +464,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   x.voff = 0;
   const int last_step = NR + a.lw[0] - 2; // a.lw[0]: lanes that own rows
   // the lane's tail cells (static per floor plan): LDS offsets of their coefficient sets (two
-  // 16-bit halves) and of their (ap, g) entries
+  // 16-bit halves)
   const bool tactive = TAIL && tail_col<NR>(lane, 0) >= 0;
   const int tc0 = tactive ? tail_col<NR>(lane, 0) : 0;
-  int tset[kTailMax], tcls[kTailMax];
+  int tset[kTailMax];
 #pragma unroll
   for (int t = 0; t < kTailMax; ++t) {
     tset[t] = (a.ncset - 1) * 32 * 0x10001; // the pad set (the table's last)
-    tcls[t] = (16 * a.ncls) * 0x10001;
-    if (TAIL && t < a.T && tactive) {
+    if (TAIL && t < a.T && tactive)
       tset[t] = ((int)a.tcset[t * NR + tc0] << 2) | ((int)a.tcset[t * NR + tc0 + 1] << 18); // set * 8 -> set * 32
-      tcls[t] = ((int)a.tcls[t * NR + tc0] << 4) | ((int)a.tcls[t * NR + tc0 + 1] << 20);   // class -> class * 16
-    }
   }
   const unsigned long long *amap = a.amapS + lane;
   const unsigned long long *zmap = a.zmapS + lane;
@@ -488,18 +484,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   Grid<NR> g;
   g.init();
   Win w;
-  double nx_g[kG] = {0.0, 0.0, 0.0, 0.0}, nx_tail[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}, nx_tnow = 0.0, nx_lo = 0.0, nx_hi = 0.0;
+  double nx_tnow = 0.0, nx_lo = 0.0, nx_hi = 0.0;
+  double tv[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // the lane's tail cells
+  // a building's small inputs: its g per class goes straight into the (ap, g) table (free once the
+  // previous building's A pass is done), its tail rows into tv
 #define SB_LOAD_AUX(bb)                                                                         \
   do {                                                                                          \
     nx_tnow = a.bld[(bb)].t_now;                                                                \
     nx_lo = a.scal[(size_t)(bb) * kNScal + 16];                                                 \
     nx_hi = a.scal[(size_t)(bb) * kNScal + 17];                                                 \
-    _Pragma("unroll") for (int k = 0; k < kG; ++k)                                              \
-      if (k * 64 < a.ts) nx_g[k] = a.gtabg[(size_t)(bb) * a.ts + ((k * 64 + lane) & (a.ts - 1))]; \
+    for (int c = lane; c < a.ts; c += 64) tapg[2 * c + 1] = a.gtabg[(size_t)(bb) * a.ts + c];   \
     const double *tt_ = a.temp + (size_t)(bb) * a.state_doubles + NE * 64;                      \
     _Pragma("unroll") for (int t = 0; t < kTailMax; ++t)                                        \
       _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
-        if (TAIL && t < a.T) nx_tail[t][k] = tt_[t * NR + tc0 + k];                             \
+        if (TAIL && t < a.T) tv[t][k] = tt_[t * NR + tc0 + k];                                  \
   } while (0)
   if ((int)blockIdx.x < a.B) {
     const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles;
@@ -522,14 +520,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // exterior-space cells outside the trim box all become t_now in the first sweep
     // (simulator.py:256-258); their largest |delta| follows from their extreme values
     const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0;
-#pragma unroll
-    for (int k = 0; k < kG; ++k)
-      if (k * 64 + lane < a.ts) tapg[2 * (k * 64 + lane) + 1] = nx_g[k];
-    double tv[kTailMax][2];
-#pragma unroll
-    for (int t = 0; t < kTailMax; ++t)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) tv[t][k] = nx_tail[t][k];
     if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -540,7 +530,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
       for (int k = 0; k < 2; ++k)
         if (TAIL && t < a.T && tactive) {
-          const d2 pg = *(const d2 *)((const char *)tapg + ((tcls[t] >> (16 * k)) & 0xffff));
+          const d2 pg = *(const d2 *)((const char *)tapg + 16 * (int)a.tcls[t * NR + tc0 + k]); // (ap, g) of the cell's class
           At[t][k] = fma(pg.x, tv[t][k], pg.y);
         }
     double Areg[kNAR];

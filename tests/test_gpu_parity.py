@@ -415,6 +415,50 @@ def test_full_size_batch_register_and_lds_kernels_agree(monkeypatch):
     sim.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("rooms,room_shape,B", [((8, 5), (12, 14), 16384), ((14, 9), (8, 7), 8192)])
+def test_mixed_classes_at_size_two_rows_and_lds_kernels_agree(rooms, room_shape, B, monkeypatch):
+  """BASELINE.json configs[2]'s larger classes ("SB2-synth" 107x78, "SB1-synth" 129x75 inside the
+  ring) at batch size: the two-rows-per-lane register kernel with its predicted blocks and the
+  LDS-grid kernel must take the same number of Gauss-Seidel sweeps for EVERY building at every
+  step (tens of sweeps each, blocks overrunning now and then) and end within 1e-9 K of each other."""
+  _need_gpu()
+  from sbsim_amd.floorplan import rectangular_floor_plan
+  g = load("h2_sb1_r9_random.npz")
+  plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, room_shape), Materials.sb1(), 10.0, 300.0)
+  H, W = plan.shape
+  T = 6
+  gen = torch.Generator(device="cuda")
+  gen.manual_seed(9)
+  t0 = (294.0 + torch.randn((B, 1), generator=gen, device="cuda", dtype=torch.float64)).clamp(285.0, 305.0)
+  init = (t0 + 0.05 * torch.randn((B, H * W), generator=gen, device="cuda", dtype=torch.float64)).contiguous()
+  acts = torch.rand((T, B, 2), generator=gen, device="cuda", dtype=torch.float32) * 2.0 - 1.0
+  sims = []
+  for force_lds in (False, True):
+    if force_lds:
+      monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
+    sim = BatchedSimulator(plan, SimConfig.sb1(), B, float(g["h_conv"]))
+    assert sim.launch_info["path"] == (0 if force_lds else 1)
+    sim.reset(temps=init)
+    assert torch.equal(sim.temps().reshape(B, -1), init)
+    sims.append(sim)
+  obs = [torch.zeros((B, s.O), dtype=torch.float32, device="cuda") for s in sims]
+  rew = [torch.zeros((B,), dtype=torch.float32, device="cuda") for _ in sims]
+  info = [torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda") for _ in sims]
+  total = 0.0
+  for t in range(T):
+    si = _step_in(g, 100 + t)
+    for k, sim in enumerate(sims):
+      sim.step(acts[t], si, obs[k], rew[k], info[k])
+    assert torch.equal(info[0][:, 4], info[1][:, 4]), t          # sweeps, every building
+    total += float(info[0][:, 4].sum())
+    assert float((sims[0].zone_temps() - sims[1].zone_temps()).abs().max()) < 1e-9, t
+  assert float((sims[0].temps() - sims[1].temps()).abs().max()) < 1e-9
+  assert 5.0 < total / (B * T) <= 100.0
+  for sim in sims:
+    sim.close()
+
+
 def test_full_size_isothermal_fixed_point():
   """A size-independent property at the full BASELINE batch: a building that is everywhere at
   the ambient temperature, with the air handler passing that air through (heating setpoint <=
