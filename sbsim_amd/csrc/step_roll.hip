@@ -26,16 +26,17 @@
 //     mask that one DPP shift per step maintains is OR-ed into the high word, one running max
 //     (sweep k) and one running min (sweep k+1) -- no lane compare, no select
 // Plain step: 14.5 issue slots (was 16), window step 19.5 (was 22), 12 LDS cycles (was 20).
-#include "sb_device.h"
+#include "sweep_common.h"
 
 namespace sb {
 namespace {
+
+using namespace sweep;
 
 #ifndef SB_ONE_WAIT
 #define SB_ONE_WAIT 1
 #endif
 constexpr int kWin = 63;      // steps of a period in which the lanes are in two different sweeps
-constexpr int kTailMax = 2;
 constexpr int kTS = 32;       // entries of the per-class tables (ap, g) and of the coefficient-set table
 constexpr int kSeamPad = 8;
 
@@ -45,37 +46,6 @@ constexpr int kSeamPad = 8;
 constexpr int lds_slots(int NR) { return NR == 96 ? 74 : ((NR / 2) % 2 ? NR : NR + 2); }
 constexpr int a_stride(int NR) { return NR == 96 ? 74 : ((NR / 2) % 2 ? NR : NR + 2); }
 constexpr int tail_row(int NR) { return NR + 4; } // tail rows in LDS: column c at [2 + c], zero guards around
-
-__device__ __forceinline__ int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
-// Lanes 0..J as a lane predicate: one SALU instruction where it is used.
-template <int J>
-__device__ __forceinline__ bool lanes_upto() {
-  unsigned long long m;
-  asm volatile("s_bfm_b64 %0, %1, 0" : "=s"(m) : "n"(J + 1));
-  return __builtin_amdgcn_inverse_ballot_w64(m);
-}
-
-// lane l <- lane l-1 (CTRL 0x138, wave_shr:1) / lane l+1 (0x130, wave_shl:1).  SEAM: the lane
-// without a source keeps `old`; otherwise it reads 0.
-template <int CTRL, bool SEAM>
-__device__ __forceinline__ double wave_shift1(double x, double old) {
-  int lo, hi;
-  if (SEAM) {
-    lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, 0xf, false);
-  } else {
-    lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
-  }
-  return __hiloint2double(hi, lo);
-}
-
-typedef double d2 __attribute__((ext_vector_type(2))); // two doubles = one ds_read_b128
-typedef const d2 __attribute__((address_space(3))) *lds_d2;
 
 struct PairBuf { // LDS values of two consecutive steps
   d2 ud0, lr0, ud1, lr1; // (bU, bD), (bL, bR)
@@ -256,78 +226,6 @@ __device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kW
     if constexpr ((J & 7) == 6) __builtin_amdgcn_sched_barrier(0);
     hand_over<NR, J + 2>(e, bk, zw, zmap, tp, np_, zs);
   }
-}
-
-// ---------------------------------------------------------------- tail rows
-// Rows 64.. of the trimmed grid (at most two) are finished after the wavefront's pass, lanes =
-// columns.  Along a row the Gauss-Seidel update is the first-order recurrence
-//     x_c = bL_c * x_{c-1} + q_c,    q_c = A + bD*D_old + bR*R_old + bU*U_new,
-// which an inclusive scan over the affine maps f_c(x) = bL_c x + q_c evaluates in log2(64) DPP
-// steps (F <- F o F_shifted; lanes without a source compose with the identity).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void scan_step(double &a, double &q) {
-  const double one = 1.0;
-  const int alo = __builtin_amdgcn_update_dpp(__double2loint(one), __double2loint(a), CTRL, ROW_MASK, 0xf, false);
-  const int ahi = __builtin_amdgcn_update_dpp(__double2hiint(one), __double2hiint(a), CTRL, ROW_MASK, 0xf, false);
-  const int qlo = __builtin_amdgcn_update_dpp(0, __double2loint(q), CTRL, ROW_MASK, 0xf, false);
-  const int qhi = __builtin_amdgcn_update_dpp(0, __double2hiint(q), CTRL, ROW_MASK, 0xf, false);
-  const double as = __hiloint2double(ahi, alo), qs = __hiloint2double(qhi, qlo);
-  q = fma(a, qs, q); // (a, q) o (as, qs) = (a*as, a*qs + q)
-  a = a * as;
-}
-__device__ __forceinline__ void affine_scan(double &a, double &q) {
-  scan_step<0x111, 0xf>(a, q); // row_shr:1,2,4,8: inclusive scan inside each row of 16 lanes
-  scan_step<0x112, 0xf>(a, q);
-  scan_step<0x114, 0xf>(a, q);
-  scan_step<0x118, 0xf>(a, q);
-  scan_step<0x142, 0xa>(a, q); // row_bcast:15 -> rows 1 and 3
-  scan_step<0x143, 0xc>(a, q); // row_bcast:31 -> rows 2 and 3
-}
-
-// A lane owns two neighbouring columns of a tail row: NR <= 128 columns are one 64-lane scan.  The
-// columns sit in the TOP lanes (that is where the shift registers deliver row 63): lane l owns
-// columns 2 (l - L0), 2 (l - L0) + 1 with L0 = 64 - NR / 2.
-template <int NR>
-__device__ __forceinline__ int tail_col(int lane, int k) { return 2 * (lane - (64 - NR / 2)) + k; }
-
-// One Gauss-Seidel pass over the tail rows; returns the lane's max |delta|.  The rows' current
-// values live in registers (tv[t][k]: the lane's two cells of tail row t); U0 / U1: row 63's new
-// values above them; the first tail row also goes to LDS (tE0, by column: lane 63 reads it as its
-// lower neighbour during the next sweep).  The lane first composes the maps of its two columns
-// (x_{2l+1} = bL1*(bL0*x + q0) + q1), the scan runs over the 64 composed maps, and the even column
-// follows from its left neighbour.  Lanes without columns use the pad set (all zero).
-// tset[t]: byte offsets of the lane's two cells' coefficient sets in the table (low / high half).
-template <int NR>
-__device__ __forceinline__ double tail_pass(int T, bool active, double *tE0c, double U0, double U1,
-                                            double (&tv)[kTailMax][2], const int (&tset)[kTailMax],
-                                            const double (&At)[kTailMax][2]) {
-  static_assert(NR % 2 == 0 && NR <= 128, "two columns per lane");
-  double dmax = 0.0;
-#pragma unroll
-  for (int t = 0; t < kTailMax; ++t) {
-    if (t < T) {
-      const lds_d2 s0 = (lds_d2)(unsigned)(tset[t] & 0xffff), s1 = (lds_d2)((unsigned)tset[t] >> 16);
-      const d2 ud0 = s0[0], lr0 = s0[1], ud1 = s1[0], lr1 = s1[1];
-      const double old0 = tv[t][0], old1 = tv[t][1];
-      const double R1 = wave_shift1<0x130, false>(old0, 0.0); // the next lane's first column (not yet updated)
-      const double D0 = t + 1 < T ? tv[t + 1 < kTailMax ? t + 1 : t][0] : 0.0, D1 = t + 1 < T ? tv[t + 1 < kTailMax ? t + 1 : t][1] : 0.0;
-      const double q0 = fma(ud0.x, U0, fma(lr0.y, old1, fma(ud0.y, D0, At[t][0]))); // right neighbour: not yet updated
-      const double q1 = fma(ud1.x, U1, fma(lr1.y, R1, fma(ud1.y, D1, At[t][1])));
-      double a = lr1.x * lr0.x, Q = fma(lr1.x, q0, q1);
-      affine_scan(a, Q); // Q: the odd column (the row starts from bL = 0: no carry-in)
-      const double xl = wave_shift1<0x138, false>(Q, 0.0); // the column to the left of the lane's first
-      const double x0 = fma(lr0.x, xl, q0);
-      if (active) {
-        dmax = fmax(dmax, fmax(fabs(x0 - old0), fabs(Q - old1)));
-        tv[t][0] = x0;
-        tv[t][1] = Q;
-        if (t == 0) *(d2 *)tE0c = d2{x0, Q}; // 16-byte aligned: even column, even row base
-      }
-      U0 = x0; // the next tail row's upper neighbours
-      U1 = Q;
-    }
-  }
-  return dmax;
 }
 
 extern __shared__ __attribute__((aligned(16))) double lds[];
