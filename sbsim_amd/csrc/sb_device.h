@@ -82,6 +82,7 @@ struct Dev {
   int nslots;              // chunk slots (barriers) per sweep
   float pred_haste;        // mode 4: block-length prediction (step_two.hip predict_block)
   int pred_margin;
+  int pred_first;          // mode 4: sweeps of a step's first block when the previous step took >= 6 (1: start with single sweeps)
   int lds_reg_bytes;       // dynamic LDS per workgroup (one building)
   int wg_per_cu;
   int r_seam, r_A, r_zscr, r_xchg, r_zoff, r_zmode; // LDS offsets in doubles

@@ -694,6 +694,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.pred_haste = 1.0f; d.pred_margin = 0; // measured (tools/bench_two_rows.py): 0.3 % of the blocks overrun
     if (const char *e = getenv("SBSIM_DEBUG_PRED_HASTE")) d.pred_haste = (float)atof(e); // developer knobs: speed only,
     if (const char *e = getenv("SBSIM_DEBUG_PRED_MARGIN")) d.pred_margin = atoi(e);      // never the result
+    d.pred_first = 4;
+    if (const char *e = getenv("SBSIM_DEBUG_PRED_FIRST")) d.pred_first = std::max(1, atoi(e));
     SB_TRY(upload(h->zone_cells_l, plan->zone_cells, (size_t)plan->zone_off[plan->Z]));
     SB_TRY(upload(h->cmapS, r.cmapS.data(), r.cmapS.size()));
     SB_TRY(upload(h->amapS, r.amapS.data(), r.amapS.size()));

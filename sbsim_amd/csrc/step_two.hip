@@ -223,14 +223,12 @@ __device__ __forceinline__ void step(Grid<NR> &g, Win &w, const StepBuf &p, Acc 
   double sa = nva, sb = nvb;
   if constexpr (ROLL && S >= NR) {
     constexpr int J = S - NR;
-    const double da = nva - w.ca, db = nvb - w.cb;
-    // +|d| in the lanes still in sweep k, -|d| in the lanes already in sweep k+1
-    const double sda = __hiloint2double((__double2hiint(da) & 0x7fffffff) | acc.sg, __double2loint(da));
-    const double sdb = __hiloint2double((__double2hiint(db) & 0x7fffffff) | acc.sg, __double2loint(db));
-    acc.cur = fmax(acc.cur, sda);
-    acc.neg = fmin(acc.neg, sda);
-    acc.cur = fmax(acc.cur, sdb);
-    acc.neg = fmin(acc.neg, sdb);
+    // the lane's two cells are in the same sweep: one |d| for both, + in the lanes still in sweep k,
+    // - in the lanes already in sweep k+1
+    const double dm = fmax(fabs(nva - w.ca), fabs(nvb - w.cb));
+    const double sd = __hiloint2double(__double2hiint(dm) | acc.sg, __double2loint(dm));
+    acc.cur = fmax(acc.cur, sd);
+    acc.neg = fmin(acc.neg, sd);
     asm volatile("" : "+v"(acc.neg)); // here: sunk below the period's exit, the minima keep every sd of the period alive
     if constexpr (J + 1 < 63) // lane J + 1 starts its next sweep at the next step (lane 0 keeps its bit)
       acc.sg = __builtin_amdgcn_update_dpp(acc.sg, acc.sg, 0x138, 0xf, 0xf, false);
@@ -476,11 +474,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         return md;
       };
       const float thr = (float)p.conv_threshold;
+      const int prev_sweeps = __builtin_amdgcn_readfirstlane(a.nsw[b] & 0xffff); // of this building's previous step
       float d1 = 0.0f, d0 = 0.0f; // max |delta| of the last two sweeps
 #pragma nounroll
       for (;;) { // simulator.py:348-368
         // a block of m sweeps: overlapped, stopping after exactly m
-        int m = n_sweeps >= 2 ? predict_block(d1, d0, thr, p.iter_limit - n_sweeps, a.pred_haste, a.pred_margin) : 1;
+        // the first block: no decay to go by yet -- three sweeps if the building's previous step took
+        // six or more (a hint only: a step that converges sooner overruns and is run again from Tprev)
+        int m = n_sweeps >= 2 ? predict_block(d1, d0, thr, p.iter_limit - n_sweeps, a.pred_haste, a.pred_margin)
+                : (n_sweeps == 0 && prev_sweeps >= 6 ? min(a.pred_first, p.iter_limit) : 1);
         m = __builtin_amdgcn_readfirstlane(m);
         const int n0 = n_sweeps;
         if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + (m > 1 ? 13 : 14), 1ull); // developer aid: blocks / single sweeps
