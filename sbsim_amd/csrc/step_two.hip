@@ -185,15 +185,17 @@ __device__ __forceinline__ void load_step(StepBuf &p, Ctx &x, const double (&Are
   const unsigned long long wd = x.w[(S / 2) % (kWA + 1)];
   const unsigned h = S % 2 == 0 ? (unsigned)wd : (unsigned)(wd >> 32);
   const lds_d2 sa = (lds_d2)(h & 0xffffu), sb = (lds_d2)(h >> 16);
+  // A last: the step's first FMA needs it, so its one s_waitcnt covers every read of the step
+  if constexpr (TAIL && S >= 63) p.sm = *(const double __attribute__((address_space(3))) *)(x.seam + 8u * S);
+  else p.sm = 0.0;
   p.uda = sa[0];
   p.lra = sa[1];
   p.udb = sb[0];
   p.lrb = sb[1];
+  __builtin_amdgcn_sched_barrier(0);
   constexpr int r = S % NR, NL = lds_slots(NR);
   if constexpr (r < NL) p.A = *(lds_d2)(x.arow + 16u * r);
   else p.A = d2{Areg[2 * (r - NL)], Areg[2 * (r - NL) + 1]};
-  if constexpr (TAIL && S >= 63) p.sm = *(const double __attribute__((address_space(3))) *)(x.seam + 8u * S);
-  else p.sm = 0.0;
 }
 
 // One Gauss-Seidel update of every lane's two current cells at step S:
