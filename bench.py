@@ -244,7 +244,7 @@ def mixed_config(args) -> None:
     kern_s += ms * 1e-3
     per_class[c["name"]] = {
         "grid": list(env.sim.plan.shape), "zones": env.sim.Z, "buildings": env.sim.B,
-        "kernel": "k_sweep_roll / k_sweep_reg" if li["path"] == 1 else "k_sweep_lds",
+        "kernel": _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?"),
         "sweep_kernel_ms": ms, "mean_sweeps_per_env_step": float(env.info[:, 4].mean()),
         "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launch": li}
   zone_updates = sum(c["env"].sim.B * c["env"].sim.Z for c in classes) * K
@@ -266,6 +266,94 @@ def mixed_config(args) -> None:
     c["env"].close()
 
 
+def policy_config(args) -> None:
+  """BASELINE.json configs[4] (SURVEY.md 8d "Config 5"): the configs[1] batch per GPU driven through
+  `BatchedEnvironment.step()` by a SAC-shaped actor (2 x 128 MLP, tanh-squashed Gaussian, the policy
+  network of the reference's SAC notebook) evaluated on the environment's own GPU -- observations
+  never leave HBM, data-parallel actors, no per-step collective.  env-steps/s INCLUDE policy inference
+  and the host-side step inputs.  tf-agents is not installable here: the loop makes the same env API
+  calls (`reset()`, `step(action)` -> TimeStep) a tf-agents driver would."""
+  rank, local_rank, world = sd.env_rank_world()
+  torch.cuda.set_device(local_rank)
+  distributed = sd.init_process_group("nccl")
+  if distributed:
+    import torch.distributed as dist
+    if dist.get_world_size() != args.gpus:
+      raise SystemExit(f"bench.py: --gpus {args.gpus} but {dist.get_world_size()} ranks are running")
+  elif args.gpus != 1:
+    raise SystemExit(f"bench.py: --gpus {args.gpus} but only one rank is running")
+  dev = torch.device("cuda", local_rank)
+  B, K, W = args.buildings, args.steps, args.warmup
+  plan = r9_plan()
+  env = BatchedEnvironment(plan, B, device=local_rank, holiday_calendar="us", num_days_in_episode=3)
+  H, Wd = plan.shape
+  Z = env.sim.Z
+  ts = env.reset()
+  rs = np.random.RandomState(sd.shard_seed(7, rank))
+  t_init = np.clip(294.0 + rs.randn(B), 285.0, 305.0)
+  env.sim.reset(temps=torch.tensor(t_init, dtype=torch.float64, device=dev)[:, None].expand(B, H * Wd).contiguous())
+  torch.manual_seed(sd.shard_seed(0, rank))
+  O = env.observation_spec().shape[0]
+  actor = torch.nn.Sequential(torch.nn.Linear(O, 128), torch.nn.ReLU(), torch.nn.Linear(128, 128), torch.nn.ReLU(),
+                              torch.nn.Linear(128, 4)).to(dev)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(sd.shard_seed(1, rank))
+
+  @torch.no_grad()
+  def act(obs):
+    out = actor(torch.nan_to_num(obs))
+    mean, log_std = out[:, :2], out[:, 2:].clamp(-5, 2)
+    return torch.tanh(mean + log_std.exp() * torch.randn(mean.shape, device=dev, generator=gen)).contiguous()
+
+  def barrier():
+    if distributed:
+      dist.barrier()
+    torch.cuda.synchronize(dev)
+
+  obs = ts.observation
+  returns = torch.zeros((B,), dtype=torch.float32, device=dev)
+  for _ in range(W):
+    ts = env.step(act(obs))
+    obs = ts.observation
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(K):
+    ts = env.step(act(obs))
+    obs = ts.observation
+    returns += ts.reward
+  barrier()
+  elapsed = sd.max_over_ranks(time.perf_counter() - t0, dev)
+  gather_ms, n_gathered = 0.0, B
+  if distributed:
+    g0 = time.perf_counter()
+    n_gathered = int(sd.gather_returns(returns, world * B).numel())
+    torch.cuda.synchronize(dev)
+    gather_ms = (time.perf_counter() - g0) * 1e3
+  if rank == 0:
+    li = env.sim.launch_info
+    env_steps_per_s = world * B * K / elapsed
+    achieved = li["algorithmic_bytes_per_env_step"] * B * K / elapsed / 1e9
+    print(json.dumps({
+        "metric": "zone-updates/sec (env-steps/sec x 9 zones) INCLUDING policy inference, batch=64k buildings per GPU",
+        "value": env_steps_per_s * Z, "unit": "zone-updates/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "env_steps_per_s": env_steps_per_s,
+        "return_gather_ms": gather_ms, "gathered_returns": n_gathered,
+        "config": {"workload": "BASELINE.json configs[4]: configs[1]'s batch per GPU driven through BatchedEnvironment.step() "
+                               "by a SAC-shaped actor (2 x 128 MLP, tanh-squashed Gaussian) on the environment's GPU",
+                   "buildings_per_gpu": B, "grid": [H, Wd], "zones": Z, "policy": "MLP %d-128-128-4, fp32" % O,
+                   "mean_return_per_step": float(returns.mean()) / K,
+                   "parallelism": f"{world} x (building shard + its own actor), no per-step collective", "launch": li},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?"),
+                     "note": "over the whole env step including the policy network (a smooth policy needs fewer "
+                             "Gauss-Seidel sweeps per step than random actions)"}}))
+  env.close()
+  if distributed:
+    dist.destroy_process_group()
+
+
 def main() -> None:
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -276,9 +364,10 @@ def main() -> None:
   ap.add_argument("--iteration-limit", type=int, default=100,
                   help="Simulator.iteration_limit (100 = the reference's SB1 value; 1 is used only to "
                        "calibrate the PMC byte counters on a known traffic pattern)")
-  ap.add_argument("--config", choices=("replicated", "mixed"), default="replicated",
+  ap.add_argument("--config", choices=("replicated", "mixed", "policy"), default="replicated",
                   help="replicated: BASELINE.json configs[1] (the metric's configuration, default); "
-                       "mixed: configs[2], three floor-plan classes on one GPU")
+                       "mixed: configs[2], three floor-plan classes on one GPU; policy: configs[4], the "
+                       "replicated batch driven by a SAC-shaped actor on the same GPU(s)")
   ap.add_argument("--stub-step", action="store_true",
                   help="developer / CPU test: launcher, barrier and return-gather plumbing with a stub step (gloo)")
   args = ap.parse_args()
@@ -289,6 +378,8 @@ def main() -> None:
     if args.gpus != 1:
       raise SystemExit("bench.py --config mixed is a one-GPU configuration")
     return mixed_config(args)
+  if args.config == "policy":
+    return policy_config(args)
 
   rank, local_rank, world = sd.env_rank_world()
   torch.cuda.set_device(local_rank)
@@ -396,7 +487,7 @@ def main() -> None:
                    "return_gather_ms": gather_ms, "launch": li},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "k_sweep_reg" if li.get("path") == 1 else "k_sweep_lds",
+                     "kernel": _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?"),
                      "avg_kernel_ms": avg_kernel_s * 1e3,
                      # the step's two small launches around it (device algebra, reward/observation)
                      "avg_pre_kernel_ms": pre_ms, "avg_post_kernel_ms": post_ms,

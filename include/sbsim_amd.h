@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 5
+#define SB_ABI_VERSION 6
 #define SB_NUM_ACTIONS 2   /* the SB1 action set (sim_config.gin:239-242): boiler supply_water_setpoint, AHU
                             * supply_air_heating_temperature_setpoint -- the default of sb_params.n_actions */
 #define SB_ACTION_KEEP (-3.0e38f)
@@ -175,13 +175,23 @@ typedef struct sb_step_in {
   float aux[SB_NUM_AUX];       /* auxiliary observation features at t+dt, already fp32 */
 } sb_step_in;
 
+typedef enum sb_sweep_kernel {
+  SB_KERNEL_LDS = 0,      /* k_sweep_lds: grid in LDS, any plan that fits (step_lds.hip) */
+  SB_KERNEL_REG = 1,      /* k_sweep_reg mode 1: one wavefront, <= 64 rows (step_reg.hip) */
+  SB_KERNEL_REG_PAIR = 2, /* k_sweep_reg mode 2: two wavefronts, <= 128 rows */
+  SB_KERNEL_ROLL = 3,     /* k_sweep_roll: one wavefront + tail rows, overlapped sweeps (step_roll.hip) */
+  SB_KERNEL_TWO_ROWS = 4  /* k_sweep_two: two rows per lane, 67..130 rows, sweeps overlapped in blocks (step_two.hip) */
+} sb_sweep_kernel;
+
 /* Launch geometry chosen for the floor plan (reported for DESIGN.md / bench.py). */
 typedef struct sb_launch_info {
   int32_t waves_per_workgroup, workgroups, lds_bytes_per_workgroup, sweep_steps;
   int64_t algorithmic_bytes_per_env_step; /* 8HW+24Z+4A+4O+44 (fp32 state) */
   int64_t state_bytes_per_env_step;       /* what this build really moves: fp64 grid r+w */
-  int32_t path;               /* 1: grid in registers (step_reg.hip), 0: grid in LDS (step_lds.hip) */
+  int32_t path;               /* 1: grid in registers, 0: grid in LDS (step_lds.hip) */
   int32_t waves_per_building; /* wavefronts that share one building (1 or 2) */
+  int32_t kernel;             /* sb_sweep_kernel: which sweep kernel owns this floor plan */
+  int32_t reserved;
 } sb_launch_info;
 
 int sb_abi_version(void);

@@ -14,7 +14,7 @@ SB_NUM_ACTIONS = 2     # the SB1 action set; sb_params.n_actions is the width of
 SB_MAX_ACTIONS = 16
 SB_ACTION_KEEP = -3.0e38   # sb_step_in.actions_native: this column leaves its field alone
 SB_NUM_AUX = 7
-SB_ABI_VERSION = 5   # include/sbsim_amd.h
+SB_ABI_VERSION = 6   # include/sbsim_amd.h
 # sb_action_kind
 SB_ACT_BOILER_SUPPLY_WATER_SETPOINT, SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT = 0, 1
 SB_ACT_AHU_SUPPLY_AIR_COOLING_SETPOINT, SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND = 2, 3
@@ -100,7 +100,12 @@ class LaunchInfo(C.Structure):
               ("lds_bytes_per_workgroup", C.c_int32), ("sweep_steps", C.c_int32),
               ("algorithmic_bytes_per_env_step", C.c_int64),
               ("state_bytes_per_env_step", C.c_int64),
-              ("path", C.c_int32), ("waves_per_building", C.c_int32)]
+              ("path", C.c_int32), ("waves_per_building", C.c_int32),
+              ("kernel", C.c_int32), ("reserved", C.c_int32)]
+
+
+# sb_sweep_kernel
+SWEEP_KERNELS = {0: "k_sweep_lds", 1: "k_sweep_reg", 2: "k_sweep_reg (two wavefronts)", 3: "k_sweep_roll", 4: "k_sweep_two"}
 
 
 EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",

@@ -573,6 +573,7 @@ void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan 
   if (r.ok) {
     out->path = 1;
     out->waves_per_building = r.P == 2 ? 2 : 1;
+    out->kernel = r.P; // sb_sweep_kernel: modes 1..4 are SB_KERNEL_REG .. SB_KERNEL_TWO_ROWS
     out->waves_per_workgroup = r.P == 2 ? 2 : 1;
     out->workgroups = std::max(1, std::min(n_buildings, cus * r.wg_per_cu));
     out->lds_bytes_per_workgroup = r.lds_bytes;
@@ -585,6 +586,7 @@ void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan 
     if (wpw > 4) { wg_per_cu = std::min(8, wpw / 4); wpw = 4; } // several smaller workgroups once 4 waves fit
     out->path = 0;
     out->waves_per_building = 1;
+    out->kernel = SB_KERNEL_LDS;
     out->waves_per_workgroup = wpw;
     out->workgroups = std::max(1, std::min((n_buildings + wpw - 1) / wpw, cus * wg_per_cu));
     out->lds_bytes_per_workgroup = (int32_t)(q.shared_bytes + q.wave_bytes * wpw);

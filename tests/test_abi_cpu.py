@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
   assert set(names) == set(_ffi.EXPORTS), (names, _ffi.EXPORTS)
   for n in names:
     assert hasattr(lib, n), n
-  assert _ffi.load().sb_abi_version() == _ffi.SB_ABI_VERSION == 5
+  assert _ffi.load().sb_abi_version() == _ffi.SB_ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header():
@@ -67,21 +67,21 @@ def test_plan_info_picks_the_step_kernel_without_a_gpu():
   from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
   r9 = FloorPlan.from_file_input(rectangular_floor_plan((3, 3), (20, 30)), Materials.sb1(), 10.0, 300.0)
   rc, rows = _plan_info(r9)
-  assert rc == 0 and rows["path"] == 1 and rows["waves_per_building"] == 1
+  assert rc == 0 and rows["path"] == 1 and rows["waves_per_building"] == 1 and rows["kernel"] == 3   # k_sweep_roll
   assert 4 * ((rows["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
   rc, cols = _plan_info(r9.transposed())
-  assert rc == 0 and cols["path"] == 1 and cols["waves_per_building"] == 1
+  assert rc == 0 and cols["path"] == 1 and cols["waves_per_building"] == 1 and cols["kernel"] == 4   # k_sweep_two
   assert cols["sweep_steps"] == 76 + 48 - 1            # step_two.hip: 66 columns -> 76 slots, 96 rows -> 48 lanes
   assert 2 * ((cols["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024   # two buildings per CU
   assert cols["algorithmic_bytes_per_env_step"] == 53764
   sb1 = FloorPlan.from_file_input(rectangular_floor_plan((14, 9), (8, 7)), Materials.sb1(), 10.0, 300.0)
   rc, big = _plan_info(sb1)
-  assert rc == 0 and big["path"] == 1 and big["waves_per_building"] == 1
+  assert rc == 0 and big["path"] == 1 and big["waves_per_building"] == 1 and big["kernel"] == 4
   assert big["sweep_steps"] == 76 + 64 - 1 + 4         # 129 x 75 inside the ring: 64 lanes + one tail row
   assert 2 * ((big["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
   small = FloorPlan.from_file_input(rectangular_floor_plan((1, 2), (6, 8)), Materials.sb1(), 10.0, 300.0)
   rc, one = _plan_info(small)
-  assert rc == 0 and one["path"] == 1 and one["waves_per_building"] == 1
+  assert rc == 0 and one["path"] == 1 and one["waves_per_building"] == 1 and one["kernel"] == 1
 
 
 def test_plan_checks_reject_bad_tables_without_a_gpu():
