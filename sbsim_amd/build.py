@@ -15,7 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["sbsim_hip.hip", "step_reg.hip", "step_roll.hip", "step_two.hip", "step_lds.hip",    # one translation unit per step kernel
            "generators.hip",                                 # occupancy / convection generators
            "floorplan.cpp", "episode.cpp"]                   # host-only: floor-plan preprocessing, episode shards
-HEADERS = [os.path.join(CSRC, "sb_device.h"), os.path.join(CSRC, "sb_host.h"), os.path.join(ROOT, "include", "sbsim_amd.h")]
+HEADERS = [os.path.join(CSRC, "sb_device.h"), os.path.join(CSRC, "sb_host.h"), os.path.join(CSRC, "sweep_common.h"),
+           os.path.join(ROOT, "include", "sbsim_amd.h")]
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(_HERE, "libsbsim_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-fPIC"]
