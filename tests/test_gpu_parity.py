@@ -631,7 +631,18 @@ def test_two_rows_kernel_tail_rows_and_overrun_blocks(haste, margin, monkeypatch
   _check_plan_against_oracle(fp, 126, "rows", 1, monkeypatch, expect_steps=76 + 64 - 1 + 8)
 
 
-def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatch, expect_steps=None):
+@pytest.mark.parametrize("limit", [1, 3, 7, 12])
+def test_two_rows_kernel_iteration_limit(limit, monkeypatch):
+  """simulator.py:348-368 with a limit that bites on the two-rows-per-lane kernel ("SB2-synth" needs
+  ~18 sweeps per step): blocks are clipped to the sweeps that are left, the limit ends a step at a
+  block's exact stop, sweep counts and grids against the oracle."""
+  from sbsim_amd.floorplan import rectangular_floor_plan
+  _check_plan_against_oracle(rectangular_floor_plan((8, 5), (12, 14)), 40, "auto", 1, monkeypatch,
+                             iteration_limit=limit, expect_kernel=4)
+
+
+def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatch, expect_steps=None,
+                               iteration_limit=None, expect_kernel=None):
   _need_gpu()
   g = load("h2_sb1_r9_random.npz")
   plan = FloorPlan.from_file_input(file_plan, Materials.sb1(), 10.0, 300.0)
@@ -641,6 +652,9 @@ def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatc
   init = np.clip(294.0 + 2.0 * rs.randn(B, 1) + 0.2 * rs.randn(B, H * W), 285.0, 305.0)
   acts = rs.uniform(-1, 1, size=(T, B, 2)).astype(np.float32)
   cfg = SimConfig.sb1()
+  if iteration_limit is not None:
+    import dataclasses
+    cfg = dataclasses.replace(cfg, iteration_limit=iteration_limit)
   if orientation == "generic":
     monkeypatch.setenv("SBSIM_FORCE_GENERIC_SWEEP", "1")
     orientation = "rows"
@@ -650,6 +664,8 @@ def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatc
   assert sim.Z == n_zones and sim.launch_info["path"] == path
   if expect_steps is not None:
     assert sim.launch_info["sweep_steps"] == expect_steps   # the two-rows kernel with two tail rows
+  if expect_kernel is not None:
+    assert sim.launch_info["kernel"] == expect_kernel
   sim.reset(temps=torch.tensor(init, dtype=torch.float64, device="cuda"))
   twins = [_oracle_twin(plan, cfg, init[b]) for b in range(B)]
   obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
