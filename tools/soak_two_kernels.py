@@ -1,9 +1,13 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from sbsim_amd.environment import BatchedEnvironment, SimConfig
-from bench import r9_plan
+from bench import MIXED_CLASSES, r9_plan
+from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
 B, T = int(os.environ.get("B", 4096)), int(os.environ.get("T", 900))
 plan = r9_plan()
+if os.environ.get("PLAN"):   # PLAN=SB2-synth / SB1-synth: the two-rows-per-lane kernel against the LDS-grid kernel
+    _, rooms, shape = next(c for c in MIXED_CLASSES if c[0] == os.environ["PLAN"])
+    plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
 envs = []
 for force in (False, True):
     if force: os.environ["SBSIM_FORCE_LDS_PATH"] = "1"
@@ -17,4 +21,4 @@ for t in range(T):
     if outs[0].step_type[0].item() == 0: continue   # reset step
     mism += int((envs[0].info[:, 4] != envs[1].info[:, 4]).sum())
     worst = max(worst, float((envs[0].sim.zone_temps() - envs[1].sim.zone_temps()).abs().max()))
-print("steps", T, "buildings", B, "sweep-count mismatches", mism, "max |dT_zone| between kernels", worst, "paths", envs[0].sim.launch_info["path"], envs[1].sim.launch_info["path"])
+print("steps", T, "buildings", B, "sweep-count mismatches", mism, "max |dT_zone| between kernels", worst, "kernels", envs[0].sim.launch_info["kernel"], envs[1].sim.launch_info["kernel"])
