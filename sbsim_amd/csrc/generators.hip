@@ -15,12 +15,30 @@ constexpr int kLdsCap = 160 * 1024;
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): ten
 // rounds of two 32x32 -> 64 multiplies on a 128-bit counter under a 64-bit key.
 __device__ inline void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
     c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
+}
+
+// Position of the k-th (0-based) set bit of m (k < popcount(m)): halving by population counts, no
+// lane-divergent loop.
+__device__ inline int kth_set_bit(unsigned long long m, int k) {
+  int pos = 0;
+  uint32_t w = (uint32_t)m;
+  int c = __popc(w);
+  if (k >= c) { k -= c; pos = 32; w = (uint32_t)(m >> 32); }
+#pragma unroll
+  for (int half = 16; half >= 1; half >>= 1) {
+    const uint32_t lo = w & ((1u << half) - 1u);
+    c = __popc(lo);
+    if (k >= c) { k -= c; pos += half; w >>= half; }
+    else w = lo;
+  }
+  return pos;
 }
 
 struct OccArgs {
@@ -158,9 +176,7 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
           if (!(u > o.p)) { // :119
             const int cnt = __popcll(cc[q].mask);
             int pick = (int)(((unsigned long long)c[1] * (unsigned long long)cnt) >> 32); // uniform in [0, cnt)
-            unsigned long long m = cc[q].mask;
-            for (; pick > 0; --pick) m &= m - 1; // drop the lowest set bits
-            const int k = __ffsll((long long)m) - 1;
+            const int k = kth_set_bit(cc[q].mask, pick);
             other = o.local[cc[q].gh + o.off[k]]; // off[k]: offset k as a step in the handle's grid
           }
           ConvRec r;
