@@ -149,7 +149,10 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
   ConvRec *rec = (ConvRec *)conv_lds;            // [max_room]
   double *vout = (double *)(rec + o.max_room);   // [max_room] the value that ends in this cell
   int *head = (int *)(vout + o.max_room);        // [max_room] first swap that chose this cell (-1: none)
+  __shared__ int soff[64];                       // the offset table as steps in the handle's grid
   const int tid = threadIdx.x;
+  if (tid < 64) soff[tid] = tid < o.n_off ? o.off[tid] : 0;
+  __syncthreads();
   for (int z = 0; z < o.Z; ++z) {
     const int c0 = o.zone_off[z], n = o.zone_off[z + 1] - c0;
     ConvCell cc[Q];
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
             const int cnt = __popcll(cc[q].mask);
             int pick = (int)(((unsigned long long)c[1] * (unsigned long long)cnt) >> 32); // uniform in [0, cnt)
             const int k = kth_set_bit(cc[q].mask, pick);
-            other = o.local[cc[q].gh + o.off[k]]; // off[k]: offset k as a step in the handle's grid
+            other = o.local[cc[q].gh + soff[k]]; // offset k as a step in the handle's grid
           }
           ConvRec r;
           r.key = c[2];
