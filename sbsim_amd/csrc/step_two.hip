@@ -276,7 +276,8 @@ __device__ __forceinline__ void run_steps(Grid<NR> &g, Win &w, const double (&Ar
 // Sweeps to run overlapped before the next look at max|delta|: d1 -> d0 over the last sweep, the
 // threshold `thr`, `room` sweeps to the iteration limit.  Assumes a decay `haste` x as fast (in the
 // exponent) as the last one and stops `margin` sweeps short of where that would converge
-// (Dev::pred_haste, Dev::pred_margin: 1.0, 0 -- the decay slows down as the fast modes die out).
+// (Dev::pred_haste, Dev::pred_margin: 1.0, -1 = one sweep PAST it: the decay slows down as the fast
+// modes die out, so the extrapolation errs on the short side).
 __device__ __forceinline__ int predict_block(float d1, float d0, float thr, int room, float haste, int margin) {
   int m = 1;
   if (d0 < d1 && d0 > thr && thr > 0.0f) {
