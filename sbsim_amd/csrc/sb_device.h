@@ -80,9 +80,9 @@ struct Dev {
   int lw[2], l0[2], rowbase[2], nch[2]; // per wave: rows, first lane, first row, 8-step chunks
   int lag;                 // wave 1 runs `lag` chunk slots behind wave 0
   int nslots;              // chunk slots (barriers) per sweep
-  float pred_haste;        // mode 4: block-length prediction (step_two.hip predict_block)
-  int pred_margin;
-  int pred_first;          // mode 4: sweeps of a step's first block when the previous step took >= 6 (1: start with single sweeps)
+  float pred_haste;        // mode 4: when may the next sweep overlap (step_two.hip may_roll)
+  float pred_slack;
+  int pred_first;          // mode 4: a step's first block rolls pred_first - 1 periods unseen when the previous step took >= 6 sweeps (1: never)
   int lds_reg_bytes;       // dynamic LDS per workgroup (one building)
   int wg_per_cu;
   int r_seam, r_A, r_zscr, r_xchg, r_zoff, r_zmode; // LDS offsets in doubles

@@ -693,10 +693,10 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.lag = r.lag; d.nslots = r.nslots; d.nsteps = r.steps;
     d.lds_reg_bytes = r.lds_bytes; d.wg_per_cu = r.wg_per_cu;
     d.r_seam = r.r_seam; d.r_A = r.r_A; d.r_xchg = r.r_xchg;
-    d.pred_haste = 1.0f; d.pred_margin = -1; // measured (tools/bench_two_rows.py): 1-5 % of the building-steps see an overrun
-    if (const char *e = getenv("SBSIM_DEBUG_PRED_HASTE")) d.pred_haste = (float)atof(e); // developer knobs: speed only,
-    if (const char *e = getenv("SBSIM_DEBUG_PRED_MARGIN")) d.pred_margin = atoi(e);      // never the result
-    d.pred_first = 4;
+    d.pred_haste = 1.0f; d.pred_slack = 1.0f; // measured (tools/bench_two_rows.py); developer knobs: speed only,
+    if (const char *e = getenv("SBSIM_DEBUG_PRED_HASTE")) d.pred_haste = (float)atof(e); // never the result
+    if (const char *e = getenv("SBSIM_DEBUG_PRED_SLACK")) d.pred_slack = (float)atof(e);
+    d.pred_first = 3;
     if (const char *e = getenv("SBSIM_DEBUG_PRED_FIRST")) d.pred_first = std::max(1, atoi(e));
     SB_TRY(upload(h->zone_cells_l, plan->zone_cells, (size_t)plan->zone_off[plan->Z]));
     SB_TRY(upload(h->cmapS, r.cmapS.data(), r.cmapS.size()));

@@ -16,16 +16,18 @@
 // ds_read_b128 per cell, addressed by 16-bit LDS offsets that arrive in class words from L2).
 //
 // Sweeps are overlapped in BLOCKS (step_roll.hip overlaps all of them, undoing the started sweep from
-// copies -- another 252 registers here).  A block of m sweeps is a ramp-up (63 steps, lanes > s
-// masked), m - 1 rolling periods of NR steps (lanes <= s - NR already in the next sweep) and a final
-// period whose lanes <= s - NR are masked: it stops after exactly m sweeps, and costs 63 + m NR
-// steps instead of m (NR + 63).  Whether sweep k was the last one (simulator.py:360) is known only
-// after its period, so m comes from a prediction (the decay of max|delta| over the last two
-// sweeps, rounded towards fewer sweeps): the grid is stored before a block, and a block that finds
-// max|delta| <= threshold before its last sweep is run again from the stored grid with m = that
-// sweep -- the iterates and the sweep count are always those of the plain schedule; the prediction
-// only decides the speed.  max|delta| of the two sweeps in flight is separated by its sign as in
-// step_roll.hip.  Two buildings fit in a CU's LDS, so two of the four SIMDs run (LDS-grid kernel: one).
+// copies -- another 252 registers here).  A block is a ramp-up (63 steps, lanes > s masked), rolling
+// periods of NR steps (lanes <= s - NR already in the next sweep) and a final period whose lanes
+// <= s - NR are masked: it stops after exactly m sweeps and costs 63 + m NR steps instead of
+// m (NR + 63).  Whether sweep k was the last one (simulator.py:360) is known only after its period,
+// so a period rolls only while the decay of max|delta| over the last two sweeps says that the NEXT
+// sweep cannot converge yet (may_roll); then the block ends with a final period, and if that sweep
+// did not converge either, the next block starts.  The grid is stored before a block; a rolling
+// period that finds max|delta| <= threshold has started the next sweep already -- the block is run
+// again from the stored grid with m = that sweep.  The iterates and the sweep count are always
+// those of the plain schedule; the prediction only decides the speed.  max|delta| of the two sweeps
+// in flight is separated by its sign as in step_roll.hip.  Two buildings fit in a CU's LDS, so two
+// of the four SIMDs run (LDS-grid kernel: one).
 #include <type_traits>
 
 #include "sweep_common.h"
@@ -273,19 +275,15 @@ __device__ __forceinline__ void run_steps(Grid<NR> &g, Win &w, const double (&Ar
   }
 }
 
-// Sweeps to run overlapped before the next look at max|delta|: d1 -> d0 over the last sweep, the
-// threshold `thr`, `room` sweeps to the iteration limit.  Assumes a decay `haste` x as fast (in the
-// exponent) as the last one and stops `margin` sweeps short of where that would converge
-// (Dev::pred_haste, Dev::pred_margin: 1.0, -1 = one sweep PAST it: the decay slows down as the fast
-// modes die out, so the extrapolation errs on the short side).
-__device__ __forceinline__ int predict_block(float d1, float d0, float thr, int room, float haste, int margin) {
-  int m = 1;
-  if (d0 < d1 && d0 > thr && thr > 0.0f) {
-    const float r = __log2f(thr / d0) / (haste * __log2f(d0 / d1));
-    m = r < 40.0f ? (int)r - margin : 32;
-  }
-  m = min(min(m, 32), room);
-  return m < 2 ? 1 : m;
+// May the sweep after the last one run overlapped, i.e. is it safe to assume that it will NOT be the
+// step's last?  d1 -> d0: max|delta| of the last two sweeps.  Extrapolates the last decay (`haste` x
+// as fast, in the exponent) to the threshold: r sweeps to go; the next sweep may overlap if r > slack
+// (Dev::pred_haste, Dev::pred_slack: 1.0, 1.0 -- the decay slows down as the fast modes die out, so
+// the extrapolation errs on the short side).  Speed only: a wrong yes is found out and repaired.
+__device__ __forceinline__ bool may_roll(float d1, float d0, float thr, float haste, float slack) {
+  if (!(d0 > thr)) return false;
+  if (!(d0 < d1)) return true; // not decaying
+  return __log2f(thr / d0) < slack * haste * __log2f(d0 / d1); // r = log(thr/d0) / (haste log(d0/d1)) > slack; both logarithms are negative
 }
 
 // A = ap*Tprev + g for the lane's cells (e = Tprev before the first sweep): the pair of slot j to
@@ -481,15 +479,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       float d1 = 0.0f, d0 = 0.0f; // max |delta| of the last two sweeps
 #pragma nounroll
       for (;;) { // simulator.py:348-368
-        // a block of m sweeps: overlapped, stopping after exactly m
-        // the first block: no decay to go by yet -- three sweeps if the building's previous step took
-        // six or more (a hint only: a step that converges sooner overruns and is run again from Tprev)
-        int m = n_sweeps >= 2 ? predict_block(d1, d0, thr, p.iter_limit - n_sweeps, a.pred_haste, a.pred_margin)
-                : (n_sweeps == 0 && prev_sweeps >= 6 ? min(a.pred_first, p.iter_limit) : 1);
-        m = __builtin_amdgcn_readfirstlane(m);
+        // a block: ramp-up, rolling periods while the next sweep cannot be the last one, final period.
+        // The step's first block has no decay to go by: it rolls (pred_first - 1 periods, then by the
+        // decay) if the building's previous step took six sweeps or more -- a hint; a step that
+        // converges sooner is found out and run again from Tprev.
         const int n0 = n_sweeps;
-        if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + (m > 1 ? 13 : 14), 1ull); // developer aid: blocks / single sweeps
-        if (m > 1 && n0 > 0) { // the grid as of n0 sweeps, should the block overrun (before any sweep: Tprev is still there)
+        int roll0 = n0 >= 2 ? (int)may_roll(d1, d0, thr, a.pred_haste, a.pred_slack) : (int)(n0 == 0 && prev_sweeps >= 6 && a.pred_first > 1);
+        roll0 = __builtin_amdgcn_readfirstlane(roll0) && n0 + 2 <= p.iter_limit;
+        if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + (roll0 ? 13 : 14), 1ull); // developer aid: blocks / single sweeps
+        if (roll0 && n0 > 0) { // the grid as of n0 sweeps, should the block overrun (before any sweep: Tprev is still there)
           const unsigned lo8 = (unsigned)opaque(lane * 8);
           static_for<0, NE>([&](auto Jc) { g.template store<decltype(Jc)::value>(tp, lo8); });
 #pragma unroll
@@ -497,8 +495,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             if (TAIL && t < a.T && tactive) *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
         }
         double md = 0.0;
+        int m = 0; // > 0: the block is being run again and ends with its m-th sweep
 #pragma nounroll
-        for (;;) { // at most twice: the second time with m = the sweep that converged
+        for (;;) { // at most twice
           __builtin_amdgcn_sched_barrier(0);
 #define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && n_sweeps == 4 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
           SB_STAMP2(10);
@@ -513,7 +512,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           run_steps<NR, 0, 63, TAIL, false>(g, w, Areg, pb, x, acc, last_step); // ramp-up; reads ahead for step 63
           bool overrun = false;
 #pragma nounroll
-          for (int q = 1; q < m; ++q) {
+          for (int q = 1;; ++q) {
+            int go;
+            if (m > 0) go = q < m;
+            else if (!roll0 || n_sweeps + 2 > p.iter_limit) go = 0; // the final period must fit under the limit
+            else if (q == 1) go = 1;
+            else go = n_sweeps >= 2 ? (int)may_roll(d1, d0, thr, a.pred_haste, a.pred_slack) : (int)(q < a.pred_first);
+            if (!__builtin_amdgcn_readfirstlane(go)) break;
             // A does not change during the sweeps: unless its address does (as far as the compiler can
             // tell), every ds_read of the period is hoisted out of this loop -- into scratch
             asm volatile("" : "+v"(x.arow), "+v"(x.seam));

@@ -617,17 +617,17 @@ def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("haste,margin", [(1.0, 0), (0.3, -3)])
-def test_two_rows_kernel_tail_rows_and_overrun_blocks(haste, margin, monkeypatch):
+@pytest.mark.parametrize("haste,slack", [(1.0, 1.0), (1.0, 0.0)])
+def test_two_rows_kernel_tail_rows_and_overrun_blocks(haste, slack, monkeypatch):
   """step_two.hip: a 130-row plan (SB1-synth with a 3-CV wall at the bottom: TWO tail rows), and the
-  block-length prediction pushed far too high: most blocks overrun and are run again from the
-  stored grid -- sweep counts and temperatures must not notice."""
+  prediction switched off (slack 0: every period rolls, so every step runs past its last sweep and
+  is run again from the stored grid) -- sweep counts and temperatures must not notice."""
   from sbsim_amd.floorplan import rectangular_floor_plan
   fp = rectangular_floor_plan((14, 9), (8, 7))
   fp = np.insert(fp, fp.shape[0] - 2, fp[-2], axis=0)
   assert fp.shape == (132, 77)
   monkeypatch.setenv("SBSIM_DEBUG_PRED_HASTE", str(haste))
-  monkeypatch.setenv("SBSIM_DEBUG_PRED_MARGIN", str(margin))
+  monkeypatch.setenv("SBSIM_DEBUG_PRED_SLACK", str(slack))
   _check_plan_against_oracle(fp, 126, "rows", 1, monkeypatch, expect_steps=76 + 64 - 1 + 8)
 
 
