@@ -608,6 +608,7 @@ def _oracle_twin(plan, cfg, init_flat):
     ((14, 9), (8, 7), "auto", 1),      # "SB1-synth" 129x75, 137 cell classes -> two rows per lane + ONE tail row, 76 slots
     ((5, 3), (24, 24), "rows", 1),     # 128x78: two rows per lane, all 64 lanes, no tail row
     ((4, 4), (15, 17), "rows", 1),     # 67x75: two rows per lane, 34 lanes (the sweep ends early)
+    ((14, 7), (8, 10), "rows", 1),     # 129x80: two rows per lane, 80 slots + ONE tail row
 ])
 def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, monkeypatch):
   """BASELINE.json configs[2] semantics: other floor-plan classes (different H x W and zone
