@@ -223,7 +223,7 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
   auto cell_class = [&](int R, int col) { // trimmed coordinates
     return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? (int)plan->cell_class[(x0 + R) * W + (y0 + col)] : pad;
   };
-  const int NW = (NR + 63 + 1) / 2, NWD = (NE + 3) / 4;
+  const int NW = NR + 63, NWD = (NE + 3) / 4;
   r.cmapS.assign((size_t)NW * 64, 0);
   r.amapS.assign((size_t)NWD * 64, 0);
   r.zmapS.assign((size_t)NWD * 64, 0);
@@ -239,15 +239,11 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
       const int R = 2 * lane + k;
       return (R < Hw && col >= 0 && col < NR) ? cell_class(R, col) : pad;
     };
-    for (int wd = 0; wd < NW; ++wd) { // two steps per word: (upper, lower) set offsets
-      unsigned long long word = 0;
-      for (int k = 0; k < 4; ++k) {
-        const int st = 2 * wd + k / 2;
-        int col = st - lane;
-        if (col >= NR) col -= NR; // rolling periods: the lane is in its next sweep
-        word |= (unsigned long long)(set_of[row_class(k & 1, col)] * 32) << (16 * k);
-      }
-      r.cmapS[(size_t)wd * 64 + lane] = word;
+    for (int st = 0; st < NW; ++st) { // one word per step: (upper, lower) set offsets in its halves
+      int col = st - lane;
+      if (col >= NR) col -= NR; // rolling periods: the lane is in its next sweep
+      r.cmapS[(size_t)st * 64 + lane] = (unsigned long long)(set_of[row_class(0, col)] * 32) |
+                                        ((unsigned long long)(set_of[row_class(1, col)] * 32) << 32);
     }
     for (int g = 0; g < NWD; ++g) { // register J = 2 * slot + (row & 1)
       unsigned long long aword = 0, zword = 0;

@@ -38,7 +38,7 @@ namespace {
 using namespace sweep;
 
 constexpr int kSets = 32;  // entries of the coefficient-set table (at LDS address 0)
-constexpr int kWA = 4;     // class words (two steps each) are read this many words ahead
+constexpr int kWA = 7;     // class words (one step each) are read this many words ahead
 constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in the hand-over
 
 // Slots of A kept in LDS (the rest in registers): with them a building needs < 80 KB of LDS -- two
@@ -150,11 +150,11 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
-// Class words: per step two 16-bit fields -- the LDS byte offsets (set * 32) of the coefficient
-// sets of the lane's upper and lower cell -- two steps per 64-bit word, read from global memory
-// (L2 hits) kWA words ahead.
+// Class words: one 64-bit word per step -- the LDS byte offsets (set * 32) of the coefficient sets of
+// the lane's upper (low half) and lower cell (high half): the halves ARE the ds_read addresses, no
+// instruction to extract them -- read from global memory (L2 hits) kWA steps ahead.
 template <int NR>
-constexpr int words_per_sweep() { return (NR + 63 + 1) / 2; }
+constexpr int words_per_sweep() { return NR + 63; }
 __device__ __forceinline__ unsigned long long class_word(const Ctx &x) {
   return *(const unsigned long long *)(x.cmap + x.voff);
 }
@@ -167,26 +167,25 @@ __device__ __forceinline__ void first_words(Ctx &x, int lane) { // words 0 .. kW
   }
 }
 
-// A rolling period starts at step 63 = the odd half of word 31; load_step<64> continues with word 36.
+// A rolling period starts at step 63; load_step<63> continues with word 63 + kWA.
 __device__ __forceinline__ void period_words(Ctx &x, int lane) {
-  x.voff = (unsigned)opaque(lane * 8 + 31 * 512);
+  x.voff = (unsigned)opaque(lane * 8 + 63 * 512);
 #pragma unroll
-  for (int k = 0; k <= kWA; ++k) {
-    x.w[(31 + k) % (kWA + 1)] = class_word(x);
-    if (k < kWA) x.voff += 512u;
+  for (int k = 0; k < kWA; ++k) {
+    x.w[(63 + k) % (kWA + 1)] = class_word(x);
+    if (k + 1 < kWA) x.voff += 512u;
   }
 }
 
 template <int NR, int S, bool TAIL, int NAR>
 __device__ __forceinline__ void load_step(StepBuf &p, Ctx &x, const double (&Areg)[NAR]) {
-  if constexpr (S % 2 == 0 && S / 2 + kWA < words_per_sweep<NR>()) {
+  if constexpr (S + kWA < words_per_sweep<NR>()) {
     x.voff += 512u;
     asm volatile("" : "+v"(x.voff)); // a running offset: nothing for the compiler to hoist
-    x.w[(S / 2 + kWA) % (kWA + 1)] = class_word(x);
+    x.w[(S + kWA) % (kWA + 1)] = class_word(x);
   }
-  const unsigned long long wd = x.w[(S / 2) % (kWA + 1)];
-  const unsigned h = S % 2 == 0 ? (unsigned)wd : (unsigned)(wd >> 32);
-  const lds_d2 sa = (lds_d2)(h & 0xffffu), sb = (lds_d2)(h >> 16);
+  const unsigned long long wd = x.w[S % (kWA + 1)];
+  const lds_d2 sa = (lds_d2)(unsigned)wd, sb = (lds_d2)(unsigned)(wd >> 32);
   // A last: the step's first FMA needs it, so its one s_waitcnt covers every read of the step
   if constexpr (TAIL && S >= 63) p.sm = *(const double __attribute__((address_space(3))) *)(x.seam + 8u * S);
   else p.sm = 0.0;
