@@ -227,8 +227,32 @@ def mixed_config(args) -> None:
         if timed:
           c["ev"].append((e0, e1))
 
-  for t in range(W):
+  def alone(t):
+    """One untimed round with the classes one after the other: a class's sweep kernel with the chip to itself."""
+    for c in classes:
+      torch.cuda.synchronize(dev)
+      c["ev"].clear()
+    for c in classes:
+      with torch.cuda.stream(c["stream"]):
+        env = c["env"]
+        si = env.make_step_in(env.current_simulation_timestamp)
+        a = (c["acts"][t], si, env._obs, env._reward, env._info)
+        env.sim.step(*a, phases=1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        env.sim.step(*a, phases=2)
+        e1.record()
+        env.sim.step(*a, phases=4)
+        env._prev_thermostat_ts = env._now
+        env._now = env._now + env._step_interval
+      torch.cuda.synchronize(dev)
+      c.setdefault("alone_ms", []).append(e0.elapsed_time(e1))
+
+  n_alone = min(3, W)
+  for t in range(W - n_alone):
     round_(t, False)
+  for t in range(W - n_alone, W):   # the last warm-up rounds double as the per-class measurement
+    alone(t)
   torch.cuda.synchronize(dev)
   t0 = time.perf_counter()
   for t in range(W, W + K):
@@ -245,8 +269,13 @@ def mixed_config(args) -> None:
     per_class[c["name"]] = {
         "grid": list(env.sim.plan.shape), "zones": env.sim.Z, "buildings": env.sim.B,
         "kernel": _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?"),
-        "sweep_kernel_ms": ms, "mean_sweeps_per_env_step": float(env.info[:, 4].mean()),
-        "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launch": li}
+        # in the timed rounds the classes' kernels overlap on their streams (a class also waits for CUs);
+        # `alone`: the same kernel with the chip to itself (the last warm-up rounds, one class after the other)
+        "sweep_kernel_ms": ms, "sweep_kernel_ms_alone": float(np.mean(c["alone_ms"])) if c.get("alone_ms") else None,
+        "mean_sweeps_per_env_step": float(env.info[:, 4].mean()),
+        "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "roofline_frac_alone": (alg / (float(np.mean(c["alone_ms"])) * 1e-3) / 1e9 / HBM_PEAK_GBPS) if c.get("alone_ms") else None,
+        "launch": li}
   zone_updates = sum(c["env"].sim.B * c["env"].sim.Z for c in classes) * K
   env_steps = sum(c["env"].sim.B for c in classes) * K
   achieved = alg_bytes / kern_s / 1e9
