@@ -208,11 +208,18 @@ void sb_destroy(sb_handle *h);
 int sb_get_launch_info(const sb_handle *h, sb_launch_info *out);
 
 /* Simulator.reset(): temp <- initial_temp (or `temps_dev` [B][H*W] float64), input_q <- 0,
- * devices <- constructor values.  Thermostat modes are NOT restored (vav.py:93-99). */
+ * devices <- constructor values: every VAV's damper 0.1 and reheat valve closed (vav.py:93-99).
+ * The Thermostat objects -- their modes and previous time stamps -- and the boiler's action time
+ * stamp are NOT restored (thermostat.py:66-69, smart_device.py:71-72): the clock rewinds under
+ * them, so the boiler's "time since my last action" is negative until the episode's first accepted
+ * action (boiler.py:158-217). */
 int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *stream);
 
 /* request_observations() at the current simulator time: writes obs_dev [B][O] fp32.
- * t_amb_dev: optional DEVICE [B] per-building ambient temperature (overrides t_amb). */
+ * t_amb_dev: optional DEVICE [B] per-building ambient temperature (overrides t_amb).
+ * Like the reference's, this read of the boiler's supply_water_temperature_sensor is not free of
+ * side effects (boiler.py:146-217): it becomes the action time stamp when there is none yet and
+ * advances the tank lag by the time since the last action.  Environment.reset() calls it once. */
 int sb_observe(sb_handle *h, const float aux[SB_NUM_AUX], double t_amb, const double *t_amb_dev,
                float *obs_dev, void *stream);
 /* ... with per-building num_occupants (DEVICE [B], see sb_step_in.num_occupants_dev) */

@@ -172,14 +172,16 @@ def obs_request(m, sb):
 
 
 def rollout_h2(m, sim, building, hvac, weather, schedule, n_steps, actions_norm, grid_steps,
-               label, extra_actions=(), rejected_steps=()):
+               label, extra_actions=(), rejected_steps=(), prev_ts=None):
   """Environment._step ordering without tf-agents (environment.py:1228-1309).
 
   extra_actions: more columns of the action vector after the SB1 pair, as (device_id,
   setpoint_name, (lo, hi)) -- actions_norm then has 2 + len(extra_actions) columns.
   rejected_steps: steps at which the building rejects the whole request (a RuntimeError out of
   request_action, rejection_simulator_building.py:52-60): Environment catches it, skips nothing
-  else, and returns reward -inf (environment.py:1266-1309)."""
+  else, and returns reward -inf (environment.py:1266-1309).
+  prev_ts: Thermostat._previous_timestamp as a previous episode on the same simulator left it
+  (it survives Simulator.reset(), thermostat.py:66-69); only the recorded comfort_prev uses it."""
   pb = m["smart_control_building_pb2"]
   cu = m["conversion_utils"]
   occ_cfg = SB1["occupancy"]
@@ -212,7 +214,6 @@ def rollout_h2(m, sim, building, hvac, weather, schedule, n_steps, actions_norm,
   # first observation at reset (environment.py:1165-1176)
   first = sb.request_observations(req)
   obs0 = np.array([r.continuous_value for r in first.single_observation_responses], np.float32)
-  prev_ts = None
   t0 = time.time()
   for step in range(n_steps):
     ts = sim.current_timestamp

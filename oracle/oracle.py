@@ -363,6 +363,11 @@ class OracleBuilding:
     lib().sbo_reset(self.plan.cptr(), C.byref(self._pc), C.byref(self._s),
                     self.initial_temp, rt)
 
+  def observe_boiler(self, obs_ts: float) -> None:
+    """One read of boiler.supply_water_temperature_sensor at ``obs_ts`` (boiler.py:146-217), e.g.
+    Environment.reset()'s first observation (environment.py:1165-1176)."""
+    lib().sbo_observe_boiler(C.byref(self._pc), C.byref(self._s), float(obs_ts))
+
   @property
   def state(self) -> _State:
     return self._s

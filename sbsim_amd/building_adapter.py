@@ -287,11 +287,13 @@ class HipSimulatorBuilding:
         r.additional_info = "the handle was not configured to drive this field (SimConfig.action_names)"
       else:
         v = _f32(single.continuous_value)
-        if dev.device_type == DeviceType.VAV and not 0.0 <= v <= 1.0:   # vav.py:125-129
+        # vav.py:125-129: the setter raises for `value < 0 or value > 1` (a NaN passes, as in the
+        # reference).  The value goes to the device either way: k_pre makes the same test, leaves the
+        # damper alone and returns the reward -inf (environment.py:1301-1302) for this building.
+        if dev.device_type == DeviceType.VAV and (v < 0.0 or v > 1.0):
           r.response_type = ActionResponseType.REJECTED_NOT_ENABLED_OR_AVAILABLE
           r.additional_info = "damper_setting must be in [0 ,1]"
-        else:
-          row[self._action_col[(single.device_id, single.setpoint_name)]] = v
+        row[self._action_col[(single.device_id, single.setpoint_name)]] = v
       resp.single_action_responses.append(r)
     self._actions[:] = torch.tensor(row, dtype=torch.float32, device=self._actions.device)
     self._all_accepted = all(r.response_type == ActionResponseType.ACCEPTED for r in resp.single_action_responses)

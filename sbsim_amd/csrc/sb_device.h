@@ -38,6 +38,14 @@ constexpr int kNScalOut = 16;        // scalars exported by sb_get_scalars
 constexpr int kNScal = 20;           // stored per building: + ring_lo, ring_hi (register path), 2 spare
 constexpr int kChunk = 8;            // sweep steps per software-pipelined chunk
 constexpr int kPad = 8;              // doubles (bytes for cls) of padding around each grid in HBM
+// scal[19] = (last observation - boiler action time stamp) / dt.  It goes negative when an episode
+// reset rewinds the clock under a surviving time stamp (smart_device.py:71-72), so "no time stamp
+// yet" is a sentinel far below any age.
+constexpr double kAgeNone = -1e300;
+__host__ __device__ inline bool age_is_none(double age) { return age < -1e200; }
+// mode[b][z]: bits 0..7 the thermostat mode (survives Simulator.reset()), bit 8 the VAV's reheat
+// valve (Vav.reset() closes it, vav.py:93-99; a rejected step leaves it alone)
+constexpr int kModeMask = 0xff, kValveBit = 0x100;
 
 // Everything a kernel needs, passed by value.
 struct Dev {
@@ -299,6 +307,25 @@ struct Bld {
   double action_age; // steps since the boiler's last accepted action (-> scal[19])
 };
 
+// boiler.py:158-217: one read of supply_water_temperature_sensor outside a step (Environment.reset()'s
+// observation, environment.py:1165-1176; sb_observe) stamps the observation, turns it into the action
+// time stamp when there is none, and advances the tank lag by the duration since the action.
+__device__ inline void observe_boiler(const Dev &a, double *S) {
+  const sb_params &p = a.p;
+  if (age_is_none(S[19])) S[19] = 0.0;
+  else S[10] = S[19] * p.dt;
+  if (p.blr_cooling_rate > 0.0 && p.blr_heating_rate > 0.0) {
+    const double begin = S[8], sp = S[4];
+    double cur = sp;
+    if (sp > begin) cur = fmin(begin + p.blr_heating_rate * S[10] / 60.0, sp);
+    else if (sp < begin) cur = fmax(begin - p.blr_cooling_rate * S[10] / 60.0, sp);
+    S[8] = cur;
+    S[9] = cur - begin;
+  } else {
+    S[8] = S[4];
+  }
+}
+
 // k_pre, one thread per building.  request_action: setup_step_sim (thermostats on the stored
 // zone means), then the agent's setpoints; execute_step_sim: the AHU supply temperature, the
 // per-building table g[class] = gc*T_amb + sc*q_zone (q of the PREVIOUS step feeds this sweep),
@@ -389,18 +416,21 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   int ahu_count = 0, blr_count = 0;
   for (int z = 0; z < a.Z; ++z) {
     const double tz = a.zmean[zb + z];  // pre-update zone mean (vav.zone_air_temperature)
-    int mode = a.mode[zb + z];          // thermostat.py:114-148
+    const int mraw = a.mode[zb + z];
+    int mode = mraw & kModeMask;        // thermostat.py:114-148
+    bool valve_open = (mraw & kValveBit) != 0;
     if (!rejected) {
       if (in.comfort_now) mode = default_control(mode, tz, hsp, csp);
       else if (comfort_prev == 1) mode = 3;
       else if (!(mode == 3 && tz > hsp)) mode = default_control(mode, tz, hsp, csp);
-      a.mode[zb + z] = mode;
+      valve_open = mode == 1;           // vav.py:229-243: update_settings writes damper and valve
+      a.mode[zb + z] = mode | (valve_open ? kValveBit : 0);
     }
-    double damper = (mode == 1 || mode == 2) ? 1.0 : 0.1; // vav.py:229-243
+    double damper = (mode == 1 || mode == 2) ? 1.0 : 0.1;
     if (rejected) damper = a.damper[zb + z];                // nobody touched the VAV: what it had
     for (int i = 0; i < p.n_actions; ++i)                   // set_action after update_settings
       if ((damper_set >> i & 1u) && p.act_zone[i] == z) damper = damper_cmd[i];
-    const double valve = mode == 1 ? 1.0 : 0.0;
+    const double valve = valve_open ? 1.0 : 0.0;
     const double reheat = valve * p.vav_max_water_flow;
     const double air = damper * p.vav_max_air_flow;
     const double heat_diff = kCAir * air - kCWater * reheat;     // vav.py:181-195
@@ -426,13 +456,14 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   // boiler.py:158-168 at this step's observation (Environment: one per step): with an action time stamp
   // (smart_device.py:193; a rejected request leaves the old one) the duration is observation_ts -
   // action_ts; without one the first observation becomes it and the duration keeps its value.
-  // scal[19]: (last observation - action time stamp) / dt, -1 = no action time stamp yet.
+  // scal[19]: (last observation - action time stamp) / dt, kAgeNone = no action time stamp yet.
   double age = S[19];
   if (in.has_action) {
+    const bool none = age_is_none(age);
     if (boiler_action) age = 1.0;
-    else if (age < 0.0) age = 0.0;
+    else if (none) age = 0.0;
     else age += 1.0;
-    if (boiler_action || S[19] >= 0.0) v.duration = age * p.dt;
+    if (boiler_action || !none) v.duration = age * p.dt;
   }
   v.action_age = age;
   v.comfort_seen = rejected ? (int)S[18] : in.comfort_now;

@@ -81,6 +81,7 @@ struct sb_handle {
   sb::Dev d{};
   int device = 0, cus = 256;
   bool was_reset = false; // the first sb_reset also sets the construction-time device state
+  int steps_since_reset = 0; // how far a reset rewinds the clock (the boiler's action age, scal[19])
   sb_launch_info info{};
   DevBuf<uint8_t> cls, tcls, tcset;
   DevBuf<double> ctab, csetab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum,

@@ -27,7 +27,7 @@ constexpr int kGuardHost = 16; // must match kGuard in step_lds.hip
 
 // ---------------------------------------------------------------- kernels
 // Simulator.reset(): grid (either state layout), zone means, device scalars.
-__global__ void k_reset(Dev a, double initial_temp, const double *temps, int first) {
+__global__ void k_reset(Dev a, double initial_temp, const double *temps, int first, int steps_since_reset) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -73,6 +73,7 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps, int fir
         a.zmean[o] = zs / (double)(b1 - b0);
         a.zair[o] = 0.0;   // vav.py:93-99
         a.damper[o] = 0.1;
+        a.mode[o] &= kModeMask; // ... the reheat valve closes; the thermostat keeps its mode
         a.qz[o] = 0.0;     // building.py:791 input_q <- 0
       }
     }
@@ -87,7 +88,9 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps, int fir
       S[17] = a.reg && a.n_ring > 0 ? rhi : 0.0;
       // Thermostat._previous_timestamp and SmartDevice._action_timestamp are construction state:
       // Simulator.reset() leaves them alone (thermostat.py:66-69, smart_device.py:71-72)
-      if (first) { S[18] = -1.0; S[19] = -1.0; }
+      // ... but the clock rewinds under them: the boiler's age of its last action goes negative
+      if (first) { S[18] = -1.0; S[19] = kAgeNone; }
+      else if (!age_is_none(S[19])) S[19] -= (double)steps_since_reset;
     }
   }
 }
@@ -96,8 +99,18 @@ __global__ void k_observe(Dev a, float *obs, float aux0, float aux1, float aux2,
                           float aux4, float aux5, float aux6, double t_amb, const double *t_amb_b,
                           const float *num_occupants, double occ_norm) {
   const float aux[SB_NUM_AUX] = {aux0, aux1, aux2, aux3, aux4, aux5, aux6};
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
-    write_obs(a, b, obs, aux, t_amb_b ? t_amb_b[b] : t_amb, a.scal + (size_t)b * kNScal, num_occupants, occ_norm);
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x) {
+    double *S = a.scal + (size_t)b * kNScal;
+    observe_boiler(a, S);
+    write_obs(a, b, obs, aux, t_amb_b ? t_amb_b[b] : t_amb, S, num_occupants, occ_norm);
+  }
+}
+
+// Thermostat modes without the valve bit.
+__global__ void k_copy_modes(Dev a, int32_t *out) {
+  const size_t n = (size_t)a.B * a.Z;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = a.mode[i] & kModeMask;
 }
 
 // building.temp in the caller's row-major layout, whichever state layout the handle uses.
@@ -129,13 +142,22 @@ __global__ void k_copy_scalars(Dev a, double *out) {
 }
 
 // Per-building algebra before / after the sweep kernel: one thread per building (sb_device.h).
-__global__ void __launch_bounds__(64) k_pre(Dev a, StepArgs s) {
+// only >= 0: that building alone (the known-answer taps).
+__global__ void __launch_bounds__(64) k_pre(Dev a, StepArgs s, int only) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_b = 0; // the sweep kernel's draw counter
+  if (only >= 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) pre_building(a, s, only);
+    return;
+  }
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
     pre_building(a, s, b);
 }
 
-__global__ void __launch_bounds__(64) k_post(Dev a, StepArgs s) {
+__global__ void __launch_bounds__(64) k_post(Dev a, StepArgs s, int only) {
+  if (only >= 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) post_building(a, s, only);
+    return;
+  }
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
     post_building(a, s, b);
 }
@@ -869,8 +891,9 @@ int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *s
   const int wpb = 4;
   const int blocks = std::min((h->d.B + wpb - 1) / wpb, 4096);
   hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(64 * wpb), 0, (hipStream_t)stream, h->d, initial_temp,
-                     temps_dev, h->was_reset ? 0 : 1);
+                     temps_dev, h->was_reset ? 0 : 1, h->steps_since_reset);
   h->was_reset = true;
+  h->steps_since_reset = 0;
   SB_HIP(hipGetLastError());
   return SB_OK;
 }
@@ -902,7 +925,7 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   const Dev &d = h->d;
   const int blocks = std::max(1, std::min((d.B + 63) / 64, h->cus * 16)); // one thread per building
   if (phases & SB_PHASE_PRE) {
-    hipLaunchKernelGGL(k_pre, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s);
+    hipLaunchKernelGGL(k_pre, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s, -1);
     SB_HIP(hipGetLastError());
   }
   if (phases & SB_PHASE_SWEEP) {
@@ -921,7 +944,8 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
       const int rc = sb_launch_convection(h, (hipStream_t)stream); // k_post do not change (values move inside rooms)
       if (rc != SB_OK) return rc;
     }
-    hipLaunchKernelGGL(k_post, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s);
+    hipLaunchKernelGGL(k_post, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s, -1);
+    ++h->steps_since_reset;
     SB_HIP(hipGetLastError());
   }
   return SB_OK;
@@ -958,7 +982,13 @@ int sb_get_scalars(sb_handle *h, double *out_dev, void *stream) {
     return SB_OK;                                                                                 \
   }
 SB_COPY_OUT(sb_get_zone_temps, h->d.zmean, (size_t)h->d.B *h->d.Z, double)
-SB_COPY_OUT(sb_get_modes, h->d.mode, (size_t)h->d.B *h->d.Z, int32_t)
+int sb_get_modes(sb_handle *h, int32_t *out_dev, void *stream) {
+  if (!h || !out_dev) return fail(SB_ERR_INVALID, "sb_get_modes: null argument");
+  SB_ON_DEVICE(h->device);
+  hipLaunchKernelGGL(k_copy_modes, dim3(256), dim3(256), 0, (hipStream_t)stream, h->d, out_dev);
+  SB_HIP(hipGetLastError());
+  return SB_OK;
+}
 SB_COPY_OUT(sb_get_zone_power, h->d.qz, (size_t)h->d.B *h->d.Z, double)
 
 /* ---- known-answer taps: k_pre / k_post on prescribed state of one building ---- */
@@ -985,8 +1015,7 @@ int sb_tap_pre(sb_handle *h, int32_t building, const double *zone_temps, const i
   }
   StepArgs s{};
   s.actions = act.p; s.in = *in;
-  const int blocks = std::max(1, std::min((d.B + 63) / 64, h->cus * 16));
-  hipLaunchKernelGGL(k_pre, dim3(blocks), dim3(64), 0, nullptr, d, s);
+  hipLaunchKernelGGL(k_pre, dim3(1), dim3(64), 0, nullptr, d, s, building); // this building alone
   SB_HIP(hipGetLastError());
   SB_HIP(hipDeviceSynchronize());
   if (bld) {
@@ -997,7 +1026,10 @@ int sb_tap_pre(sb_handle *h, int32_t building, const double *zone_temps, const i
   }
   if (q_zone) SB_HIP(hipMemcpy(q_zone, d.qz + zb, sizeof(double) * d.Z, hipMemcpyDeviceToHost));
   if (damper) SB_HIP(hipMemcpy(damper, d.damper + zb, sizeof(double) * d.Z, hipMemcpyDeviceToHost));
-  if (modes_out) SB_HIP(hipMemcpy(modes_out, d.mode + zb, sizeof(int32_t) * d.Z, hipMemcpyDeviceToHost));
+  if (modes_out) {
+    SB_HIP(hipMemcpy(modes_out, d.mode + zb, sizeof(int32_t) * d.Z, hipMemcpyDeviceToHost));
+    for (int z = 0; z < d.Z; ++z) modes_out[z] &= kModeMask;
+  }
   return SB_OK;
 }
 
@@ -1028,8 +1060,7 @@ int sb_tap_post(sb_handle *h, int32_t building, const sb_tap_bld *bld, const dou
   if (rc != SB_OK) return rc;
   StepArgs s{};
   s.reward = rew.p; s.info = inf.p; s.in = *in;
-  const int blocks = std::max(1, std::min((d.B + 63) / 64, h->cus * 16));
-  hipLaunchKernelGGL(k_post, dim3(blocks), dim3(64), 0, nullptr, d, s);
+  hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, nullptr, d, s, building); // this building alone
   SB_HIP(hipGetLastError());
   SB_HIP(hipDeviceSynchronize());
   SB_HIP(hipMemcpy(reward, rew.p + building, sizeof(float), hipMemcpyDeviceToHost));

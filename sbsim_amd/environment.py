@@ -643,6 +643,12 @@ class BatchedEnvironment:
         raise ValueError(f"rejected must be a [{self.batch_size}] tensor on {self.sim.tdev}")
       self._rejected = rejected.to(torch.uint8).contiguous()
       si.reject_dev = self._rejected.data_ptr()
+    elif getattr(self, "_rejected", None) is not None:
+      # once buildings may skip thermostat updates, "the previous update" stays per building on the
+      # device (scal[18]): the host's comfort_prev assumes every building updated at the last step
+      if getattr(self, "_no_reject", None) is None:
+        self._no_reject = torch.zeros((self.batch_size,), dtype=torch.uint8, device=self.sim.tdev)
+      si.reject_dev = self._no_reject.data_ptr()
     self.sim.step(action, si, self._obs, self._reward, self._info)
     self._prev_thermostat_ts = self._now
     self._now = self._now + self._step_interval
