@@ -36,9 +36,10 @@ __device__ __forceinline__ double dpp_zero(double x) {
 template <int S, int NS>
 __device__ __forceinline__ bool lanes_at_seam() { // lanes l with l == S (mod NS): a 64-bit literal in SGPRs
   constexpr unsigned long long m = (1ull << (S % NS)) | ((S % NS) + NS < 64 ? 1ull << ((S % NS) + NS) : 0ull);
-  unsigned long long v;
-  asm volatile("s_mov_b64 %0, %1" : "=s"(v) : "n"(m));
-  return __builtin_amdgcn_inverse_ballot_w64(v);
+  unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+  asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((unsigned)m));
+  if (hi) asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((unsigned)(m >> 32)));
+  return __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
 }
 
 struct Ctx {
