@@ -180,7 +180,8 @@ typedef enum sb_sweep_kernel {
   SB_KERNEL_REG = 1,      /* k_sweep_reg mode 1: one wavefront, <= 64 rows (step_reg.hip) */
   SB_KERNEL_REG_PAIR = 2, /* k_sweep_reg mode 2: two wavefronts, <= 128 rows */
   SB_KERNEL_ROLL = 3,     /* k_sweep_roll: one wavefront + tail rows, overlapped sweeps (step_roll.hip) */
-  SB_KERNEL_TWO_ROWS = 4  /* k_sweep_two: two rows per lane, 67..130 rows, sweeps overlapped in blocks (step_two.hip) */
+  SB_KERNEL_TWO_ROWS = 4, /* k_sweep_two: two rows per lane, 67..130 rows, sweeps overlapped in blocks (step_two.hip) */
+  SB_KERNEL_BAND = 5      /* k_sweep_band: two wavefronts, one row per lane, 67..130 rows, sweeps overlapped in blocks (step_band.hip) */
 } sb_sweep_kernel;
 
 /* Launch geometry chosen for the floor plan (reported for DESIGN.md / bench.py). */

@@ -295,6 +295,113 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
   return true;
 }
 
+// Mode 5 (step_band.hip): two wavefronts per building, one row per lane (rows 0..63 / 64..127) + at
+// most two tail rows, up to 80 columns inside the exterior ring; sweeps overlapped in predicted blocks.
+bool plan_band(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const std::vector<int> &zone_of, RegPlan &r) {
+  const int W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = plan->H * plan->W;
+  auto coef = [&](int c, int j) { return plan->class_coef[c * 8 + j]; };
+  int NR = 0;
+  for (int s : {76, 80})
+    if (!NR && s >= Ws && sweep_band_supported(s)) NR = s;
+  if (!NR || Hs <= 64 || Hs > 128 + 2) return false;
+  const int T = std::max(0, Hs - 128), Hw = Hs - T;
+  for (int x = x0 + Hw; x < x0 + Hs; ++x)
+    for (int y = y0; y < y0 + Ws; ++y)
+      if (zone_of[x * W + y] >= 0) return false; // the tail scan adds no zone sums
+  int ts = 32;
+  while (ts < ncls + 1) ts *= 2;
+  if (ts > 256) return false;
+  const int pad = ncls;
+  std::vector<int> set_of(ncls + 1, 0);
+  r.csetab.clear();
+  for (int c = 0; c < ncls; ++c) {
+    int found = -1;
+    for (size_t k = 0; k < r.csetab.size() / 4 && found < 0; ++k)
+      if (r.csetab[4 * k] == coef(c, 0) && r.csetab[4 * k + 1] == coef(c, 1) && r.csetab[4 * k + 2] == coef(c, 2) &&
+          r.csetab[4 * k + 3] == coef(c, 3)) found = (int)k;
+    if (found < 0) {
+      found = (int)r.csetab.size() / 4;
+      for (int j = 0; j < 4; ++j) r.csetab.push_back(coef(c, j));
+    }
+    set_of[c] = found;
+  }
+  set_of[pad] = (int)r.csetab.size() / 4; // the pad set: no neighbour counts
+  for (int j = 0; j < 4; ++j) r.csetab.push_back(0.0);
+  if ((int)r.csetab.size() / 4 > sweep_band_set_table()) { r.csetab.clear(); return false; }
+
+  const int AS = sweep_band_lds_slots(NR), ZRS = 65;
+  if ((Z + 1) * ZRS > 65535) { r.csetab.clear(); return false; }
+  int off = 4 * sweep_band_set_table() + 2 * ts;
+  r.r_seam = off; off += sweep_band_seam_doubles(NR);
+  r.r_xchg = off; off += sweep_band_sync_doubles();
+  off = (off + 1) & ~1;
+  r.r_A = off; off += std::max(2 * 64 * AS, (Z + 1) * ZRS); // the zone-sum scratch aliases A
+  r.AS = AS;
+  r.lds_bytes = off * 8;
+  if (const char *padb = getenv("SBSIM_DEBUG_LDS_PAD")) r.lds_bytes += atoi(padb);
+  r.wg_per_cu = std::min(2, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule)); // two wavefronts each, one per SIMD
+  if (r.wg_per_cu < 1) { r.csetab.clear(); return false; }
+
+  r.NR = NR; r.P = 5; r.RS = 128; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
+  r.T = T; r.ts = ts;
+  r.state_doubles = NR * 128 + T * NR;
+  r.lw[0] = 64; r.lw[1] = Hw - 64; r.l0[0] = r.l0[1] = 0; r.rowbase[0] = 0; r.rowbase[1] = 64;
+  r.nch[0] = r.nch[1] = 0; r.lag = 0; r.nslots = 0;
+  r.steps = NR + 4 * T;
+  auto cell_class = [&](int R, int col) { // trimmed coordinates
+    return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? (int)plan->cell_class[(x0 + R) * W + (y0 + col)] : pad;
+  };
+  const int NW = NR + 63, NWD = NR / 4;
+  std::vector<uint32_t> cw((size_t)2 * NW * 64, 0);
+  r.amapS.assign((size_t)2 * NWD * 64, 0);
+  r.zmapS.assign((size_t)2 * NWD * 64, 0);
+  r.tcls.assign((size_t)std::max(T, 1) * NR, (uint8_t)pad);
+  r.tcset.assign((size_t)std::max(T, 1) * NR, (uint8_t)(8 * set_of[pad]));
+  for (int t = 0; t < T; ++t)
+    for (int c = 0; c < NR; ++c) {
+      r.tcls[(size_t)t * NR + c] = (uint8_t)cell_class(Hw + t, c);
+      r.tcset[(size_t)t * NR + c] = (uint8_t)(8 * set_of[cell_class(Hw + t, c)]);
+    }
+  for (int w = 0; w < 2; ++w)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int R = 64 * w + lane;
+      const bool valid = R < Hw;
+      for (int st = 0; st < NW; ++st) { // one word per step: the set offset of the lane's cell
+        int col = st - lane;
+        if (col >= NR) col -= NR; // rolling periods: the lane is in its next sweep
+        const int c = (valid && col >= 0) ? cell_class(R, col) : pad;
+        cw[((size_t)w * NW + st) * 64 + lane] = (uint32_t)(set_of[c] * 32);
+      }
+      for (int g = 0; g < NWD; ++g) {
+        unsigned long long aword = 0, zword = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int j = 4 * g + k, col = ((j - lane) % NR + NR) % NR;
+          const bool cell = valid && col < Ws;
+          aword |= (unsigned long long)((cell ? cell_class(R, col) : pad) * 16) << (16 * k);
+          int z = Z; // dump row
+          if (cell && zone_of[(x0 + R) * W + (y0 + col)] >= 0) z = zone_of[(x0 + R) * W + (y0 + col)];
+          zword |= (unsigned long long)(z * ZRS + lane) << (16 * k);
+        }
+        r.amapS[((size_t)w * NWD + g) * 64 + lane] = aword;
+        r.zmapS[((size_t)w * NWD + g) * 64 + lane] = zword;
+      }
+    }
+  r.cmapS.assign((cw.size() + 1) / 2, 0);
+  std::memcpy(r.cmapS.data(), cw.data(), cw.size() * sizeof(uint32_t));
+  r.cell_state.assign(N, 0);
+  int ring = 0;
+  for (int x = 0; x < plan->H; ++x)
+    for (int y = 0; y < W; ++y) {
+      const int R = x - x0, col = y - y0;
+      if (R < 0 || R >= Hs || col < 0 || col >= Ws) { r.cell_state[x * W + y] = -(++ring); continue; }
+      if (R >= Hw) { r.cell_state[x * W + y] = NR * 128 + (R - Hw) * NR + col; continue; }
+      const int slot = (col + (R & 63)) % NR;
+      r.cell_state[x * W + y] = (slot / 2) * 256 + R * 2 + (slot & 1); // state layout [NR / 2][128][2]
+    }
+  r.ok = true;
+  return true;
+}
+
 // lds_per_cu: buildings per CU the LDS-grid kernel would hold (0: the plan does not fit it).
 void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   const int H = plan->H, W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = H * W;
@@ -321,6 +428,8 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   std::vector<int> zone_of(N, -1);
   for (int z = 0; z < Z; ++z)
     for (int i = plan->zone_off[z]; i < plan->zone_off[z + 1]; ++i) zone_of[plan->zone_cells[i]] = z;
+  // mode 5: two wavefronts, one row per lane, sweeps overlapped in blocks (67..130 rows, <= 80 columns)
+  if (Hs > 64 + 2 && !env_flag("SBSIM_NO_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   // mode 4: one wavefront, two rows per lane (67..130 rows, <= 80 columns)
   if (Hs > 64 + 2 && !env_flag("SBSIM_NO_TWO_ROW_PATH") && plan_two(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   auto pick_slots = [&](int mode) { // narrowest instantiation that holds the width and the class count
@@ -590,9 +699,9 @@ void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan 
   const int64_t rest = (8 * 4 + 4 * 2) * Z + 16ll * kNScalOut + 4ll * n_actions + 4ll * n_obs + 4;
   if (r.ok) {
     out->path = 1;
-    out->waves_per_building = r.P == 2 ? 2 : 1;
-    out->kernel = r.P; // sb_sweep_kernel: modes 1..4 are SB_KERNEL_REG .. SB_KERNEL_TWO_ROWS
-    out->waves_per_workgroup = r.P == 2 ? 2 : 1;
+    out->waves_per_building = (r.P == 2 || r.P == 5) ? 2 : 1;
+    out->kernel = r.P; // sb_sweep_kernel: modes 1..5 are SB_KERNEL_REG .. SB_KERNEL_BAND
+    out->waves_per_workgroup = (r.P == 2 || r.P == 5) ? 2 : 1;
     out->workgroups = std::max(1, std::min(n_buildings, cus * r.wg_per_cu));
     out->lds_bytes_per_workgroup = r.lds_bytes;
     out->sweep_steps = r.steps;
@@ -714,7 +823,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.pred_haste = 1.0f; d.pred_slack = 1.0f; // measured (tools/bench_two_rows.py); developer knobs: speed only,
     if (const char *e = getenv("SBSIM_DEBUG_PRED_HASTE")) d.pred_haste = (float)atof(e); // never the result
     if (const char *e = getenv("SBSIM_DEBUG_PRED_SLACK")) d.pred_slack = (float)atof(e);
-    d.pred_first = 3;
+    d.pred_first = r.P == 5 ? 4 : 3; // step_band.hip decides one sweep later: one more period unseen
     if (const char *e = getenv("SBSIM_DEBUG_PRED_FIRST")) d.pred_first = std::max(1, atoi(e));
     SB_TRY(upload(h->zone_cells_l, plan->zone_cells, (size_t)plan->zone_off[plan->Z]));
     SB_TRY(upload(h->cmapS, r.cmapS.data(), r.cmapS.size()));
@@ -858,7 +967,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     if (alloc_zero(h->dbg, 16) == SB_OK) d.dbg = h->dbg.p;
   }
 
-  const int e = d.reg ? (d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
+  const int e = d.reg ? (d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
                       : prepare_sweep_lds((size_t)h->info.lds_bytes_per_workgroup);
   if (e != (int)hipSuccess) {
     delete h;
@@ -931,7 +1040,8 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   if (phases & SB_PHASE_SWEEP) {
     if (!(phases & SB_PHASE_PRE)) // k_pre zeroes the sweep kernel's draw counter; without it in this call:
       SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream));
-    const int e = d.reg ? (d.P == 4   ? launch_sweep_two(d, (hipStream_t)stream)
+    const int e = d.reg ? (d.P == 5   ? launch_sweep_band(d, (hipStream_t)stream)
+                       : d.P == 4 ? launch_sweep_two(d, (hipStream_t)stream)
                        : d.P == 3 ? launch_sweep_roll(d, (hipStream_t)stream)
                                   : launch_sweep_reg(d, h->cus, (hipStream_t)stream))
                         : launch_sweep_lds(d, h->info.workgroups, h->info.waves_per_workgroup,

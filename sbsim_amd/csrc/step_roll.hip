@@ -308,11 +308,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   // next one from a device counter (zeroed before every launch).
   int iter = 0;
   for (int b = blockIdx.x, bn = 0; b < a.B; b = bn, ++iter) {
-    {
-      int nb = 0;
-      if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
-      bn = __builtin_amdgcn_readfirstlane(nb);
-    }
+    // the draw of the NEXT building: issued here, read before the hand-over (an atomic's round trip
+    // to L2 is 1-2 us: the sweeps hide it)
+    int nb = 0;
+    if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
     SB_STAMP(0);
     unsigned long long amapw[kASlots]; // issued here, used by the A pass: the setup hides the latency
     {
@@ -452,6 +451,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(3);
+    bn = __builtin_amdgcn_readfirstlane(nb);
     SB_STAMP(4);
 
     // grid back to HBM.  Zone sums (A is dead now): every lane adds its cells into its own

@@ -302,13 +302,14 @@ class BatchedSimulator:
 
     # device-side orientation (internal to the library; reset()/temps() convert, so callers
     # always see the reference's [H, W] layout): the library reports, per orientation, which
-    # step kernel it would use and how many wavefront steps one sweep takes
+    # step kernel it would use, how many wavefront steps one sweep takes and on how many wavefronts
     cands = {"rows": [False], "columns": [True], "auto": [False, True]}[orientation]
     best = None
     for tr in cands:
       cand = describe(plan.transposed() if tr else plan)
       rc, info = cand[3]
-      key = (rc != 0, -info.path if rc == 0 else 0, info.sweep_steps if rc == 0 else 0)
+      # SIMD steps per building-sweep: a kernel that spreads a building over two wavefronts holds half as many
+      key = (rc != 0, -info.path if rc == 0 else 0, info.sweep_steps * max(info.waves_per_building, 1) if rc == 0 else 0)
       if best is None or key < best[0]:
         best = (key, tr, cand)
     self.transposed = best[1]

@@ -56,7 +56,7 @@ def _step_in(g, t, has_action=True, occupancy=None):
 
 
 @pytest.mark.parametrize("tag,kernel", [("random", "reg"), ("const", "reg-pair"), ("const", "lds"),
-                                        ("random", "lds-columns"), ("random", "reg-two")])
+                                        ("random", "lds-columns"), ("random", "reg-two"), ("random", "reg-band")])
 def test_one_day_rollout_against_reference_golden(tag, kernel, monkeypatch):
   """BASELINE.json configs[0] semantics on the GPU: SB1 physics on R9, 288 steps."""
   _need_gpu()
@@ -67,18 +67,22 @@ def test_one_day_rollout_against_reference_golden(tag, kernel, monkeypatch):
   # lanes, two wavefronts per building exchanging their seam rows through LDS; "lds": rows as
   # lanes on the LDS-grid kernel (two bands + seam); "lds-columns": the LDS-grid kernel on the
   # transposed grid; "reg-two": columns as lanes, one wavefront, two columns per lane, sweeps
-  # overlapped in predicted blocks (step_two.hip).  All five wavefront schedules are checked
+  # overlapped in predicted blocks (step_two.hip); "reg-band": columns as lanes, two wavefronts (64 + 32
+  # columns), sweeps overlapped in predicted blocks (step_band.hip).  All six wavefront schedules are checked
   # against the reference.
   if kernel.startswith("lds"):
     monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
   if kernel == "reg-pair":
-    monkeypatch.setenv("SBSIM_NO_TWO_ROW_PATH", "1")   # the library's own choice for 96 x 66 is "reg-two"
+    monkeypatch.setenv("SBSIM_NO_TWO_ROW_PATH", "1")   # the library's own choice for 96 x 66 is "reg-band", then "reg-two"
+  if kernel in ("reg-pair", "reg-two"):
+    monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
   sim = BatchedSimulator(_plan(load("plan_r9_sb1.npz")), SimConfig.sb1(), B, float(g["h_conv"]),
                          orientation={"reg": "auto", "reg-pair": "columns", "lds": "rows",
-                                      "lds-columns": "columns", "reg-two": "columns"}[kernel])
-  assert sim.transposed == (kernel in ("reg-pair", "lds-columns", "reg-two"))
+                                      "lds-columns": "columns", "reg-two": "columns", "reg-band": "columns"}[kernel])
+  assert sim.transposed == (kernel in ("reg-pair", "lds-columns", "reg-two", "reg-band"))
+  assert sim.launch_info["kernel"] == {"reg": 3, "reg-pair": 2, "lds": 0, "lds-columns": 0, "reg-two": 4, "reg-band": 5}[kernel]
   assert sim.launch_info["path"] == (1 if kernel.startswith("reg") else 0)
-  assert sim.launch_info["waves_per_building"] == (2 if kernel == "reg-pair" else 1)
+  assert sim.launch_info["waves_per_building"] == (2 if kernel in ("reg-pair", "reg-band") else 1)
   sim.reset()
   obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
   rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
@@ -604,42 +608,63 @@ def _oracle_twin(plan, cfg, init_flat):
     ((2, 3), (30, 30), "rows", 1),     # 65x96 -> registers, 1 wave + ONE tail row
     ((4, 5), (10, 8), "rows", 1),      # 47x48, 20 zones -> registers, zone reduce in two 16-zone passes
     ((4, 2), (30, 17), "columns", 0),  # the same family on the LDS-grid kernel, lanes = columns
-    ((8, 5), (12, 14), "auto", 1),     # "SB2-synth" 107x78 inside the ring -> registers, two rows per lane (54 lanes, the last with one row), 80 slots
-    ((14, 9), (8, 7), "auto", 1),      # "SB1-synth" 129x75, 137 cell classes -> two rows per lane + ONE tail row, 76 slots
-    ((5, 3), (24, 24), "rows", 1),     # 128x78: two rows per lane, all 64 lanes, no tail row
-    ((4, 4), (15, 17), "rows", 1),     # 67x75: two rows per lane, 34 lanes (the sweep ends early)
-    ((14, 7), (8, 10), "rows", 1),     # 129x80: two rows per lane, 80 slots + ONE tail row
+    # 67..130 rows, <= 80 columns: step_band.hip (path 5: two wavefronts, one row per lane) is the library's
+    # choice; step_two.hip (path 4: one wavefront, two rows per lane) stays behind SBSIM_NO_BAND_PATH
+    ((8, 5), (12, 14), "auto", 5),     # "SB2-synth" 107x78 inside the ring: 64 + 43 rows, 80 slots
+    ((14, 9), (8, 7), "auto", 5),      # "SB1-synth" 129x75, 137 cell classes: 64 + 64 rows + ONE tail row, 76 slots
+    ((5, 3), (24, 24), "rows", 5),     # 128x78: 64 + 64 rows, no tail row
+    ((4, 4), (15, 17), "rows", 5),     # 67x75: 64 + 3 rows (wavefront 1's sweep ends early)
+    ((14, 7), (8, 10), "rows", 5),     # 129x80: 80 slots + ONE tail row
+    ((8, 5), (12, 14), "auto", 4),     # "SB2-synth": two rows per lane (54 lanes, the last with one row), 80 slots
+    ((14, 9), (8, 7), "auto", 4),      # "SB1-synth": two rows per lane + ONE tail row, 76 slots
+    ((5, 3), (24, 24), "rows", 4),     # 128x78: two rows per lane, all 64 lanes, no tail row
+    ((4, 4), (15, 17), "rows", 4),     # 67x75: two rows per lane, 34 lanes (the sweep ends early)
+    ((14, 7), (8, 10), "rows", 4),     # 129x80: two rows per lane, 80 slots + ONE tail row
 ])
 def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, monkeypatch):
   """BASELINE.json configs[2] semantics: other floor-plan classes (different H x W and zone
-  counts) through the same C ABI, each checked against its CPU-oracle twin."""
+  counts) through the same C ABI, each checked against its CPU-oracle twin.  path: 0 the LDS-grid
+  kernel, 1 the library's choice among the register kernels, 4 / 5 that kernel (sb_sweep_kernel)."""
   from sbsim_amd.floorplan import rectangular_floor_plan
-  _check_plan_against_oracle(rectangular_floor_plan(rooms, room_shape), rooms[0] * rooms[1], orientation, path, monkeypatch)
+  kern = None
+  if path >= 4:
+    kern, path = path, 1
+    if kern == 4:
+      monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
+  _check_plan_against_oracle(rectangular_floor_plan(rooms, room_shape), rooms[0] * rooms[1], orientation, path, monkeypatch,
+                             expect_kernel=kern)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("haste,slack", [(1.0, 1.0), (1.0, 0.0)])
-def test_two_rows_kernel_tail_rows_and_overrun_blocks(haste, slack, monkeypatch):
-  """step_two.hip: a 130-row plan (SB1-synth with a 3-CV wall at the bottom: TWO tail rows), and the
-  prediction switched off (slack 0: every period rolls, so every step runs past its last sweep and
-  is run again from the stored grid) -- sweep counts and temperatures must not notice."""
+@pytest.mark.parametrize("kern", [5, 4])
+@pytest.mark.parametrize("haste,slack", [(1.0, 1.0), (1.0, 0.0), (1.0, -100.0)])
+def test_block_kernels_tail_rows_and_overrun_blocks(haste, slack, kern, monkeypatch):
+  """step_band.hip / step_two.hip: a 130-row plan (SB1-synth with a 3-CV wall at the bottom: TWO tail
+  rows), and the prediction switched off (slack 0 / -100: every period rolls, so every step runs past
+  its last sweep and is run again from the stored grid) -- sweep counts and temperatures must not notice."""
   from sbsim_amd.floorplan import rectangular_floor_plan
   fp = rectangular_floor_plan((14, 9), (8, 7))
   fp = np.insert(fp, fp.shape[0] - 2, fp[-2], axis=0)
   assert fp.shape == (132, 77)
   monkeypatch.setenv("SBSIM_DEBUG_PRED_HASTE", str(haste))
   monkeypatch.setenv("SBSIM_DEBUG_PRED_SLACK", str(slack))
-  _check_plan_against_oracle(fp, 126, "rows", 1, monkeypatch, expect_steps=76 + 64 - 1 + 8)
+  if kern == 4:
+    monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
+  _check_plan_against_oracle(fp, 126, "rows", 1, monkeypatch, expect_steps=76 + 64 - 1 + 8 if kern == 4 else 76 + 8,
+                             expect_kernel=kern)
 
 
-@pytest.mark.parametrize("limit", [1, 3, 7, 12])
-def test_two_rows_kernel_iteration_limit(limit, monkeypatch):
-  """simulator.py:348-368 with a limit that bites on the two-rows-per-lane kernel ("SB2-synth" needs
-  ~18 sweeps per step): blocks are clipped to the sweeps that are left, the limit ends a step at a
-  block's exact stop, sweep counts and grids against the oracle."""
+@pytest.mark.parametrize("kern", [5, 4])
+@pytest.mark.parametrize("limit", [1, 2, 3, 7, 12])
+def test_block_kernels_iteration_limit(limit, kern, monkeypatch):
+  """simulator.py:348-368 with a limit that bites on the kernels that overlap sweeps in blocks
+  ("SB2-synth" needs ~18 sweeps per step): blocks are clipped to the sweeps that are left, the limit
+  ends a step at a block's exact stop, sweep counts and grids against the oracle."""
   from sbsim_amd.floorplan import rectangular_floor_plan
+  if kern == 4:
+    monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
   _check_plan_against_oracle(rectangular_floor_plan((8, 5), (12, 14)), 40, "auto", 1, monkeypatch,
-                             iteration_limit=limit, expect_kernel=4)
+                             iteration_limit=limit, expect_kernel=kern)
 
 
 def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatch, expect_steps=None,
