@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs.append(obj)
     if not force and _newer(obj, [src] + HEADERS):
       continue
-    cmd = [cc, *HIPCC_FLAGS, *inc, "-c", src, "-o", obj]
+    cmd = [cc, *HIPCC_FLAGS, *os.environ.get("SBSIM_EXTRA_HIPCC_FLAGS", "").split(), *inc, "-c", src, "-o", obj]   # developer builds
     if verbose:
       cmd.append("-Rpass-analysis=kernel-resource-usage")
     procs.append((cmd, subprocess.Popen(cmd)))

@@ -428,8 +428,11 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   std::vector<int> zone_of(N, -1);
   for (int z = 0; z < Z; ++z)
     for (int i = plan->zone_off[z]; i < plan->zone_off[z + 1]; ++i) zone_of[plan->zone_cells[i]] = z;
-  // mode 5: two wavefronts, one row per lane, sweeps overlapped in blocks (67..130 rows, <= 80 columns)
-  if (Hs > 64 + 2 && !env_flag("SBSIM_NO_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
+  // mode 5: two wavefronts, one row per lane, sweeps overlapped in blocks (67..130 rows, <= 80 columns).
+  // Measured level with mode 4 (profiles/r04_band_vs_two_rows.txt): all four SIMDs run, but four
+  // wavefronts share the CU's LDS pipe, every block starts with wavefront 1's 64-step lag and the tail
+  // scan sits on wavefront 1's critical path.  Kept, tested, behind SBSIM_BAND_PATH=1.
+  if (Hs > 64 + 2 && env_flag("SBSIM_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   // mode 4: one wavefront, two rows per lane (67..130 rows, <= 80 columns)
   if (Hs > 64 + 2 && !env_flag("SBSIM_NO_TWO_ROW_PATH") && plan_two(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   auto pick_slots = [&](int mode) { // narrowest instantiation that holds the width and the class count

@@ -40,16 +40,22 @@ namespace {
 
 using namespace sweep;
 
+#ifndef SB_BAND_EXP
+#define SB_BAND_EXP 0
+#endif
 constexpr int kSets = 32;  // entries of the coefficient-set table (at LDS address 0)
-constexpr int kWA = 7;     // class words (one step each) are read this many steps ahead
+constexpr int kWA = 11;    // class words (one step each) are read this many steps ahead (an L2 hit is ~800 cycles away)
 constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in the hand-over
 constexpr int kGrp = 8;    // steps between two checks of the other wavefront's progress
 constexpr int kHist = 8;   // ring of published max|delta| parts, by sweep number
+static_assert(kWA % 8 != 0 && (63 + kWA) % 8 != 0, "step_set: the start words leave the offset inside a chunk");
 
-// Slots of A kept in LDS (the rest: registers); also A's row stride (odd: conflict-free ds_read_b64).
-// 65: two wavefronts' A (66.6 KB) + tables + seam rows stay under 80 KB -- two buildings per CU -- and
-// the zone-sum scratch of 127 zone rows x 65 (66.0 KB) fits inside A.
-constexpr int lds_slots(int NR) { return NR < 65 ? (NR - 1) | 1 : 65; }
+// Slots of A kept in LDS (the rest: registers) = A's row stride: even (the steps go in pairs, one
+// ds_read_b128 per pair) and 2 mod 4 doubles (16-byte aligned rows, 16 lanes' ds_read_b128 cover all
+// banks).  66: two wavefronts' A (67.6 KB) + tables + seam rows stay under 80 KB -- two buildings per
+// CU -- and the zone-sum scratch of 127 zone rows x 65 (66.0 KB) fits inside A.  A row holds slot j at
+// position (j + 1) mod NR: the pair of an odd step is 16-byte aligned.
+constexpr int lds_slots(int NR) { return 66; }
 constexpr int seam_region(int NR) { return NR + 72; }                    // doubles per seam row: 64 finite ones in front (steps < 63)
 
 typedef const double __attribute__((address_space(3))) *lds_d;
@@ -57,9 +63,9 @@ typedef double __attribute__((address_space(3))) *lds_dw;
 typedef volatile int __attribute__((address_space(3))) *lds_vi;
 typedef volatile double __attribute__((address_space(3))) *lds_vd;
 
-struct StepBuf { // LDS values of one step
-  d2 ud, lr;     // (bU, bD), (bL, bR)
-  double A, rU, rD;
+struct PairBuf { // LDS values of two consecutive steps (the first one odd)
+  d2 ud0, lr0, ud1, lr1; // (bU, bD), (bL, bR)
+  d2 A, rU, rD;          // A of the two slots; upper neighbours of lane 0, lower neighbours of lane 63
 };
 
 struct Acc {
@@ -89,39 +95,90 @@ __device__ __forceinline__ void static_for(F &&f) {
 // Class words: one 32-bit word per step = the LDS byte offset (set * 32) of the cell's coefficient
 // set, read from global memory (L2 hits) kWA steps ahead; [wavefront][NR + 63 steps][64 lanes].
 __device__ __forceinline__ unsigned class_word(const Ctx &x) { return *(const unsigned *)(x.cmap + x.voff); }
-__device__ __forceinline__ void first_words(Ctx &x, int lane) { // words 0 .. kWA-1 of a sweep
-  x.voff = (unsigned)opaque(lane * 4);
+// The first kWA words of a block (steps 0 ..) and of a rolling period (steps 63 ..) are the same every
+// time: read once per kernel, kept in registers (a period would otherwise start with an L2 round trip).
+// Word S + kWA is read at step S through base + 32-bit offset + immediate: the offset register moves
+// once per 8 steps.
+// Values that are touched once per period (or per building) are homed in AGPRs by hand: the grid
+// row, the pair buffers and the class-word ring fill the 256 VGPRs that VALU instructions can address,
+// and left to the register allocator it is the grid that travels through AGPRs in every step.
+__device__ __forceinline__ int to_agpr(int v) {
+  int a;
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+  return a;
+}
+__device__ __forceinline__ int from_agpr(int a) {
+  int v;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
+struct StartWords {
+  int first[kWA], period[kWA]; // AGPRs
+};
+__device__ __forceinline__ void load_start_words(StartWords &sw, const Ctx &x, int lane) {
 #pragma unroll
   for (int k = 0; k < kWA; ++k) {
-    x.w[k] = class_word(x);
-    if (k + 1 < kWA) x.voff += 256u;
+    sw.first[k] = to_agpr((int)*(const unsigned *)(x.cmap + (unsigned)(lane * 4 + k * 256)));
+    sw.period[k] = to_agpr((int)*(const unsigned *)(x.cmap + (unsigned)(lane * 4 + (63 + k) * 256)));
   }
 }
-__device__ __forceinline__ void period_words(Ctx &x, int lane) { // a rolling period starts at step 63
-  x.voff = (unsigned)opaque(lane * 4 + 63 * 256);
+__device__ __forceinline__ void first_words(Ctx &x, const StartWords &sw, int lane) { // words 0 .. kWA-1 of a sweep
+  x.voff = (unsigned)opaque(lane * 4 + (kWA / 8) * 2048);
 #pragma unroll
-  for (int k = 0; k < kWA; ++k) {
-    x.w[(63 + k) % (kWA + 1)] = class_word(x);
-    if (k + 1 < kWA) x.voff += 256u;
+  for (int k = 0; k < kWA; ++k) x.w[k] = (unsigned)from_agpr(sw.first[k]);
+}
+__device__ __forceinline__ void period_words(Ctx &x, const StartWords &sw, int lane) { // a rolling period starts at step 63
+  x.voff = (unsigned)opaque(lane * 4 + ((63 + kWA) / 8) * 2048);
+#pragma unroll
+  for (int k = 0; k < kWA; ++k) x.w[(63 + k) % (kWA + 1)] = (unsigned)from_agpr(sw.period[k]);
+}
+// The slots of A that do not fit in LDS.
+template <int N>
+struct ARegs {
+  int a[2 * N]; // AGPRs
+  template <int K>
+  __device__ __forceinline__ void set(double v) {
+    a[2 * K] = to_agpr(__double2loint(v));
+    a[2 * K + 1] = to_agpr(__double2hiint(v));
   }
+  template <int K>
+  __device__ __forceinline__ double get() const {
+    return __hiloint2double(from_agpr(a[2 * K + 1]), from_agpr(a[2 * K]));
+  }
+};
+template <int NR, int S>
+__device__ __forceinline__ lds_d2 step_set(Ctx &x) { // the coefficient set of step S; reads word S + kWA
+  if constexpr (S + kWA < NR + 63) {
+    if constexpr ((S + kWA) % 8 == 0 && S > 0 && S != 63) { // (the start words leave the offset at its chunk)
+      x.voff += 2048u;
+      asm volatile("" : "+v"(x.voff)); // a running offset: nothing for the compiler to hoist
+    }
+    x.w[(S + kWA) % (kWA + 1)] = *(const unsigned *)(x.cmap + x.voff + (unsigned)(((S + kWA) % 8) * 256));
+  }
+  return (lds_d2)x.w[S % (kWA + 1)];
 }
 
+// LDS reads of the pair (S, S + 1), S odd.
 template <int NR, int S, int NAR>
-__device__ __forceinline__ void load_step(StepBuf &p, Ctx &x, const double (&Areg)[NAR]) {
-  if constexpr (S + kWA < NR + 63) {
-    x.voff += 256u;
-    asm volatile("" : "+v"(x.voff)); // a running offset: nothing for the compiler to hoist
-    x.w[(S + kWA) % (kWA + 1)] = class_word(x);
-  }
-  const lds_d2 st = (lds_d2)x.w[S % (kWA + 1)];
-  p.rU = *(lds_d)(x.ubase + 8u * ((S + 63) % NR));
-  p.rD = *(lds_d)(x.dbase + 8u * S);
-  p.ud = st[0];
-  p.lr = st[1];
+__device__ __forceinline__ void load_pair(PairBuf &p, Ctx &x, const ARegs<NAR> &Areg) {
+  static_assert(S % 2 == 1, "pairs start at odd steps");
+  const lds_d2 s0 = step_set<NR, S>(x), s1 = step_set<NR, S + 1>(x);
+#if SB_BAND_EXP >= 2
+  p.rU = d2{0.0, 0.0};
+  p.rD = d2{0.0, 0.0};
+#else
+  p.rU = *(lds_d2)(x.ubase + 8u * ((S + 63) % NR));
+  p.rD = *(lds_d2)(x.dbase + 8u * S);
+#endif
+  p.ud0 = s0[0];
+  p.lr0 = s0[1];
+  p.ud1 = s1[0];
+  p.lr1 = s1[1];
   __builtin_amdgcn_sched_barrier(0);
-  constexpr int r = S % NR, NL = lds_slots(NR);
-  if constexpr (r < NL) p.A = *(lds_d)(x.arow + 8u * r);
-  else p.A = Areg[r - NL];
+  constexpr int q = (S + 1) % NR, NL = lds_slots(NR); // position of slot S mod NR in the lane's A row: even
+  static_assert(q % 2 == 0, "A pairs are 16-byte aligned");
+  if constexpr (q < NL) p.A = *(lds_d2)(x.arow + 8u * q);
+  else p.A = d2{Areg.template get<q - NL>(), Areg.template get<q + 1 - NL>()};
 }
 
 // One Gauss-Seidel update of every lane's current cell at step S of a block:
@@ -130,15 +187,15 @@ __device__ __forceinline__ void load_step(StepBuf &p, Ctx &x, const double (&Are
 //   NR <= S < NR + 63  ROLL: lanes <= S - NR are in the next sweep; else they have finished (masked)
 // Association order of the four products as in step_reg.hip / step_lds.hip / step_roll.hip.
 template <int NR, int S, bool ROLL>
-__device__ __forceinline__ void step(double (&e)[NR], const StepBuf &p, Acc &acc, const Ctx &x) {
+__device__ __forceinline__ void step(double (&e)[NR], d2 ud, d2 lr, double A, double rU, double rD, Acc &acc, const Ctx &x) {
   constexpr int r = S % NR, rm = (S + NR - 1) % NR, rp = (S + 1) % NR;
-  const double Dn = wave_shift1<0x130, true>(e[rp], p.rD);
+  const double Dn = wave_shift1<0x130, true>(e[rp], rD);
   double t;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t) : "v"(p.ud.y), "v"(Dn), "v"(p.A));
-  t = fma(p.lr.y, e[rp], t);
-  const double U = wave_shift1<0x138, true>(e[rm], p.rU);
-  t = fma(p.lr.x, e[rm], t);
-  const double nv = fma(p.ud.x, U, t);
+  asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t) : "v"(ud.y), "v"(Dn), "v"(A));
+  t = fma(lr.y, e[rp], t);
+  const double U = wave_shift1<0x138, true>(e[rm], rU);
+  t = fma(lr.x, e[rm], t);
+  const double nv = fma(ud.x, U, t);
   double sel = nv;
   if constexpr (ROLL && S >= NR) {
     constexpr int J = S - NR;
@@ -157,38 +214,52 @@ __device__ __forceinline__ void step(double (&e)[NR], const StepBuf &p, Acc &acc
   }
   asm volatile("" : "+v"(acc.cur)); // here, not after the sweep (the maxima would keep every delta of the sweep alive)
   e[r] = sel;
+#if SB_BAND_EXP != 1 // (timing experiments: 1 = no publish, 2 = no seam reads, 3 = neither)
+#if SB_BAND_EXP != 3
   *(lds_dw)(x.pub + 8u * r) = sel; // lane 63 / lane 0: the seam rows; every other lane: its scratch strip
+#endif
+#endif
 }
 
 // The other wavefront's progress (steps completed in this block), before this wavefront runs steps
 // t .. t + n - 1 (and reads one step ahead).  need_off: + 64 (wavefront 1: row 63's new values must
 // exist) or - NR - 62 (wavefront 0: row 64's values of the previous sweep must exist, and wavefront 1
 // must have read the upper neighbours this wavefront is about to overwrite).
-__device__ __forceinline__ void sync_steps(lds_vi mine, lds_vi theirs, int done, int need) {
+__device__ __forceinline__ void sync_steps(lds_vi mine, lds_vi theirs, int done, int need, long long *dbg = nullptr) {
   *mine = done;
   if (need > 0) {
+#ifdef SB_BAND_COUNT_SPINS // developer aid: how long do the wavefronts wait for each other?
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(*theirs) < need) { __builtin_amdgcn_s_sleep(1); ++spins; }
+    if (dbg && spins && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)dbg + (threadIdx.x >> 6 ? 7 : 6), (unsigned long long)spins);
+#else
+    (void)dbg;
     while (__builtin_amdgcn_readfirstlane(*theirs) < need) __builtin_amdgcn_s_sleep(1);
+#endif
   }
   asm volatile("" ::: "memory");
 }
 
-// Steps S .. S1 - 1 of a block whose period started at local step tb (the block's step count is
-// tb + S); the LDS reads of step S + 1 are issued before the arithmetic of step S.
+// Pairs S, S + 2, .. < S1 (S odd) of a block whose period started at local step tb (the block's step
+// count is tb + S); the LDS reads of the next pair are issued before the arithmetic of a pair.
 template <int NR, int S, int S1, bool ROLL, int NAR>
-__device__ __forceinline__ void run_steps(double (&e)[NR], const double (&Areg)[NAR], StepBuf (&pb)[2], Ctx &x, Acc &acc,
-                                          lds_vi mine, lds_vi theirs, int tb, int need_off, int last_step) {
+__device__ __forceinline__ void run_pairs(double (&e)[NR], const ARegs<NAR> &Areg, PairBuf (&pb)[2], Ctx &x, Acc &acc,
+                                          lds_vi mine, lds_vi theirs, int tb, int need_off, int last_step, long long *dbg) {
   if constexpr (S < S1) {
-    if constexpr (!ROLL && S >= NR && (S - NR) % 4 == 0)
+    if constexpr (!ROLL && S >= NR && (S - NR) % 4 == 1)
       if (S > last_step) return; // uniform: only lanes without rows are left
-    if constexpr (S % kGrp == (S < 63 ? 0 : 63 % kGrp)) { // the group's last step reads ahead for the one after it
-      constexpr int n = (S1 - S < kGrp ? S1 - S : kGrp) + 1;
-      sync_steps(mine, theirs, tb + S, tb + S + n + need_off);
+    if constexpr (S % kGrp == (S < 63 ? 1 : 63 % kGrp)) { // the group's last pair reads ahead for the pair after it
+      constexpr int n = (S1 - S < kGrp ? S1 - S : kGrp) + 2;
+      sync_steps(mine, theirs, tb + S, tb + S + n + need_off, dbg);
     }
-    if constexpr (S + 1 < NR + 63) load_step<NR, S + 1>(pb[(S + 1) & 1], x, Areg);
+    PairBuf &cur = pb[((S - 1) / 2) & 1], &nxt = pb[((S + 1) / 2) & 1];
+    if constexpr (S + 2 < NR + 63) load_pair<NR, S + 2>(nxt, x, Areg);
     __builtin_amdgcn_sched_barrier(0);
-    step<NR, S, ROLL>(e, pb[S & 1], acc, x);
+    step<NR, S, ROLL>(e, cur.ud0, cur.lr0, cur.A.x, cur.rU.x, cur.rD.x, acc, x);
     __builtin_amdgcn_sched_barrier(0);
-    run_steps<NR, S + 1, S1, ROLL>(e, Areg, pb, x, acc, mine, theirs, tb, need_off, last_step);
+    step<NR, S + 1, ROLL>(e, cur.ud1, cur.lr1, cur.A.y, cur.rU.y, cur.rD.y, acc, x);
+    __builtin_amdgcn_sched_barrier(0);
+    run_pairs<NR, S + 2, S1, ROLL>(e, Areg, pb, x, acc, mine, theirs, tb, need_off, last_step, dbg);
   }
 }
 
@@ -203,7 +274,7 @@ __device__ __forceinline__ float sweeps_to_go(float d1, float d0, float thr, flo
 // A = ap*Tprev + g for the lane's cells (e = Tprev before the first sweep).  aw: class offsets into
 // the (ap, g) table, four slots per word.
 template <int NR, int NAR>
-__device__ __forceinline__ void a_pass(const double (&e)[NR], double (&Areg)[NAR], double *Aw, const char *tapg,
+__device__ __forceinline__ void a_pass(const double (&e)[NR], ARegs<NAR> &Areg, double *Aw, const char *tapg,
                                        const unsigned long long *amap) {
   constexpr int NL = lds_slots(NR), NWD = NR / 4;
   static_assert(NR % 4 == 0, "a_pass: four slots per word");
@@ -223,8 +294,9 @@ __device__ __forceinline__ void a_pass(const double (&e)[NR], double (&Areg)[NAR
     static_for<0, 4>([&](auto kc) {
       constexpr int k = decltype(kc)::value, j = j0 + k;
       const double av = fma(pg[k].x, e[j], pg[k].y);
-      if constexpr (j < NL) Aw[j] = av;
-      else Areg[j - NL] = av;
+      constexpr int q = (j + 1) % NR; // slot j's position in the lane's row
+      if constexpr (q < NL) Aw[q] = av;
+      else Areg.template set<q - NL>(av);
     });
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -256,7 +328,7 @@ extern __shared__ __attribute__((aligned(16))) double lds[];
 // [scratch 2 x (64 + NR + 8)] | r_xchg: sync words | r_A: A [2][64][AS] (after the sweeps: zone sums)
 template <int NR>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_band(Dev a) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wavefront-uniform: SGPRs
   constexpr int kNL = lds_slots(NR), kAS = kNL, kNAR = NR - kNL > 0 ? NR - kNL : 1, kRG = seam_region(NR);
   static_assert(NR % 4 == 0 && NR >= 68, "slots");
 
@@ -266,10 +338,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))
   double *S_zero = seam + 64, *S_up = seam + kRG + 64, *S_dn = seam + 2 * kRG + 64, *S_tl = seam + 3 * kRG + 64;
   double *tE0 = seam + 4 * kRG + 64;     // the first tail row by column (zeros without tail rows)
   double *scratch = seam + 5 * kRG;      // [2][64 + NR + 8]
-  int *sync = (int *)(lds + a.r_xchg);   // [2][64] progress | [2][kHist] sweep numbers of the published parts | misc
-  double *mpart = lds + a.r_xchg + 64 + kHist + 8; // [2][kHist]
-  int *mflag = sync + 128;               // [2][kHist]
-  int *misc = sync + 128 + 2 * kHist;    // [0]: the next building
+  int *sync = (int *)(lds + a.r_xchg);   // [2][64] progress counters
+  double *mrec = lds + a.r_xchg + 64;    // [2][kHist] records {max|delta| part, sweep number}: 16 bytes each
+  int *misc = sync + 2 * (64 + 4 * kHist); // [0]: the next building
   double *A = lds + a.r_A;               // [2][64][kAS]; after the sweeps: zone sums [Z + 1][65]
   for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0; // every byte starts finite
   __syncthreads();
@@ -311,6 +382,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))
     tset[t] = (a.ncset - 1) * 32 * 0x10001; // the pad set (the table's last)
     if (t < a.T && tactive) tset[t] = ((int)a.tcset[t * NR + tc0] << 2) | ((int)a.tcset[t * NR + tc0 + 1] << 18);
   }
+  StartWords sw;
+  load_start_words(sw, x, lane);
   const unsigned long long *amap = a.amapS + (size_t)wv * (NR / 4) * 64 + lane;
   const unsigned long long *zmap = a.zmapS + (size_t)wv * (NR / 4) * 64 + lane;
   const int R = wv * 64 + lane; // the lane's row of the state [NR / 2][128][2]
@@ -345,7 +418,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))
   for (int b = blockIdx.x, bn = 0; b < a.B; b = bn, ++iter) {
     if (threadIdx.x == 0) misc[0] = a.sweep_wgs + atomicAdd(a.next_b, 1);
     SB_STAMP(0);
-    first_words(x, lane);
+    first_words(x, sw, lane);
     double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 128; // [T][NR]
     double *tp = a.temp + (size_t)b * a.state_doubles + 2 * R;
     const double t_now = nx_tnow;
@@ -365,32 +438,55 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))
           const d2 pg = *(const d2 *)((const char *)tapg + 16 * (int)a.tcls[t * NR + tc0 + k]);
           At[t][k] = fma(pg.x, tv[t][k], pg.y);
         }
-    double Areg[kNAR];
-    Areg[0] = 0.0;
+    ARegs<kNAR> Areg;
     a_pass<NR>(e, Areg, A + ((size_t)wv * 64 + lane) * kAS, (const char *)tapg, amap);
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(2);
 
     int n_sweeps = 0, converged = 0;
     {
-      StepBuf pb[2];
+      PairBuf pb[2];
       Acc acc;
       const float thr = (float)p.conv_threshold;
       const int prev_sweeps = __builtin_amdgcn_readfirstlane(a.nsw[b] & 0xffff); // of this building's previous step
-      // max |delta| of sweep G of this step (both wavefronts' parts); G >= 1
+      // max |delta| of sweep G of this step = the maximum of both wavefronts' parts (G >= 1).  A part is
+      // published as a 16-byte record {value, G}: one ds_read_b128 per part tells whether it is there.
       auto publish_part = [&](int G, double part) {
         const double m = wave_max(part);
         if (lane == 0) {
-          *(lds_vd)(lds_addr(mpart + wv * kHist + (G % kHist))) = m;
-          *(lds_vi)(lds_addr(mflag + wv * kHist + (G % kHist))) = G;
+          const unsigned rec = lds_addr(mrec + 2 * (wv * kHist + (G % kHist)));
+          *(lds_vd)rec = m;
+          *(lds_vi)(rec + 8u) = G;
         }
       };
-      auto sweep_md = [&](int G) -> double { // waits for both parts
-        lds_vi f0 = (lds_vi)(lds_addr(mflag + (G % kHist))), f1 = (lds_vi)(lds_addr(mflag + kHist + (G % kHist)));
-        while (__builtin_amdgcn_readfirstlane(*f0) != G || __builtin_amdgcn_readfirstlane(*f1) != G) __builtin_amdgcn_s_sleep(1);
+      typedef const volatile d2 __attribute__((address_space(3))) *lds_vd2;
+      // the last three values read, by sweep number: a decision needs one new one (LDS round trip)
+      int c_g = -10;
+      double c1 = -1.0, c2 = -1.0, c3 = -1.0; // md(c_g), md(c_g - 1), md(c_g - 2); < 0: not read yet
+      auto sweep_md = [&](int G) -> double {
+        if (G == c_g && c1 >= 0.0) return c1;
+        if (G == c_g - 1 && c2 >= 0.0) return c2;
+        if (G == c_g - 2 && c3 >= 0.0) return c3;
+        const unsigned r0 = lds_addr(mrec + 2 * (G % kHist)), r1 = lds_addr(mrec + 2 * (kHist + G % kHist));
+        double m;
+        for (;;) { // waits for both parts
+          const d2 p0 = *(lds_vd2)r0, p1 = *(lds_vd2)r1;
+          if (__builtin_amdgcn_readfirstlane(__double2loint(p0.y)) == G && __builtin_amdgcn_readfirstlane(__double2loint(p1.y)) == G) {
+            m = fmax(p0.x, p1.x);
+            break;
+          }
+#ifdef SB_BAND_COUNT_SPINS
+          if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + 8, 1ull);
+#endif
+          __builtin_amdgcn_s_sleep(1);
+        }
         asm volatile("" ::: "memory");
-        const double m0 = *(lds_vd)(lds_addr(mpart + (G % kHist))), m1 = *(lds_vd)(lds_addr(mpart + kHist + (G % kHist)));
-        return fmax(m0, m1);
+        if (G == c_g + 1) { c3 = c2; c2 = c1; c1 = m; c_g = G; }
+        else if (G > c_g + 1) { c_g = G; c1 = m; c2 = c3 = -1.0; }
+        else if (G == c_g) c1 = m;
+        else if (G == c_g - 1) c2 = m;
+        else if (G == c_g - 2) c3 = m;
+        return m;
       };
       // the end of this wavefront's sweep G: the tail rows (wavefront 1), its part of max |delta|
       auto sweep_end = [&](int G) {
@@ -432,19 +528,26 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int c = 0; c < NR; ++c) S_dn[c] = e[c];
           }
-          if (threadIdx.x < 2 * kHist) mflag[threadIdx.x] = 0;
+          if (threadIdx.x < 2 * kHist) *(lds_vi)(lds_addr(mrec + 2 * threadIdx.x) + 8u) = 0; // no part of this block is published
+          c_g = -10; // (the same sweeps of a block that is run again have the same values: this is tidiness)
           __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
-#define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && n_sweeps == 4 && threadIdx.x == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
-          SB_STAMP2(10);
+#define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && q == 4 && n0 == 0 && threadIdx.x == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
           acc.cur = 0.0;
           acc.neg = 0.0;
           acc.sg = lane == 0 ? (int)0x80000000 : 0;
           n_sweeps = n0;
           q = 0;
-          sync_steps(prog_mine, prog_theirs, 0, 1 + need_off); // wavefront 1: row 63's first new value must exist
-          load_step<NR, 0>(pb[0], x, Areg);
-          run_steps<NR, 0, 63, false>(e, Areg, pb, x, acc, prog_mine, prog_theirs, 0, need_off, last_step); // ramp-up; reads ahead for step 63
+          sync_steps(prog_mine, prog_theirs, 0, 3 + need_off); // wavefront 1: row 63's first new values must exist
+          { // step 0 (lane 0, column 0) on its own: pairs start at odd steps
+            const lds_d2 st = step_set<NR, 0>(x);
+            const d2 ud = st[0], lr = st[1];
+            const double A0 = *(lds_d)(x.arow + 8u), rU0 = *(lds_d)(x.ubase + 8u * 63u), rD0 = *(lds_d)(x.dbase);
+            load_pair<NR, 1>(pb[0], x, Areg);
+            step<NR, 0, false>(e, ud, lr, A0, rU0, rD0, acc, x);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          run_pairs<NR, 1, 63, false>(e, Areg, pb, x, acc, prog_mine, prog_theirs, 0, need_off, last_step, a.dbg); // ramp-up; reads ahead for the pair (63, 64)
           bool overrun = false;
 #pragma nounroll
           for (;;) {
@@ -480,29 +583,30 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))
             if (!__builtin_amdgcn_readfirstlane(go)) break;
             asm volatile("" : "+v"(x.arow), "+v"(x.ubase), "+v"(x.dbase), "+v"(x.pub)); // not loop invariants: nothing to hoist (and spill)
             __builtin_amdgcn_sched_barrier(0);
-            run_steps<NR, 63, NR + 63, true>(e, Areg, pb, x, acc, prog_mine, prog_theirs, q * NR, need_off, last_step);
+            SB_STAMP2(10); // the fifth rolling period of wavefront 0: its steps, then its end and the next decision
+            run_pairs<NR, 63, NR + 63, true>(e, Areg, pb, x, acc, prog_mine, prog_theirs, q * NR, need_off, last_step, a.dbg);
             __builtin_amdgcn_sched_barrier(0);
             *prog_mine = q * NR + NR + 63; // every step of the period is done
+            SB_STAMP2(11);
+            if (a.dbg && blockIdx.x == 0 && iter == 3 && q == 5 && n0 == 0 && threadIdx.x == 0) a.dbg[12] = (long long)__builtin_readcyclecounter();
             ++q;
             ++n_sweeps;
-            period_words(x, lane);
+            period_words(x, sw, lane);
             sweep_end(n0 + q);
             acc.cur = -acc.neg;
             acc.neg = 0.0;
             acc.sg = lane == 0 ? (int)0x80000000 : 0;
-            load_step<NR, 63>(pb[1], x, Areg); // after the tail scan: lane 63's lower neighbour is new
+            load_pair<NR, 63>(pb[1], x, Areg); // after the tail scan: lane 63's lower neighbours are new
           }
           if (!overrun) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" : "+v"(x.arow), "+v"(x.ubase), "+v"(x.dbase), "+v"(x.pub));
-            run_steps<NR, 63, NR + 63, false>(e, Areg, pb, x, acc, prog_mine, prog_theirs, q * NR, need_off, last_step); // the block's last sweep
+            run_pairs<NR, 63, NR + 63, false>(e, Areg, pb, x, acc, prog_mine, prog_theirs, q * NR, need_off, last_step, a.dbg); // the block's last sweep
             __builtin_amdgcn_sched_barrier(0);
             *prog_mine = 1 << 30; // the other wavefront needs nothing more from this one
             ++n_sweeps;
-            first_words(x, lane);
-            SB_STAMP2(11);
+            first_words(x, sw, lane);
             sweep_end(n_sweeps);
-            SB_STAMP2(12);
             // the block's last two sweeps, complete: did the one before the last converge already?
             const int Gl = n_sweeps;
             if (m == 0) // a decision looks at the sweeps two (or one) before its own: the last three, here
@@ -534,7 +638,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int k = 0; k < 2; ++k)
               if (t < a.T && tactive) tv[t][k] = Ttail[t * NR + tc0 + k];
           if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
-          first_words(x, lane);
+          first_words(x, sw, lane);
         }
         if (converged || n_sweeps >= p.iter_limit) break;
       }

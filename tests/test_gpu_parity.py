@@ -73,9 +73,9 @@ def test_one_day_rollout_against_reference_golden(tag, kernel, monkeypatch):
   if kernel.startswith("lds"):
     monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
   if kernel == "reg-pair":
-    monkeypatch.setenv("SBSIM_NO_TWO_ROW_PATH", "1")   # the library's own choice for 96 x 66 is "reg-band", then "reg-two"
-  if kernel in ("reg-pair", "reg-two"):
-    monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
+    monkeypatch.setenv("SBSIM_NO_TWO_ROW_PATH", "1")   # the library's own choice for 96 x 66 is "reg-two"
+  if kernel == "reg-band":
+    monkeypatch.setenv("SBSIM_BAND_PATH", "1")
   sim = BatchedSimulator(_plan(load("plan_r9_sb1.npz")), SimConfig.sb1(), B, float(g["h_conv"]),
                          orientation={"reg": "auto", "reg-pair": "columns", "lds": "rows",
                                       "lds-columns": "columns", "reg-two": "columns", "reg-band": "columns"}[kernel])
@@ -420,18 +420,22 @@ def test_full_size_batch_register_and_lds_kernels_agree(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rooms,room_shape,B", [((8, 5), (12, 14), 16384), ((14, 9), (8, 7), 8192)])
-def test_mixed_classes_at_size_two_rows_and_lds_kernels_agree(rooms, room_shape, B, monkeypatch):
+@pytest.mark.parametrize("band", [False, True])
+@pytest.mark.parametrize("rooms,room_shape,B", [((8, 5), (12, 14), 21845), ((14, 9), (8, 7), 21845)])
+def test_mixed_classes_at_size_block_and_lds_kernels_agree(rooms, room_shape, B, band, monkeypatch):
   """BASELINE.json configs[2]'s larger classes ("SB2-synth" 107x78, "SB1-synth" 129x75 inside the
-  ring) at batch size: the two-rows-per-lane register kernel with its predicted blocks and the
-  LDS-grid kernel must take the same number of Gauss-Seidel sweeps for EVERY building at every
-  step (tens of sweeps each, blocks overrunning now and then) and end within 1e-9 K of each other."""
+  ring) at `bench.py --config mixed`'s batch size per class: the register kernels that overlap sweeps in
+  predicted blocks (step_two.hip; band: step_band.hip) and the LDS-grid kernel must take the same number
+  of Gauss-Seidel sweeps for EVERY building at every step (tens of sweeps each, blocks overrunning now
+  and then) and end within 1e-9 K of each other."""
   _need_gpu()
+  if band:
+    monkeypatch.setenv("SBSIM_BAND_PATH", "1")
   from sbsim_amd.floorplan import rectangular_floor_plan
   g = load("h2_sb1_r9_random.npz")
   plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, room_shape), Materials.sb1(), 10.0, 300.0)
   H, W = plan.shape
-  T = 6
+  T = 4
   gen = torch.Generator(device="cuda")
   gen.manual_seed(9)
   t0 = (294.0 + torch.randn((B, 1), generator=gen, device="cuda", dtype=torch.float64)).clamp(285.0, 305.0)
@@ -443,6 +447,8 @@ def test_mixed_classes_at_size_two_rows_and_lds_kernels_agree(rooms, room_shape,
       monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
     sim = BatchedSimulator(plan, SimConfig.sb1(), B, float(g["h_conv"]))
     assert sim.launch_info["path"] == (0 if force_lds else 1)
+    if not force_lds:
+      assert sim.launch_info["kernel"] == (5 if band else 4)
     sim.reset(temps=init)
     assert torch.equal(sim.temps().reshape(B, -1), init)
     sims.append(sim)
@@ -608,8 +614,8 @@ def _oracle_twin(plan, cfg, init_flat):
     ((2, 3), (30, 30), "rows", 1),     # 65x96 -> registers, 1 wave + ONE tail row
     ((4, 5), (10, 8), "rows", 1),      # 47x48, 20 zones -> registers, zone reduce in two 16-zone passes
     ((4, 2), (30, 17), "columns", 0),  # the same family on the LDS-grid kernel, lanes = columns
-    # 67..130 rows, <= 80 columns: step_band.hip (path 5: two wavefronts, one row per lane) is the library's
-    # choice; step_two.hip (path 4: one wavefront, two rows per lane) stays behind SBSIM_NO_BAND_PATH
+    # 67..130 rows, <= 80 columns: step_two.hip (path 4: one wavefront, two rows per lane) is the library's
+    # choice; step_band.hip (path 5: two wavefronts, one row per lane) sits behind SBSIM_BAND_PATH=1
     ((8, 5), (12, 14), "auto", 5),     # "SB2-synth" 107x78 inside the ring: 64 + 43 rows, 80 slots
     ((14, 9), (8, 7), "auto", 5),      # "SB1-synth" 129x75, 137 cell classes: 64 + 64 rows + ONE tail row, 76 slots
     ((5, 3), (24, 24), "rows", 5),     # 128x78: 64 + 64 rows, no tail row
@@ -629,8 +635,8 @@ def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, 
   kern = None
   if path >= 4:
     kern, path = path, 1
-    if kern == 4:
-      monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
+    if kern == 5:
+      monkeypatch.setenv("SBSIM_BAND_PATH", "1")
   _check_plan_against_oracle(rectangular_floor_plan(rooms, room_shape), rooms[0] * rooms[1], orientation, path, monkeypatch,
                              expect_kernel=kern)
 
@@ -648,8 +654,8 @@ def test_block_kernels_tail_rows_and_overrun_blocks(haste, slack, kern, monkeypa
   assert fp.shape == (132, 77)
   monkeypatch.setenv("SBSIM_DEBUG_PRED_HASTE", str(haste))
   monkeypatch.setenv("SBSIM_DEBUG_PRED_SLACK", str(slack))
-  if kern == 4:
-    monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
+  if kern == 5:
+    monkeypatch.setenv("SBSIM_BAND_PATH", "1")
   _check_plan_against_oracle(fp, 126, "rows", 1, monkeypatch, expect_steps=76 + 64 - 1 + 8 if kern == 4 else 76 + 8,
                              expect_kernel=kern)
 
@@ -661,8 +667,8 @@ def test_block_kernels_iteration_limit(limit, kern, monkeypatch):
   ("SB2-synth" needs ~18 sweeps per step): blocks are clipped to the sweeps that are left, the limit
   ends a step at a block's exact stop, sweep counts and grids against the oracle."""
   from sbsim_amd.floorplan import rectangular_floor_plan
-  if kern == 4:
-    monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
+  if kern == 5:
+    monkeypatch.setenv("SBSIM_BAND_PATH", "1")
   _check_plan_against_oracle(rectangular_floor_plan((8, 5), (12, 14)), 40, "auto", 1, monkeypatch,
                              iteration_limit=limit, expect_kernel=kern)
 
