@@ -181,7 +181,8 @@ typedef enum sb_sweep_kernel {
   SB_KERNEL_REG_PAIR = 2, /* k_sweep_reg mode 2: two wavefronts, <= 128 rows */
   SB_KERNEL_ROLL = 3,     /* k_sweep_roll: one wavefront + tail rows, overlapped sweeps (step_roll.hip) */
   SB_KERNEL_TWO_ROWS = 4, /* k_sweep_two: two rows per lane, 67..130 rows, sweeps overlapped in blocks (step_two.hip) */
-  SB_KERNEL_BAND = 5      /* k_sweep_band: two wavefronts, one row per lane, 67..130 rows, sweeps overlapped in blocks (step_band.hip) */
+  SB_KERNEL_BAND = 5,     /* k_sweep_band: two wavefronts, one row per lane, 67..130 rows, sweeps overlapped in blocks (step_band.hip) */
+  SB_KERNEL_STREAM = 6    /* k_sweep_stream: the grid stays in global memory, up to 16 wavefronts per building (step_stream.hip) */
 } sb_sweep_kernel;
 
 /* Launch geometry chosen for the floor plan (reported for DESIGN.md / bench.py). */
@@ -189,8 +190,8 @@ typedef struct sb_launch_info {
   int32_t waves_per_workgroup, workgroups, lds_bytes_per_workgroup, sweep_steps;
   int64_t algorithmic_bytes_per_env_step; /* 8HW+24Z+4A+4O+44 (fp32 state) */
   int64_t state_bytes_per_env_step;       /* what this build really moves: fp64 grid r+w */
-  int32_t path;               /* 1: grid in registers, 0: grid in LDS (step_lds.hip) */
-  int32_t waves_per_building; /* wavefronts that share one building (1 or 2) */
+  int32_t path;               /* 1: grid in registers, 0: grid in LDS (step_lds.hip), 2: grid in global memory (step_stream.hip) */
+  int32_t waves_per_building; /* wavefronts that share one building (1, 2, or up to 16 on path 2) */
   int32_t kernel;             /* sb_sweep_kernel: which sweep kernel owns this floor plan */
   int32_t reserved;
 } sb_launch_info;

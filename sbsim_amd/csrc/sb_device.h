@@ -73,7 +73,7 @@ struct Dev {
   // ---- register path (step_reg.hip); reg == 0 when the floor plan is not eligible ----
   int reg;                 // 1: k_step_reg owns the step
   int NR;                  // slots per lane (>= trimmed width), one of the instantiated sizes
-  int P;                   // kernel mode: 1 / 2 wavefronts per building, 3 = 1 wavefront + tail rows, 4 = two rows per lane, 5 = two wavefronts in blocks
+  int P;                   // kernel mode: 1 / 2 wavefronts per building, 3 = 1 wavefront + tail rows, 4 = two rows per lane, 5 = two wavefronts in blocks, 6 = grid in global memory
   int T;                   // mode 3: rows 64..64+T-1 are finished by the tail scan (T <= 2)
   int state_doubles;       // doubles of HBM state per building
   const uint8_t *tcls;     // mode 3: [T][NR] classes of the tail cells (class * 8)
@@ -160,6 +160,11 @@ int sweep_band_lds_slots(int NR);       // slots of A in LDS = A's row stride
 int sweep_band_seam_doubles(int NR);    // LDS doubles of the seam rows and the publish scratch
 int sweep_band_sync_doubles();          // LDS doubles of the progress counters and the published max|delta| parts
 int sweep_band_set_table();
+// step_stream.hip: mode 6 (the grid in global memory: plans that fit no other kernel)
+int launch_sweep_stream(const Dev &d, double *abuf, int waves, hipStream_t stream);
+int prepare_sweep_stream(const Dev &d);
+int sweep_stream_set_table();
+int sweep_stream_zone_columns();
 int prepare_sweep_roll(const Dev &d);
 bool sweep_roll_supported(int NR);
 int sweep_roll_lds_slots(int NR);            // slots of A in LDS

@@ -84,6 +84,7 @@ struct sb_handle {
   int steps_since_reset = 0; // how far a reset rewinds the clock (the boiler's action age, scal[19])
   sb_launch_info info{};
   DevBuf<uint8_t> cls, tcls, tcset;
+  DevBuf<double> abuf; // step_stream.hip: A = ap*Tprev + g of the buildings in flight
   DevBuf<double> ctab, csetab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum,
       hist_bins;
   DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone, cell_state, nsw, next_b, src_dest,

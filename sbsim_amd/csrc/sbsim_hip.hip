@@ -402,6 +402,109 @@ bool plan_band(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const s
   return true;
 }
 
+// Mode 6 (step_stream.hip): the grid stays in global memory; W = ceil(rows / 64) wavefronts per building
+// (W <= 16), any width whose seam rows fit in LDS.  For floor plans no other kernel holds.
+bool plan_stream(const sb_plan_desc *plan, RegPlan &r, std::string &why) {
+  const int H = plan->H, W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = H * W;
+  auto coef = [&](int c, int j) { return plan->class_coef[c * 8 + j]; };
+  auto cls_at = [&](int x, int y) { return (int)plan->cell_class[x * W + y]; };
+  std::vector<char> ambient(ncls, 0); // T' = T_ambient whatever the neighbours are (simulator.py:256-258)
+  for (int c = 0; c < ncls; ++c)
+    ambient[c] = coef(c, 0) == 0 && coef(c, 1) == 0 && coef(c, 2) == 0 && coef(c, 3) == 0 &&
+                 coef(c, 4) == 0 && coef(c, 5) == 1.0 && coef(c, 6) == 0;
+  int x0 = H, x1 = -1, y0 = W, y1 = -1;
+  for (int x = 0; x < H; ++x)
+    for (int y = 0; y < W; ++y)
+      if (!ambient[cls_at(x, y)]) {
+        x0 = std::min(x0, x); x1 = std::max(x1, x);
+        y0 = std::min(y0, y); y1 = std::max(y1, y);
+      }
+  if (x1 < 0) { why = "no cell inside the building"; return false; }
+  const int Hs = x1 - x0 + 1, Ws = y1 - y0 + 1;
+  for (int y = y0; y <= y1; ++y)
+    if (coef(cls_at(x0, y), 0) != 0 || coef(cls_at(x1, y), 1) != 0) { why = "coupling across the trim box"; return false; }
+  for (int x = x0; x <= x1; ++x)
+    if (coef(cls_at(x, y0), 2) != 0 || coef(cls_at(x, y1), 3) != 0) { why = "coupling across the trim box"; return false; }
+  const int NWV = (Hs + 63) / 64;
+  if (NWV > 16) { why = "more than 1,024 rows inside the building (try the other orientation)"; return false; }
+  const int NS = std::max(72, (Ws + 1) & ~1), RS = 64 * NWV;
+  int ts = 32;
+  while (ts < ncls + 1) ts *= 2;
+  if (ts > 256) { why = "more than 255 cell classes"; return false; }
+  const int pad = ncls;
+  std::vector<int> set_of(ncls + 1, 0);
+  r.csetab.clear();
+  for (int c = 0; c < ncls; ++c) {
+    int found = -1;
+    for (size_t k = 0; k < r.csetab.size() / 4 && found < 0; ++k)
+      if (r.csetab[4 * k] == coef(c, 0) && r.csetab[4 * k + 1] == coef(c, 1) && r.csetab[4 * k + 2] == coef(c, 2) &&
+          r.csetab[4 * k + 3] == coef(c, 3)) found = (int)k;
+    if (found < 0) {
+      found = (int)r.csetab.size() / 4;
+      for (int j = 0; j < 4; ++j) r.csetab.push_back(coef(c, j));
+    }
+    set_of[c] = found;
+  }
+  set_of[pad] = (int)r.csetab.size() / 4;
+  for (int j = 0; j < 4; ++j) r.csetab.push_back(0.0);
+  if ((int)r.csetab.size() / 4 > sweep_stream_set_table()) { why = "more than 31 distinct coefficient sets"; r.csetab.clear(); return false; }
+  if (Z > 65534) { why = "too many zones"; r.csetab.clear(); return false; }
+  const int ZC = sweep_stream_zone_columns();
+  int off = 4 * sweep_stream_set_table() + 2 * ts;
+  r.r_seam = off; off += 2 * NWV * (NS + 8);
+  r.r_xchg = off; off += 32;
+  r.r_A = off; off += (Z + 1) * ZC;
+  r.lds_bytes = off * 8;
+  if (r.lds_bytes > kLdsCap) { why = "the seam rows (rows / 64 x columns x 16 bytes) and the zone sums do not fit in 160 KiB of LDS"; r.csetab.clear(); return false; }
+  // workgroups per CU: LDS, threads (2,048 per CU) and registers (<= 128 per lane: four wavefronts per SIMD)
+  r.wg_per_cu = std::max(1, std::min({kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule), 32 / NWV, 16 / NWV}));
+  r.NR = NS; r.P = 6; r.RS = RS; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
+  r.T = 0; r.ts = ts; r.AS = 0;
+  r.state_doubles = NS * RS;
+  r.lw[0] = std::min(Hs, 64); r.lw[1] = NWV; // lw[1]: wavefronts per building
+  r.steps = 64 * (NWV - 1) + NS + 63;
+  auto cell_class = [&](int R, int col) {
+    return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? cls_at(x0 + R, y0 + col) : pad;
+  };
+  std::vector<int> zone_of(N, -1);
+  for (int z = 0; z < Z; ++z)
+    for (int i = plan->zone_off[z]; i < plan->zone_off[z + 1]; ++i) zone_of[plan->zone_cells[i]] = z;
+  const int NW = NS + 63;
+  std::vector<uint32_t> cw((size_t)NWV * NW * 64, 0);
+  std::vector<uint16_t> zm((size_t)NWV * NS * 64, (uint16_t)Z);
+  for (int w = 0; w < NWV; ++w)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int R = 64 * w + lane;
+      for (int t = 0; t < NW; ++t) {
+        const int col = t - lane;
+        const int c = (R < Hs && col >= 0 && col < NS) ? cell_class(R, col) : pad;
+        cw[((size_t)w * NW + t) * 64 + lane] = (uint32_t)(set_of[c] * 32) | ((uint32_t)(c * 16) << 16);
+      }
+      for (int s = 0; s < NS; ++s) {
+        const int col = ((s - lane) % NS + NS) % NS;
+        if (R < Hs && col < Ws && zone_of[(x0 + R) * W + (y0 + col)] >= 0)
+          zm[((size_t)w * NS + s) * 64 + lane] = (uint16_t)zone_of[(x0 + R) * W + (y0 + col)];
+      }
+    }
+  r.cmapS.assign((cw.size() + 1) / 2, 0);
+  std::memcpy(r.cmapS.data(), cw.data(), cw.size() * sizeof(uint32_t));
+  r.zmapS.assign((zm.size() + 3) / 4, 0);
+  std::memcpy(r.zmapS.data(), zm.data(), zm.size() * sizeof(uint16_t));
+  r.amapS.assign(1, 0);
+  r.tcls.assign(1, (uint8_t)0);
+  r.tcset.assign(1, (uint8_t)0);
+  r.cell_state.assign(N, 0);
+  int ring = 0;
+  for (int x = 0; x < H; ++x)
+    for (int y = 0; y < W; ++y) {
+      const int R = x - x0, col = y - y0;
+      if (R < 0 || R >= Hs || col < 0 || col >= Ws) { r.cell_state[x * W + y] = -(++ring); continue; }
+      r.cell_state[x * W + y] = ((col + (R & 63)) % NS) * RS + R; // state layout [NS][RS]
+    }
+  r.ok = true;
+  return true;
+}
+
 // lds_per_cu: buildings per CU the LDS-grid kernel would hold (0: the plan does not fit it).
 void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   const int H = plan->H, W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = H * W;
@@ -700,7 +803,15 @@ void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan 
   const int64_t N = (int64_t)plan->H * plan->W, Z = plan->Z;
   out->algorithmic_bytes_per_env_step = 8ll * N + 24ll * Z + 4ll * n_actions + 4ll * n_obs + 44;
   const int64_t rest = (8 * 4 + 4 * 2) * Z + 16ll * kNScalOut + 4ll * n_actions + 4ll * n_obs + 4;
-  if (r.ok) {
+  if (r.ok && r.P == 6) { // step_stream.hip: the grid in global memory
+    out->path = 2;
+    out->waves_per_building = out->waves_per_workgroup = r.lw[1];
+    out->kernel = r.P;
+    out->workgroups = std::max(1, std::min(n_buildings, cus * r.wg_per_cu));
+    out->lds_bytes_per_workgroup = r.lds_bytes;
+    out->sweep_steps = r.steps;
+    out->state_bytes_per_env_step = 16ll * r.state_doubles + rest;
+  } else if (r.ok) {
     out->path = 1;
     out->waves_per_building = (r.P == 2 || r.P == 5) ? 2 : 1;
     out->kernel = r.P; // sb_sweep_kernel: modes 1..5 are SB_KERNEL_REG .. SB_KERNEL_BAND
@@ -725,6 +836,23 @@ void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan 
   }
 }
 
+// Which sweep kernel owns this floor plan: a register kernel (plan_reg), else the LDS-grid kernel, else --
+// plans that fit neither -- the streaming kernel.  SBSIM_FORCE_STREAM_PATH=1: the streaming kernel (tests).
+int choose_kernel(const sb_plan_desc *plan, const LdsPlan &q, RegPlan &r) {
+  std::string why;
+  if (env_flag("SBSIM_FORCE_STREAM_PATH")) {
+    if (!plan_stream(plan, r, why)) return fail(SB_ERR_TOO_LARGE, "the streaming sweep kernel cannot hold this floor plan: " + why);
+    return SB_OK;
+  }
+  if (!env_flag("SBSIM_FORCE_LDS_PATH")) plan_reg(plan, lds_buildings_per_cu(q), r);
+  if (r.ok || q.fits) return SB_OK;
+  r = RegPlan();
+  if (!plan_stream(plan, r, why))
+    return fail(SB_ERR_TOO_LARGE, "no sweep kernel holds this floor plan (the streaming kernel takes up to 1,024 rows in one "
+                                  "orientation and rows / 64 x columns <= ~9,000): " + why);
+  return SB_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -738,9 +866,8 @@ int sb_plan_info(const sb_plan_desc *plan, int32_t n_obs, int32_t n_buildings, s
   if (rc != SB_OK) return rc;
   RegPlan r;
   const LdsPlan q = plan_lds(plan);
-  if (!env_flag("SBSIM_FORCE_LDS_PATH")) plan_reg(plan, lds_buildings_per_cu(q), r);
-  if (!r.ok && !q.fits)
-    return fail(SB_ERR_TOO_LARGE, "one building's float64 grid does not fit in 160 KiB of LDS");
+  rc = choose_kernel(plan, q, r);
+  if (rc != SB_OK) return rc;
   fill_launch_info(plan, r, q, n_obs, 256, std::max(n_buildings, 1), out);
   return SB_OK;
 }
@@ -786,9 +913,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
 
   RegPlan r;
   const LdsPlan q = plan_lds(plan);
-  if (!env_flag("SBSIM_FORCE_LDS_PATH")) plan_reg(plan, lds_buildings_per_cu(q), r);
-  if (!r.ok && !q.fits)
-    return fail(SB_ERR_TOO_LARGE, "sb_create: one building's float64 grid does not fit in 160 KiB of LDS");
+  rc = choose_kernel(plan, q, r);
+  if (rc != SB_OK) return rc;
 
   auto h = new sb_handle();
   h->device = device;
@@ -839,6 +965,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     SB_TRY(upload(h->csetab, r.csetab.data(), r.csetab.size()));
     d.tcset = h->tcset.p; d.csetab = h->csetab.p; d.ncset = (int)r.csetab.size() / 4;
     SB_TRY(alloc_zero(h->temp, (size_t)d.B * d.state_doubles));
+    if (d.P == 6) SB_TRY(alloc_zero(h->abuf, (size_t)h->info.workgroups * d.state_doubles)); // A = ap*Tprev + g, one grid per resident workgroup
     d.tcls = h->tcls.p;
     d.cmapS = h->cmapS.p; d.amapS = h->amapS.p; d.zmapS = h->zmapS.p; d.cell_state = h->cell_state.p;
     d.ring = h->ring.p;
@@ -970,7 +1097,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     if (alloc_zero(h->dbg, 16) == SB_OK) d.dbg = h->dbg.p;
   }
 
-  const int e = d.reg ? (d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
+  const int e = d.reg ? (d.P == 6 ? prepare_sweep_stream(d) : d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
                       : prepare_sweep_lds((size_t)h->info.lds_bytes_per_workgroup);
   if (e != (int)hipSuccess) {
     delete h;
@@ -1043,7 +1170,8 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   if (phases & SB_PHASE_SWEEP) {
     if (!(phases & SB_PHASE_PRE)) // k_pre zeroes the sweep kernel's draw counter; without it in this call:
       SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream));
-    const int e = d.reg ? (d.P == 5   ? launch_sweep_band(d, (hipStream_t)stream)
+    const int e = d.reg ? (d.P == 6   ? launch_sweep_stream(d, h->abuf.p, h->info.waves_per_workgroup, (hipStream_t)stream)
+                       : d.P == 5 ? launch_sweep_band(d, (hipStream_t)stream)
                        : d.P == 4 ? launch_sweep_two(d, (hipStream_t)stream)
                        : d.P == 3 ? launch_sweep_roll(d, (hipStream_t)stream)
                                   : launch_sweep_reg(d, h->cus, (hipStream_t)stream))

@@ -1,0 +1,217 @@
+// step_stream.hip -- the sweep kernel for floor plans that do not fit one CU (more than 130 rows or 96
+// columns inside the exterior ring, or a grid beyond the LDS of a CU): the temperature grid STAYS in
+// global memory (HBM / L2) and streams through the wavefronts once per Gauss-Seidel sweep.
+// simulator.py:278-371; any H x W is legal in building.py:609-764.
+//
+// One workgroup of W = ceil(rows / 64) wavefronts (W <= 16: 1,024 rows) per building; lane l of
+// wavefront w owns row 64 w + l and walks it in the anti-diagonal order of the register kernels: at
+// local step t it updates column t - l, wavefront w running >= 64 steps behind wavefront w - 1.  That
+// is the reference's row-major in-place order.  The state is stored
+// slot-major -- column c of row r at [slot (c + r) mod NS][r], the layout of step_reg.hip's HBM state
+// -- so a wavefront's access at step t is ONE coalesced 512-byte row of slot t mod NS.  Per cell and
+// sweep a lane loads its right-hand neighbour (8 B; it is the cell's own old value one step later),
+// A = ap*Tprev + g (8 B, written by a pass before the first sweep) and a class word (4 B, static),
+// and stores the new value (8 B); the left-hand neighbour is the lane's previous result, the upper /
+// lower neighbours come by DPP from the neighbouring lanes.  Everything a lane reads from global
+// memory was written by its own wavefront; the rows at a seam between two wavefronts (row 64 w - 1's
+// new values, row 64 w's old ones) travel through LDS under a progress counter per wavefront.
+// Registers: ~100 -- several buildings per CU, the memory latency is hidden by occupancy, not by
+// unrolling.  Bound: HBM / L2 bandwidth (28 B per cell and sweep), not instruction issue.
+#include "sb_device.h"
+
+namespace sb {
+namespace {
+
+constexpr int kSets = 32;   // entries of the coefficient-set table (at LDS address 0)
+constexpr int kPF = 8;      // steps between a global load and its use
+constexpr int kZC = 17;     // columns of the zone-sum scratch per zone (16 lane columns + 1: odd stride)
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef const d2 __attribute__((address_space(3))) *lds_d2;
+typedef volatile int __attribute__((address_space(3))) *lds_vi;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_seam(double x, double old) { // lanes without a source keep `old`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+extern __shared__ __attribute__((aligned(16))) double lds[];
+
+// LDS (doubles): [tabc 4 kSets][tapg 2 ts] | r_seam: up [W][NS + 8], dn [W][NS + 8] | r_xchg: progress
+// [16] ints, max|delta| parts [16] | r_A: zone sums [Z + 1][kZC]
+__global__ void __launch_bounds__(1024) k_sweep_stream(Dev a, double *Abuf) {
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int W = (int)(blockDim.x >> 6), NS = a.NR, RS = a.RS, NSP = NS + 8;
+  double *tabc = lds;
+  double *tapg = lds + 4 * kSets;
+  double *up = lds + a.r_seam;              // up[w][c]: row 64 w + 63's new value at column c (this sweep)
+  double *dn = up + (size_t)W * NSP;        // dn[w][c]: row 64 w's latest value at column c
+  int *prog = (int *)(lds + a.r_xchg);      // [W] steps completed in this sweep
+  double *mpart = lds + a.r_xchg + 8;       // [W] max |delta| of the wavefront's rows
+  int *misc = (int *)(lds + a.r_xchg + 24); // [0]: the next building
+  double *zs = lds + a.r_A;                 // [Z + 1][kZC]
+  for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * kSets; i += blockDim.x) tabc[i] = i < 4 * a.ncset ? a.csetab[i] : 0.0;
+  for (int c = threadIdx.x; c < a.ts; c += blockDim.x) tapg[2 * c] = c <= a.ncls ? a.ctab[c * 8 + 4] : 0.0; // row `ncls`: the pad class
+  __syncthreads();
+  if ((unsigned)(size_t)(__attribute__((address_space(3))) double *)tabc != 0u) __builtin_trap(); // class words hold LDS addresses
+
+  const sb_params &p = a.p;
+  const int row = wv * 64 + lane;
+  const int NW = NS + 63;                                          // steps of a wavefront per sweep
+  const unsigned *cmap = (const unsigned *)a.cmapS + (size_t)wv * NW * 64 + lane; // [W][NW][64]: set offset | class * 16 << 16
+  const unsigned short *zmap = (const unsigned short *)a.zmapS + (size_t)wv * NS * 64 + lane; // [W][NS][64]: zone (Z: none)
+  lds_vi prog_mine = (lds_vi)(unsigned)(size_t)(__attribute__((address_space(3))) int *)(prog + wv);
+  lds_vi prog_prev = (lds_vi)(unsigned)(size_t)(__attribute__((address_space(3))) int *)(prog + (wv > 0 ? wv - 1 : 0));
+  const double *up_prev = up + (size_t)(wv > 0 ? wv - 1 : 0) * NSP;  // lane 0's upper neighbours
+  const double *dn_next = dn + (size_t)(wv + 1 < W ? wv + 1 : wv) * NSP; // lane 63's lower neighbours
+  const bool has_prev = wv > 0, has_next = wv + 1 < W;
+  double *up_mine = up + (size_t)wv * NSP, *dn_mine = dn + (size_t)wv * NSP;
+
+  for (int b = blockIdx.x, bn = 0; b < a.B; b = bn) {
+    if (threadIdx.x == 0) misc[0] = a.sweep_wgs + atomicAdd(a.next_b, 1);
+    double *E = a.temp + (size_t)b * a.state_doubles + row;   // [NS][RS], this lane's column of rows
+    double *Ab = Abuf + (size_t)blockIdx.x * a.state_doubles + row; // one A grid per resident workgroup
+    const double t_now = a.bld[b].t_now;
+    const double ring_lo = a.scal[(size_t)b * kNScal + 16], ring_hi = a.scal[(size_t)b * kNScal + 17];
+    // exterior-space cells outside the trim box all become t_now in the first sweep
+    // (simulator.py:256-258); their largest |delta| follows from their extreme values
+    const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - ring_lo), fabs(t_now - ring_hi)) : 0.0;
+    for (int c = threadIdx.x; c < a.ts; c += blockDim.x) tapg[2 * c + 1] = a.gtabg[(size_t)b * a.ts + c];
+    for (int i = threadIdx.x; i < (a.Z + 1) * kZC; i += blockDim.x) zs[i] = 0.0;
+    __syncthreads();
+    bn = __builtin_amdgcn_readfirstlane(*(volatile int *)misc);
+    // A = ap*Tprev + g for every cell of the lane's row, slot by slot (the class of slot s: the word of
+    // the step at which the lane works on it, s - lane mod NS + lane); row 64 w's values into dn[w]
+    for (int s = 0; s < NS; ++s) {
+      int t = s - lane;           // the lane's column at slot s
+      if (t < 0) t += NS;
+      const unsigned cw = cmap[(size_t)(t + lane) * 64]; // step t + lane: column t
+      const d2 pg = *(const d2 *)((const char *)tapg + (cw >> 16));
+      const double v = E[(size_t)s * RS];
+      Ab[(size_t)s * RS] = fma(pg.x, v, pg.y);
+      if (lane == 0) dn_mine[s] = v; // lane 0: column s sits in slot s
+    }
+    int n_sweeps = 0, converged = 0;
+    for (;;) { // simulator.py:348-368
+      if (lane == 0) *prog_mine = 0;
+      __syncthreads();
+      double acc = 0.0;
+      // streams: eR(t) = E[(t + 1) mod NS] (the right-hand neighbour at step t = the cell's own old value
+      // at step t + 1), A(t) = Ab[t mod NS], cw(t); kPF steps ahead, in a ring of registers
+      double ring_e[kPF], ring_a[kPF];
+      unsigned ring_c[kPF];
+      int sl = 0; // slot of step t + kPF ... maintained incrementally: sl = (t + kPF) mod NS
+#pragma unroll
+      for (int k = 0; k < kPF; ++k) { // steps 0 .. kPF-1
+        const int s0 = k % NS, s1 = (k + 1) % NS;
+        ring_e[k] = E[(size_t)s1 * RS];
+        ring_a[k] = Ab[(size_t)s0 * RS];
+        ring_c[k] = cmap[(size_t)k * 64];
+      }
+      sl = kPF % NS;
+      double old = E[0];      // the lane's own old value at step 0 (slot 0)
+      double nv = 0.0;        // the lane's previous result (left-hand neighbour)
+      for (int t0 = 0; t0 < NW; t0 += kPF) {
+        // the wavefront above must have published row 63's new values for the columns lane 0 reaches here
+        if (has_prev) {
+          const int need = min(t0 + kPF, NS) + 63; // column c is published at step c + 63: c + 64 steps completed
+          while (__builtin_amdgcn_readfirstlane(*prog_prev) < need) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < kPF; ++k) {
+          const int t = t0 + k;
+          const int s = t < NS ? t : t - NS; // t mod NS (t < NS + 63 <= 2 NS)
+          const double eR = ring_e[k], Av = ring_a[k];
+          const unsigned cw = ring_c[k];
+          { // refill the ring entry with step t + kPF
+            const int tn = t + kPF;
+            int s1 = sl + 1;
+            if (s1 >= NS) s1 -= NS;
+            ring_e[k] = E[(size_t)s1 * RS];
+            ring_a[k] = Ab[(size_t)sl * RS];
+            ring_c[k] = cmap[(size_t)min(tn, NW - 1) * 64];
+            sl = s1;
+          }
+          const lds_d2 st = (lds_d2)(cw & 0xffffu);
+          const d2 ud = st[0], lr = st[1];
+          const int c0 = t, c63 = t - 63;   // columns of lane 0 / lane 63 at this step
+          const double rU = has_prev && c0 < NS ? up_prev[c0] : 0.0;
+          const double rD = has_next && c63 >= 0 ? dn_next[c63] : 0.0;
+          const double Dn = dpp_seam<0x130>(eR, rD);    // lane l + 1's right-hand value is this lane's lower neighbour
+          const double U = dpp_seam<0x138>(nv, rU);     // lane l - 1's previous result
+          double tt = fma(ud.y, Dn, Av);
+          tt = fma(lr.y, eR, tt);
+          tt = fma(lr.x, nv, tt);
+          const double res = fma(ud.x, U, tt);
+          const int col = t - lane;
+          const bool act = col >= 0 && col < NS;
+          if (act) {
+            acc = fmax(acc, fabs(res - old));
+            E[(size_t)s * RS] = res;
+            if (lane == 63) up_mine[col] = res;
+            if (lane == 0) dn_mine[col] = res;
+          }
+          nv = act ? res : nv;
+          old = eR;
+        }
+        if (lane == 0) *prog_mine = min(t0 + kPF, NW); // steps completed (LDS operations of a wavefront stay in order)
+      }
+      // max |delta| over the building
+      double m = wave_max(acc);
+      if (lane == 0) mpart[wv] = m;
+      __syncthreads();
+      double md = 0.0;
+      for (int w = 0; w < W; ++w) md = fmax(md, mpart[w]);
+      if (n_sweeps == 0) md = fmax(md, ring_d);
+      ++n_sweeps;
+      converged = md <= p.conv_threshold;
+      if (converged || n_sweeps >= p.iter_limit) break;
+    }
+    // zone sums and the grid sum of the lane's row (row Z of the scratch: cells outside every zone)
+    __syncthreads();
+    for (int s = 0; s < NS; ++s) {
+      const double v = E[(size_t)s * RS];
+      const int z = (int)zmap[(size_t)s * 64];
+      __hip_atomic_fetch_add(zs + z * kZC + (lane & 15), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    if (wv == 0) {
+      double gacc = 0.0;
+      for (int zb = 0; zb <= a.Z; zb += 64) {
+        const int zz = zb + lane;
+        double v = 0.0;
+        if (zz <= a.Z)
+          for (int k = 0; k < 16; ++k) v += zs[zz * kZC + k];
+        if (zz < a.Z) a.zsum[(size_t)b * a.Z + zz] = v;
+        gacc += v;
+      }
+      const double gsum = wave_sum(gacc);
+      if (lane == 0) {
+        a.gsum[b] = gsum + (double)a.n_ring * t_now;
+        a.nsw[b] = n_sweeps | (converged << 16);
+      }
+    }
+    __syncthreads(); // the zone sums are read; the tables may change
+  }
+}
+
+} // namespace
+
+int sweep_stream_set_table() { return kSets; }
+int sweep_stream_zone_columns() { return kZC; }
+
+int prepare_sweep_stream(const Dev &d) {
+  return (int)hipFuncSetAttribute((const void *)k_sweep_stream, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_reg_bytes);
+}
+
+int launch_sweep_stream(const Dev &d, double *abuf, int waves, hipStream_t stream) {
+  hipLaunchKernelGGL(k_sweep_stream, dim3(d.sweep_wgs), dim3(64 * waves), (size_t)d.lds_reg_bytes, stream, d, abuf);
+  return (int)hipGetLastError();
+}
+
+} // namespace sb

@@ -309,7 +309,8 @@ class BatchedSimulator:
       cand = describe(plan.transposed() if tr else plan)
       rc, info = cand[3]
       # SIMD steps per building-sweep: a kernel that spreads a building over two wavefronts holds half as many
-      key = (rc != 0, -info.path if rc == 0 else 0, info.sweep_steps * max(info.waves_per_building, 1) if rc == 0 else 0)
+      pref = {1: 0, 0: 1, 2: 2}.get(info.path, 3) if rc == 0 else 9   # registers, then LDS, then the streaming kernel
+      key = (rc != 0, pref, info.sweep_steps * max(info.waves_per_building, 1) if rc == 0 else 0)
       if best is None or key < best[0]:
         best = (key, tr, cand)
     self.transposed = best[1]

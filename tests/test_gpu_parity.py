@@ -674,12 +674,11 @@ def test_block_kernels_iteration_limit(limit, kern, monkeypatch):
 
 
 def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatch, expect_steps=None,
-                               iteration_limit=None, expect_kernel=None):
+                               iteration_limit=None, expect_kernel=None, B=6, T=14, expect_waves=None):
   _need_gpu()
   g = load("h2_sb1_r9_random.npz")
   plan = FloorPlan.from_file_input(file_plan, Materials.sb1(), 10.0, 300.0)
   H, W = plan.shape
-  B, T = 6, 14
   rs = np.random.RandomState(11)
   init = np.clip(294.0 + 2.0 * rs.randn(B, 1) + 0.2 * rs.randn(B, H * W), 285.0, 305.0)
   acts = rs.uniform(-1, 1, size=(T, B, 2)).astype(np.float32)
@@ -692,12 +691,16 @@ def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatc
     orientation = "rows"
   if path == 0:
     monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
+  if path == 2 and H * W < 100000:
+    monkeypatch.setenv("SBSIM_FORCE_STREAM_PATH", "1")   # small plans reach the streaming kernel only when told to
   sim = BatchedSimulator(plan, cfg, B, float(g["h_conv"]), orientation=orientation)
   assert sim.Z == n_zones and sim.launch_info["path"] == path
   if expect_steps is not None:
     assert sim.launch_info["sweep_steps"] == expect_steps   # the two-rows kernel with two tail rows
   if expect_kernel is not None:
     assert sim.launch_info["kernel"] == expect_kernel
+  if expect_waves is not None:
+    assert sim.launch_info["waves_per_building"] == expect_waves
   sim.reset(temps=torch.tensor(init, dtype=torch.float64, device="cuda"))
   twins = [_oracle_twin(plan, cfg, init[b]) for b in range(B)]
   obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
@@ -729,3 +732,30 @@ def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatc
   grid = sim.temps().cpu().numpy()
   for b in range(B):
     assert np.abs(grid[b] - twins[b].grid()).max() < T_TOL, b
+
+
+@pytest.mark.parametrize("rooms,room_shape,orientation,waves", [
+    ((3, 3), (20, 30), "rows", 2),      # R9: 66 x 96 inside the ring -> two wavefronts (64 + 2 rows)
+    ((3, 3), (20, 30), "columns", 2),   # ... transposed: 96 x 66 (64 + 32 rows), 72 slots for 66 columns
+    ((8, 5), (12, 14), "rows", 2),      # "SB2-synth" 107 x 78, 40 zones
+    ((14, 9), (8, 7), "rows", 3),       # "SB1-synth" 129 x 75: three wavefronts (the last with one row), 126 zones, 137 classes
+    ((2, 2), (5, 9), "rows", 1),        # 15 x 23: one wavefront, no seam
+    ((10, 2), (19, 40), "rows", 4),     # 203 x 85 inside the ring: four wavefronts
+])
+def test_streaming_kernel_against_oracle(rooms, room_shape, orientation, waves, monkeypatch):
+  """step_stream.hip (the grid stays in global memory, up to 16 wavefronts per building, seam rows through
+  LDS) forced onto floor plans the other kernels own: sweep counts EQUAL, temperatures within 1e-8 K of
+  the CPU-oracle twins."""
+  from sbsim_amd.floorplan import rectangular_floor_plan
+  _check_plan_against_oracle(rectangular_floor_plan(rooms, room_shape), rooms[0] * rooms[1], orientation, 2, monkeypatch,
+                             expect_kernel=6, expect_waves=waves)
+
+
+def test_floor_plan_beyond_one_cu_against_oracle(monkeypatch):
+  """A floor plan no CU can hold (missing #1): 299 x 401 control volumes, 126 zones -- 0.96 MB of
+  float64 state per building.  The library picks the streaming kernel by itself (five wavefronts per
+  building); sweep counts EQUAL and temperatures within 1e-8 K of the CPU oracle."""
+  from sbsim_amd.floorplan import rectangular_floor_plan
+  fp = rectangular_floor_plan((14, 9), (20, 43))
+  assert fp.shape == (299, 401)
+  _check_plan_against_oracle(fp, 126, "rows", 2, monkeypatch, expect_kernel=6, expect_waves=5, B=2, T=3)
