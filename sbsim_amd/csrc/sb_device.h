@@ -162,7 +162,7 @@ int sweep_band_sync_doubles();          // LDS doubles of the progress counters 
 int sweep_band_set_table();
 // step_stream.hip: mode 6 (the grid in global memory: plans that fit no other kernel)
 int launch_sweep_stream(const Dev &d, double *abuf, int waves, hipStream_t stream);
-int prepare_sweep_stream(const Dev &d);
+int prepare_sweep_stream(const Dev &d, int waves);
 int sweep_stream_set_table();
 int sweep_stream_zone_columns();
 int prepare_sweep_roll(const Dev &d);

@@ -452,7 +452,7 @@ bool plan_stream(const sb_plan_desc *plan, RegPlan &r, std::string &why) {
   const int ZC = sweep_stream_zone_columns();
   int off = 4 * sweep_stream_set_table() + 2 * ts;
   r.r_seam = off; off += 2 * NWV * (NS + 8);
-  r.r_xchg = off; off += 32;
+  r.r_xchg = off; off += 32 + 64 * NWV; // progress, max|delta| parts, the publish scratch
   r.r_A = off; off += (Z + 1) * ZC;
   r.lds_bytes = off * 8;
   if (r.lds_bytes > kLdsCap) { why = "the seam rows (rows / 64 x columns x 16 bytes) and the zone sums do not fit in 160 KiB of LDS"; r.csetab.clear(); return false; }
@@ -1097,7 +1097,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     if (alloc_zero(h->dbg, 16) == SB_OK) d.dbg = h->dbg.p;
   }
 
-  const int e = d.reg ? (d.P == 6 ? prepare_sweep_stream(d) : d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
+  const int e = d.reg ? (d.P == 6 ? prepare_sweep_stream(d, h->info.waves_per_workgroup) : d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
                       : prepare_sweep_lds((size_t)h->info.lds_bytes_per_workgroup);
   if (e != (int)hipSuccess) {
     delete h;

@@ -41,7 +41,8 @@ extern __shared__ __attribute__((aligned(16))) double lds[];
 
 // LDS (doubles): [tabc 4 kSets][tapg 2 ts] | r_seam: up [W][NS + 8], dn [W][NS + 8] | r_xchg: progress
 // [16] ints, max|delta| parts [16] | r_A: zone sums [Z + 1][kZC]
-__global__ void __launch_bounds__(1024) k_sweep_stream(Dev a, double *Abuf) {
+template <int WMAX> // wavefronts per workgroup <= WMAX: the register budget follows the launch bound
+__global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf) {
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int W = (int)(blockDim.x >> 6), NS = a.NR, RS = a.RS, NSP = NS + 8;
   double *tabc = lds;
@@ -51,6 +52,7 @@ __global__ void __launch_bounds__(1024) k_sweep_stream(Dev a, double *Abuf) {
   int *prog = (int *)(lds + a.r_xchg);      // [W] steps completed in this sweep
   double *mpart = lds + a.r_xchg + 8;       // [W] max |delta| of the wavefront's rows
   int *misc = (int *)(lds + a.r_xchg + 24); // [0]: the next building
+  double *dummy = lds + a.r_xchg + 32;      // [W][64]: where the lanes that publish nothing write
   double *zs = lds + a.r_A;                 // [Z + 1][kZC]
   for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0;
   __syncthreads();
@@ -70,6 +72,10 @@ __global__ void __launch_bounds__(1024) k_sweep_stream(Dev a, double *Abuf) {
   const double *dn_next = dn + (size_t)(wv + 1 < W ? wv + 1 : wv) * NSP; // lane 63's lower neighbours
   const bool has_prev = wv > 0, has_next = wv + 1 < W;
   double *up_mine = up + (size_t)wv * NSP, *dn_mine = dn + (size_t)wv * NSP;
+  // every step a lane writes its result to LDS: lane 63 to up[w][column], lane 0 to dn[w][column], the
+  // others (and a lane outside its row) to a scratch double of their own -- one ds_write, no branch
+  double *const pub_dummy = dummy + (size_t)wv * 64 + lane;
+  double *const pub_seam = lane == 63 ? up_mine - 63 : (lane == 0 ? dn_mine : nullptr); // + step = + column + lane
 
   for (int b = blockIdx.x, bn = 0; b < a.B; b = bn) {
     if (threadIdx.x == 0) misc[0] = a.sweep_wgs + atomicAdd(a.next_b, 1);
@@ -150,12 +156,11 @@ __global__ void __launch_bounds__(1024) k_sweep_stream(Dev a, double *Abuf) {
           const double res = fma(ud.x, U, tt);
           const int col = t - lane;
           const bool act = col >= 0 && col < NS;
-          if (act) {
-            acc = fmax(acc, fabs(res - old));
-            E[(size_t)s * RS] = res;
-            if (lane == 63) up_mine[col] = res;
-            if (lane == 0) dn_mine[col] = res;
-          }
+          // a lane outside its row stores the slot's unchanged content back (`old` is that content)
+          const double out = act ? res : old;
+          acc = fmax(acc, fabs(out - old));
+          E[(size_t)s * RS] = out;
+          *((act && pub_seam) ? pub_seam + t : pub_dummy) = out;
           nv = act ? res : nv;
           old = eR;
         }
@@ -200,18 +205,26 @@ __global__ void __launch_bounds__(1024) k_sweep_stream(Dev a, double *Abuf) {
   }
 }
 
+template <int WMAX>
+int go(const Dev &d, double *abuf, int waves, hipStream_t stream, bool prepare) {
+  if (prepare)
+    return (int)hipFuncSetAttribute((const void *)k_sweep_stream<WMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_reg_bytes);
+  hipLaunchKernelGGL((k_sweep_stream<WMAX>), dim3(d.sweep_wgs), dim3(64 * waves), (size_t)d.lds_reg_bytes, stream, d, abuf);
+  return (int)hipGetLastError();
+}
+int dispatch(const Dev &d, double *abuf, int waves, hipStream_t stream, bool prepare) {
+  if (waves <= 2) return go<2>(d, abuf, waves, stream, prepare);
+  if (waves <= 4) return go<4>(d, abuf, waves, stream, prepare);
+  if (waves <= 8) return go<8>(d, abuf, waves, stream, prepare);
+  return go<16>(d, abuf, waves, stream, prepare);
+}
+
 } // namespace
 
 int sweep_stream_set_table() { return kSets; }
 int sweep_stream_zone_columns() { return kZC; }
 
-int prepare_sweep_stream(const Dev &d) {
-  return (int)hipFuncSetAttribute((const void *)k_sweep_stream, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_reg_bytes);
-}
-
-int launch_sweep_stream(const Dev &d, double *abuf, int waves, hipStream_t stream) {
-  hipLaunchKernelGGL(k_sweep_stream, dim3(d.sweep_wgs), dim3(64 * waves), (size_t)d.lds_reg_bytes, stream, d, abuf);
-  return (int)hipGetLastError();
-}
+int prepare_sweep_stream(const Dev &d, int waves) { return dispatch(d, nullptr, waves, nullptr, true); }
+int launch_sweep_stream(const Dev &d, double *abuf, int waves, hipStream_t stream) { return dispatch(d, abuf, waves, stream, false); }
 
 } // namespace sb
