@@ -181,6 +181,57 @@ def stub_rank(args) -> None:
     dist.destroy_process_group()
 
 
+
+class TwinCheck:
+  """In-run parity for the configs that do not carry the cpu_baseline leg: the first `n` buildings of a
+  BatchedEnvironment are re-stepped on CPU-oracle twins (oracle/sb_oracle.c -- the checker, never the
+  product) with the very inputs the device saw; Gauss-Seidel sweep counts must be EQUAL and zone
+  temperatures within 1e-8 K at every step.  `record` copies a few numbers to the host per step, so it
+  is off unless asked for (--check-buildings)."""
+
+  def __init__(self, env: BatchedEnvironment, plan: FloorPlan, init_temps: np.ndarray, n: int):
+    from oracle import oracle as orc   # checker only
+    self.env, self.n, self.steps = env, n, []
+    oplan = orc.OraclePlan(plan.conductivity, plan.density, plan.heat_capacity, plan.exterior_space,
+                           plan.zone_cell_lists(), plan.diffusers, plan.cv_size_cm, plan.floor_height_cm)
+    c = env.config
+    oprm = orc.OracleParams(
+        dt=c.time_step_sec, conv_threshold=c.convergence_threshold, iter_limit=c.iteration_limit,
+        vav_max_air_flow=c.vav_max_air_flow_rate, vav_max_water_flow=c.vav_reheat_max_water_flow_rate,
+        ahu_recirc=c.ahu_recirculation, ahu_heat_sp=c.ahu_heating_air_temp_setpoint,
+        ahu_cool_sp=c.ahu_cooling_air_temp_setpoint, ahu_dp=c.ahu_fan_differential_pressure,
+        ahu_eff=c.ahu_fan_efficiency, blr_setpoint=c.boiler_reheat_water_setpoint,
+        blr_head=c.boiler_water_pump_differential_head, blr_pump_eff=c.boiler_water_pump_efficiency,
+        comfort_lo=c.comfort_temp_window[0], comfort_hi=c.comfort_temp_window[1],
+        eco_lo=c.eco_temp_window[0], eco_hi=c.eco_temp_window[1],
+        blr_heating_rate=c.boiler_heating_rate, blr_cooling_rate=c.boiler_cooling_rate, ahu_has_weather=1)
+    H, W = plan.shape
+    self.twins = [orc.OracleBuilding(oplan, oprm, 0.0, reset_temps=np.full(H * W, float(init_temps[b]))) for b in range(n)]
+    for tw in self.twins:
+      tw.observe_boiler(0.0)   # Environment.reset()'s observation
+
+  def record(self, step_in, actions: torch.Tensor) -> None:
+    """After the device step with `step_in` / `actions`: what the twins need and what the device found."""
+    env, n = self.env, self.n
+    self.steps.append((step_in, actions[:n].detach().cpu().numpy().copy(), env.info[:n, 4].cpu().numpy().copy(),
+                       env.sim.zone_temps()[:n].cpu().numpy().copy()))
+
+  def verify(self) -> dict:
+    lo, hi = self.env.config.action_ranges
+    worst, mismatches = 0.0, 0
+    for t, (si, acts, nsw, zt) in enumerate(self.steps):
+      for b, tw in enumerate(self.twins):
+        native = [np.float32((float(acts[b, 0]) + 1.0) / 2.0 * (lo[1] - lo[0]) + lo[0]),
+                  np.float32((float(acts[b, 1]) + 1.0) / 2.0 * (hi[1] - hi[0]) + hi[0])]
+        o = tw.step(now_ts=300.0 * t, t_amb_now=si.t_amb_now, h_conv=100.0, t_amb_next=si.t_amb_next,
+                    comfort_now=bool(si.comfort_now), comfort_prev=si.comfort_prev == 1,
+                    comfort_next=bool(si.comfort_next), occupancy=si.occupancy, e_price=si.e_price,
+                    e_carbon=si.e_carbon, g_price=si.g_price, g_carbon=si.g_carbon, action=native)
+        mismatches += int(int(nsw[b]) != o["n_sweeps"])
+        worst = max(worst, float(np.abs(zt[b] - o["zone_temp_post"]).max()))
+    return {"buildings": self.n, "steps": len(self.steps), "sweep_count_mismatches": mismatches, "max_abs_dT_zone_K": worst}
+
+
 MIXED_CLASSES = [("R9", (3, 3), (20, 30)), ("SB2-synth", (8, 5), (12, 14)), ("SB1-synth", (14, 9), (8, 7))]
 
 
@@ -193,6 +244,7 @@ def mixed_config(args) -> None:
   dev = torch.device("cuda", 0)
   torch.cuda.set_device(0)
   B_each, K, W = args.buildings // len(MIXED_CLASSES), args.steps, args.warmup
+  N_ALONE = 3
   classes = []
   for name, rooms, shape in MIXED_CLASSES:
     plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
@@ -206,8 +258,10 @@ def mixed_config(args) -> None:
       env.sim.reset(temps=t_init[:, None].expand(B_each, H * Wd).contiguous())
       gen = torch.Generator(device=dev)
       gen.manual_seed(1234)
-      acts = torch.rand((W + K, B_each, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
-    classes.append(dict(name=name, env=env, acts=acts, stream=stream, ev=[], sweeps=0.0))
+      acts = torch.rand((W + K + N_ALONE, B_each, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+    check = TwinCheck(env, plan, t_init[:args.check_buildings].cpu().numpy(),
+                      args.check_buildings) if args.check_buildings else None
+    classes.append(dict(name=name, env=env, acts=acts, stream=stream, ev=[], sweeps=0.0, check=check))
   torch.cuda.synchronize(dev)
 
   def round_(t, timed):
@@ -226,12 +280,13 @@ def mixed_config(args) -> None:
         env._now = env._now + env._step_interval
         if timed:
           c["ev"].append((e0, e1))
+        if c["check"]:
+          c["check"].record(si, c["acts"][t])
 
   def alone(t):
     """One untimed round with the classes one after the other: a class's sweep kernel with the chip to itself."""
     for c in classes:
       torch.cuda.synchronize(dev)
-      c["ev"].clear()
     for c in classes:
       with torch.cuda.stream(c["stream"]):
         env = c["env"]
@@ -245,20 +300,21 @@ def mixed_config(args) -> None:
         env.sim.step(*a, phases=4)
         env._prev_thermostat_ts = env._now
         env._now = env._now + env._step_interval
+        if c["check"]:
+          c["check"].record(si, c["acts"][t])
       torch.cuda.synchronize(dev)
       c.setdefault("alone_ms", []).append(e0.elapsed_time(e1))
 
-  n_alone = min(3, W)
-  for t in range(W - n_alone):
+  for t in range(W):
     round_(t, False)
-  for t in range(W - n_alone, W):   # the last warm-up rounds double as the per-class measurement
-    alone(t)
   torch.cuda.synchronize(dev)
   t0 = time.perf_counter()
   for t in range(W, W + K):
     round_(t, True)
   torch.cuda.synchronize(dev)
   elapsed = time.perf_counter() - t0
+  for t in range(W + K, W + K + N_ALONE):   # after the timed rounds, in the same regime: each class with the chip to itself
+    alone(t)
   per_class, alg_bytes, kern_s = {}, 0.0, 0.0
   for c in classes:
     env, li = c["env"], c["env"].sim.launch_info
@@ -270,12 +326,14 @@ def mixed_config(args) -> None:
         "grid": list(env.sim.plan.shape), "zones": env.sim.Z, "buildings": env.sim.B,
         "kernel": _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?"),
         # in the timed rounds the classes' kernels overlap on their streams (a class also waits for CUs);
-        # `alone`: the same kernel with the chip to itself (the last warm-up rounds, one class after the other)
+        # `alone`: the same kernel with the chip to itself (three rounds after the timed ones, one class after the other)
         "sweep_kernel_ms": ms, "sweep_kernel_ms_alone": float(np.mean(c["alone_ms"])) if c.get("alone_ms") else None,
         "mean_sweeps_per_env_step": float(env.info[:, 4].mean()),
         "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "roofline_frac_alone": (alg / (float(np.mean(c["alone_ms"])) * 1e-3) / 1e9 / HBM_PEAK_GBPS) if c.get("alone_ms") else None,
         "launch": li}
+    if c["check"]:
+      per_class[c["name"]]["parity_vs_oracle"] = c["check"].verify()
   zone_updates = sum(c["env"].sim.B * c["env"].sim.Z for c in classes) * K
   env_steps = sum(c["env"].sim.B for c in classes) * K
   achieved = alg_bytes / kern_s / 1e9
@@ -314,7 +372,8 @@ def policy_config(args) -> None:
   dev = torch.device("cuda", local_rank)
   B, K, W = args.buildings, args.steps, args.warmup
   plan = r9_plan()
-  env = BatchedEnvironment(plan, B, device=local_rank, holiday_calendar="us", num_days_in_episode=3)
+  env = BatchedEnvironment(plan, B, device=local_rank, holiday_calendar="us", num_days_in_episode=3,
+                           collect_info=bool(args.check_buildings))
   H, Wd = plan.shape
   Z = env.sim.Z
   ts = env.reset()
@@ -341,13 +400,25 @@ def policy_config(args) -> None:
 
   obs = ts.observation
   returns = torch.zeros((B,), dtype=torch.float32, device=dev)
+  check = None
+  if args.check_buildings and rank == 0:
+    check = TwinCheck(env, plan, t_init, args.check_buildings)
+
+  def step_once(obs):
+    a = act(obs)
+    si = env.make_step_in(env.current_simulation_timestamp) if check else None
+    ts = env.step(a)
+    if check:
+      check.record(si, a)
+    return ts
+
   for _ in range(W):
-    ts = env.step(act(obs))
+    ts = step_once(obs)
     obs = ts.observation
   barrier()
   t0 = time.perf_counter()
   for _ in range(K):
-    ts = env.step(act(obs))
+    ts = step_once(obs)
     obs = ts.observation
     returns += ts.reward
   barrier()
@@ -372,6 +443,7 @@ def policy_config(args) -> None:
                                "by a SAC-shaped actor (2 x 128 MLP, tanh-squashed Gaussian) on the environment's GPU",
                    "buildings_per_gpu": B, "grid": [H, Wd], "zones": Z, "policy": "MLP %d-128-128-4, fp32" % O,
                    "mean_return_per_step": float(returns.mean()) / K,
+                   **({"parity_vs_oracle": check.verify()} if check else {}),
                    "parallelism": f"{world} x (building shard + its own actor), no per-step collective", "launch": li},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -390,6 +462,8 @@ def main() -> None:
   ap.add_argument("--warmup", type=int, default=12)
   ap.add_argument("--buildings", type=int, default=65536, help="buildings PER GPU")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--check-buildings", type=int, default=0,
+                  help="--config mixed / policy: re-step the first N buildings (per class) on CPU-oracle twins and report the agreement")
   ap.add_argument("--iteration-limit", type=int, default=100,
                   help="Simulator.iteration_limit (100 = the reference's SB1 value; 1 is used only to "
                        "calibrate the PMC byte counters on a known traffic pattern)")

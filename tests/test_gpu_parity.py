@@ -759,3 +759,111 @@ def test_floor_plan_beyond_one_cu_against_oracle(monkeypatch):
   fp = rectangular_floor_plan((14, 9), (20, 43))
   assert fp.shape == (299, 401)
   _check_plan_against_oracle(fp, 126, "rows", 2, monkeypatch, expect_kernel=6, expect_waves=5, B=2, T=3)
+
+
+@pytest.mark.parametrize("kernel", ["auto", "lds", "stream"])
+def test_rectangular_building_without_exterior_ring(kernel, monkeypatch):
+  """SURVEY 8c G7 on the HIP path: the deprecated rectangular ``Building`` (building.py:394-605) has no
+  exterior-space ring -- its neighbour lists keep every in-bounds cell (building.py:529-545), so the
+  trim box is the whole grid and the corner / edge formulas sit on its rim.  One cold thermostat-only
+  step of the 3x3-room scenario: 100 sweeps, the reference's KAT 301.895482 (simulator_test.py:955-987)
+  and its final grid (tests/golden/rect_building_cold200.npz, from the reference's own Building)."""
+  _need_gpu()
+  import json
+  g = load("rect_building_cold200.npz")
+  h = load("h1_r9_test_cold200.npz")
+  H, W = g["conductivity"].shape
+  rs, bs = g["room_shape"], g["building_shape"]
+  label = np.full((H, W), -1, dtype=np.int64)
+  for zx in range(bs[0]):
+    for zy in range(bs[1]):
+      x0, y0 = zx * (rs[0] + 1) + 2, zy * (rs[1] + 1) + 2  # building.py:167-180
+      label[x0:x0 + rs[0], y0:y0 + rs[1]] = zx * bs[1] + zy
+  plan = FloorPlan(conductivity=g["conductivity"], heat_capacity=g["heat_capacity"], density=g["density"],
+                   exterior_space=np.zeros((H, W), bool), zone_label=label, diffusers=g["diffusers"],
+                   cv_size_cm=float(g["cv_size_cm"]), floor_height_cm=float(g["floor_height_cm"]),
+                   skip_exterior_neighbors=False)
+  prm = json.loads(str(h["params_json"]))
+  cfg = SimConfig(
+      time_step_sec=prm["dt"], convergence_threshold=prm["conv_threshold"], iteration_limit=prm["iter_limit"],
+      comfort_temp_window=(prm["comfort_lo"], prm["comfort_hi"]), eco_temp_window=(prm["eco_lo"], prm["eco_hi"]),
+      vav_max_air_flow_rate=prm["vav_max_air_flow"], vav_reheat_max_water_flow_rate=prm["vav_max_water_flow"],
+      ahu_recirculation=prm["ahu_recirc"], ahu_heating_air_temp_setpoint=prm["ahu_heat_sp"],
+      ahu_cooling_air_temp_setpoint=prm["ahu_cool_sp"], ahu_fan_differential_pressure=prm["ahu_dp"],
+      ahu_fan_efficiency=prm["ahu_eff"], ahu_max_air_flow_rate=prm["ahu_max_flow"], ahu_has_weather_sensor=False,
+      boiler_reheat_water_setpoint=prm["blr_setpoint"], boiler_water_pump_differential_head=prm["blr_head"],
+      boiler_water_pump_efficiency=prm["blr_pump_eff"], boiler_heating_rate=prm["blr_heating_rate"],
+      boiler_cooling_rate=prm["blr_cooling_rate"], initial_temp=200.0)
+  if kernel == "lds":
+    monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
+  if kernel == "stream":
+    monkeypatch.setenv("SBSIM_FORCE_STREAM_PATH", "1")
+  B = 3
+  sim = BatchedSimulator(plan, cfg, B, 12.0)
+  assert sim.launch_info["path"] == {"auto": 1, "lds": 0, "stream": 2}[kernel]
+  sim.reset()
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  si = _ffi.StepIn()
+  si.t_amb_now = si.t_amb_next = 296.0
+  si.comfort_now = si.comfort_next = 0
+  si.comfort_prev = -1
+  si.has_action = 0
+  si.occupancy, si.e_price, si.e_carbon, si.g_price, si.g_carbon = 1.0, 1e-8, 1e-8, 1e-8, 1e-8
+  sim.step(None, si, None, rew, info)
+  i = info.cpu().numpy()
+  assert (i[:, 4] == h["n_sweeps"][0]).all(), i[:, 4]      # the same scenario on both reference building classes
+  sc = sim.scalars().cpu().numpy()
+  assert np.abs(sc[:, 7] - float(g["blr_return_temp"])).max() < 1e-9
+  assert abs(float(sc[0, 7]) - 301.895482) < 1e-5
+  assert np.abs(sim.temps().cpu().numpy().reshape(B, H, W) - g["final_grid"]).max() < T_TOL
+  sim.close()
+
+
+def _run_bench(args, timeout=600):
+  import json, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, out.stdout[-2000:]
+  return json.loads(lines[0])
+
+
+def test_bench_mixed_config_line_and_its_twins():
+  """`bench.py --config mixed` (BASELINE.json configs[2]) at the full batch, two timed rounds: the JSON line
+  parses, names the three classes' kernels, and 64 buildings per class agree with their CPU-oracle twins
+  (sweep counts EQUAL, zone temperatures within 1e-8 K) at every step of the run."""
+  _need_gpu()
+  d = _run_bench(["--config", "mixed", "--buildings", "65535", "--steps", "2", "--warmup", "1", "--check-buildings", "64"])
+  assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "zone-updates/s" and d["value"] > 1e7
+  cl = d["config"]["classes"]
+  assert set(cl) == {"R9", "SB2-synth", "SB1-synth"}
+  for name, c in cl.items():
+    assert c["buildings"] == 21845 and c["sweep_kernel_ms_alone"] > 0
+    par = c["parity_vs_oracle"]
+    assert par["buildings"] == 64 and par["steps"] == 6            # 1 warm-up + 2 timed + 3 one-class-at-a-time rounds
+    assert par["sweep_count_mismatches"] == 0 and par["max_abs_dT_zone_K"] < T_TOL, (name, par)
+
+
+def test_bench_policy_config_line_and_its_twins():
+  """`bench.py --config policy` (BASELINE.json configs[4]: the batch driven by a SAC-shaped actor on the
+  same GPU): the line parses and 64 buildings agree with their oracle twins fed the actor's actions."""
+  _need_gpu()
+  d = _run_bench(["--config", "policy", "--steps", "2", "--warmup", "2", "--check-buildings", "64"])
+  assert d["n_gpus"] == 1 and d["gathered_returns"] == 65536 and d["value"] > 1e7
+  par = d["config"]["parity_vs_oracle"]
+  assert par["buildings"] == 64 and par["steps"] == 4
+  assert par["sweep_count_mismatches"] == 0 and par["max_abs_dT_zone_K"] < T_TOL, par
+
+
+def test_bench_two_gpus_when_the_box_has_them():
+  """`bench.py --gpus 2` on a box with two devices: two ranks over RCCL, 131,072 gathered returns, a
+  per-GPU rate within 5 % ... of the one-GPU line's (weak scaling: independent shards, one gather)."""
+  _need_gpu()
+  if torch.cuda.device_count() < 2:
+    pytest.skip("one GPU visible")
+  one = _run_bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+  two = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+  assert two["n_gpus"] == 2 and two["gathered_returns"] == 131072
+  assert two["value"] / 2 > 0.9 * one["value"]
