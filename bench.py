@@ -609,8 +609,16 @@ def main() -> None:
     if os.path.exists(tr):   # PMC passes of this same command (tools/collect_profiles.sh)
       with open(tr) as fh:
         t = json.load(fh)
-      result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-      result["roofline"]["traffic_source"] = t.get("source")
+      # the counters were taken on a particular kernel and state layout: a profile of another one is not this run's traffic
+      rest = (8 * 4 + 4 * 2) * Z + 16 * 16 + 8 + 4 * env.sim.O + 4
+      state_bytes = (li["state_bytes_per_env_step"] - rest) // 2
+      same_kernel = _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?") in str(t.get("kernel", ""))
+      if same_kernel and t.get("state_bytes_per_building") == state_bytes and B == 65536:
+        result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+        result["roofline"]["traffic_source"] = t.get("source")
+      else:
+        result["roofline"]["traffic_source"] = (f"profiles/traffic_latest.json is for kernel {t.get('kernel')!r}, "
+                                                f"{t.get('state_bytes_per_building')} state bytes per building, 65,536 buildings: not this run")
     if world == 1 and not args.no_cpu_baseline:
       nb_s = 2048
       # the CPU leg goes on past the GPU's K timed steps (same action distribution, same generator)

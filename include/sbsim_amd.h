@@ -280,8 +280,10 @@ int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, flo
  * reference draws from Python's global `random`; here the draws are Philox4x32-10 keyed by
  * `seed` with counter (global building index, call number, grid cell): the same random process
  * (statistically equivalent, sharding-independent), not the same stream.  p == 0 or
- * distance == 0 detaches (the reference returns early); distance == -1 (whole-room shuffle)
- * is SB_ERR_UNSUPPORTED.  sb_step then runs the shuffle between the sweep and the reward.
+ * distance == 0 detaches (the reference returns early); distance == -1 is the reference's whole-room
+ * random.shuffle (stochastic_convection_simulator.py:78-99): with p == 1 a keyed bijection on the room's
+ * cells (k_convect_all), with p < 1 SB_ERR_UNSUPPORTED (the reference then falls into a 1000-cell
+ * window).  sb_step then runs the shuffle between the sweep and the reward.
  * transposed: the plan given to sb_create is the transpose of the caller's floor plan (the host
  * picks the cheaper orientation, sb_plan_info); cells are then numbered -- and candidates
  * ordered -- as in the caller's [H, W] grid, so the shuffle does not depend on the orientation. */

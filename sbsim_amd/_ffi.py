@@ -105,7 +105,8 @@ class LaunchInfo(C.Structure):
 
 
 # sb_sweep_kernel
-SWEEP_KERNELS = {0: "k_sweep_lds", 1: "k_sweep_reg", 2: "k_sweep_reg (two wavefronts)", 3: "k_sweep_roll", 4: "k_sweep_two"}
+SWEEP_KERNELS = {0: "k_sweep_lds", 1: "k_sweep_reg", 2: "k_sweep_reg (two wavefronts)", 3: "k_sweep_roll", 4: "k_sweep_two",
+                 5: "k_sweep_band", 6: "k_sweep_stream"}
 
 
 EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",

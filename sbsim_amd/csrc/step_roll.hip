@@ -181,7 +181,7 @@ __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], 
     constexpr bool wrapped = WRAP && S + 2 * kDepth >= S1;
     constexpr int N = wrapped ? S + 2 * kDepth - NR : S + 2 * kDepth;
     PairBuf &cur = pb[pair_buf(S)], &nxt = pb[pair_buf(N)];
-#if SB_ONE_WAIT // one s_waitcnt per pair: measured slower (the second half's reads are only one step old)
+#if SB_ONE_WAIT // one s_waitcnt per pair: every LDS value of the pair is asked for here, before the next pair's reads are issued
     asm volatile("" ::"v"(cur.ud0.x), "v"(cur.A.x), "v"(cur.sm.x), "v"(cur.ud1.x), "v"(cur.lr1.x));
     __builtin_amdgcn_sched_barrier(0);
 #endif

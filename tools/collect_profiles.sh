@@ -39,8 +39,15 @@ Z, O = bench.get("config", {}).get("zones", 9), 46
 # sb_launch_info.state_bytes_per_env_step = 16*state_doubles + per-zone/scalar/obs bytes (sbsim_hip.hip)
 state_bytes = (li.get("state_bytes_per_env_step", 0) - ((8 * 4 + 4 * 2) * Z + 16 * 16 + 8 + 4 * O + 4)) // 2
 kern = "k_sweep"
-res = {"tag": tag, "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB", "kernel": kern,
-       "state_bytes_per_building": state_bytes}
+# the sweep kernel's real name, from the counter rows themselves
+kernel_name = kern
+for f in sorted(glob.glob(f"/tmp/prof_FETCH_SIZE_main_{tag}/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        if kern in r.get("Kernel_Name", ""):
+            kernel_name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sb::(anonymous namespace)::", "")
+            break
+res = {"tag": tag, "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB", "kernel": kernel_name,
+       "sweep_kernel_id": li.get("kernel"), "state_bytes_per_building": state_bytes}
 f_main, w_main = vals("FETCH_SIZE", "main", kern), vals("WRITE_SIZE", "main", kern)
 f_cal, w_cal = vals("FETCH_SIZE", "calib", kern), vals("WRITE_SIZE", "calib", kern)
 res["fetch_kib_per_launch_all"] = f_main
@@ -72,3 +79,12 @@ json.dump(res, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if not k.endswith("_all")}, indent=1))
 PY
 head -3 $out/kernel_stats.csv | cut -c1-200
+# SQ counters of the sweep kernel (instruction mix, wave cycles, LDS conflicts, instruction cache), per timed launch
+bash $PWD/tools/pmc_sweep.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
+  "SQ_WAVES SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_MISSES" > $out/pmc_sq.txt 2>&1
+# cycle stamps of one building's phases inside the sweep kernel, and the per-sweep / fixed cost split
+SBSIM_PHASE_TIMING=1 LIMS=1,2,4 timeout 600 python $PWD/tools/prof_sweeps.py 2>&1 | grep -v amdgpu.ids > $out/phase_cycles.txt
+# the same bench after 100 warm-up steps: the steady state beside the driver's transient window
+timeout 600 python $PWD/bench.py --steps 20 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_steady.json
+ls -la $out
