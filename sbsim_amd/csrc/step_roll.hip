@@ -70,7 +70,7 @@ struct Ctx {
   const double *seam;  // first tail row by step: the value under lane 63 at step s is seam[s]
   const char *cmap;    // class words: a.cmapS (uniform)
   unsigned voff;       // byte offset of the lane's NEXT class word: 8 * lane + 512 * word
-  unsigned long long w, wn, wnn; // class word (4 steps) in use / the next two, in flight
+  unsigned long long w, wn, wnn, wn3; // class word (4 steps) in use / the next three, in flight
 };
 
 // Class words hold one 16-bit field per step: the LDS byte offset of the step's coefficient set
@@ -83,14 +83,15 @@ __device__ __forceinline__ unsigned long long class_word(Ctx<NR> &x) { // global
 }
 template <int NR, int S>
 __device__ __forceinline__ lds_d2 step_set(Ctx<NR> &x) {
-  if constexpr (S % 4 == 0) { // words are read two ahead (8 steps): an L2 hit takes longer than four steps
+  if constexpr (S % 4 == 0) { // words are read three ahead (12 steps): under the hand-overs' HBM traffic an L2 hit can take > 8 steps
     x.w = x.wn;
     x.wn = x.wnn;
+    x.wnn = x.wn3;
     // after the period's last word comes step 64's (a running offset: not loop-invariant, nothing to hoist)
-    if constexpr (S == NR + kWin - 7) x.voff -= (unsigned)((NR + kWin - 3) / 4 - (kWin / 4 + 1)) * 512u;
+    if constexpr (S == NR + kWin - 11) x.voff -= (unsigned)((NR + kWin - 3) / 4 - (kWin / 4 + 1)) * 512u;
     else x.voff += 512u;
     asm volatile("" : "+v"(x.voff)); // ... as far as the compiler can tell
-    x.wnn = class_word<NR>(x);
+    x.wn3 = class_word<NR>(x);
   }
   const unsigned h = S % 4 < 2 ? (unsigned)x.w : (unsigned)(x.w >> 32);
   const unsigned off = S % 2 ? h >> 16 : h & 0xffffu;
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   x.seam = tE0 - kWin; // lane 63 works on column s - 63 at step s
   x.cmap = (const char *)a.cmapS;
   x.voff = 0;
-  x.w = x.wn = x.wnn = 0;
+  x.w = x.wn = x.wnn = x.wn3 = 0;
   // the lane's tail cells (static per floor plan): table offsets of their coefficient sets
   // (two 16-bit halves) and of their classes (two bytes)
   const bool tactive = tail_col<NR>(lane, 0) >= 0; // the lane owns two tail columns
@@ -319,9 +320,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
       for (int g = 0; g < kASlots; ++g) amapw[g] = amap[o + g * 64];
       x.voff = (unsigned)opaque(lane * 8);
-      x.wn = class_word<NR>(x); // the first two class words of the ramp-up
+      x.wn = class_word<NR>(x); // the first three class words of the ramp-up
       x.voff += 512u;
       x.wnn = class_word<NR>(x);
+      x.voff += 512u;
+      x.wn3 = class_word<NR>(x);
     }
     double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 64; // [T][NR]
     __builtin_amdgcn_sched_barrier(0);
