@@ -280,10 +280,12 @@ int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, flo
  * reference draws from Python's global `random`; here the draws are Philox4x32-10 keyed by
  * `seed` with counter (global building index, call number, grid cell): the same random process
  * (statistically equivalent, sharding-independent), not the same stream.  p == 0 or
- * distance == 0 detaches (the reference returns early); distance == -1 is the reference's whole-room
- * random.shuffle (stochastic_convection_simulator.py:78-99): with p == 1 a keyed bijection on the room's
- * cells (k_convect_all), with p < 1 SB_ERR_UNSUPPORTED (the reference then falls into a 1000-cell
- * window).  sb_step then runs the shuffle between the sweep and the reward.
+ * distance == 0 detaches (the reference returns early); distance == -1 with p == 1 is the reference's
+ * whole-room random.shuffle (stochastic_convection_simulator.py:78-99): a keyed bijection on the room's
+ * cells (k_convect_all); with p < 1 the reference falls into its 1000-cell window (:108-109) and so does
+ * this.  Windows of more than 64 offsets (distance >= 20) draw the partner by rejection sampling inside
+ * the disc -- uniform over the reference's candidate list.  Rooms of more than 2047 cells and distances
+ * above 1000 are SB_ERR_UNSUPPORTED.  sb_step then runs the shuffle between the sweep and the reward.
  * transposed: the plan given to sb_create is the transpose of the caller's floor plan (the host
  * picks the cheaper orientation, sb_plan_info); cells are then numbered -- and candidates
  * ordered -- as in the caller's [H, W] grid, so the shuffle does not depend on the orientation. */

@@ -26,6 +26,34 @@ def offsets(distance: int):
           if dx * dx + dy * dy <= distance]
 
 
+WIDE_TRIAL_BLOCKS = 16   # rejection sampling: 4 candidates per Philox block
+
+
+def wide_partner(gb: int, call: int, g0: int, seed: int, distance: int, accept):
+  """The device's partner choice for windows of more than 64 offsets (distance >= 20; distance = -1
+  with p < 1 is the reference's 1000: stochastic_convection_simulator.py:108-109): rejection sampling --
+  (dx, dy) uniform in [-R, R]^2, R = floor(sqrt(distance)), accepted when dx^2 + dy^2 <= distance and
+  the cell is in the room (`accept(dx, dy)` -> the partner's index in the room, or -1).  Uniform over the
+  reference's candidate list (the window [-d, d) does not cut the disc: R < d).  Draws: Philox blocks
+  with counter word 3 = g0 | (block + 1) << 20, each word one candidate; no candidate accepted after
+  WIDE_TRIAL_BLOCKS blocks: the cell stays (None)."""
+  M = 0xFFFFFFFF
+  R = int(np.floor(np.sqrt(distance)))
+  one = lambda v: np.array([v], dtype=np.uint64)
+  for blk in range(WIDE_TRIAL_BLOCKS):
+    w = philox4x32_10(one(gb & M), one(gb >> 32), one(call), one(g0 | ((blk + 1) << 20)), seed & M, (seed >> 32) & M)
+    for k in range(4):
+      x = int(w[k][0])
+      dx = (((x & 0xFFFF) * (2 * R + 1)) >> 16) - R
+      dy = (((x >> 16) * (2 * R + 1)) >> 16) - R
+      if dx * dx + dy * dy > distance:
+        continue
+      j = accept(dx, dy)
+      if j >= 0:
+        return j
+  return None
+
+
 def whole_room_permutation(n: int, gb: int, call: int, z: int, seed: int) -> np.ndarray:
   """dest[r] of the device's whole-room shuffle (k_convect_all, generators.hip): a keyed bijection on
   the ranks 0..n-1 of a room's cells in raster order -- three rounds of (odd multiply, add,
@@ -59,7 +87,10 @@ class ConvectionOracle:
     self.zones = [np.asarray(c, dtype=np.int64) for c in zone_cell_lists]
     self.H, self.W, self.p, self.seed, self.first = H, W, float(p), int(seed), int(first_building)
     self.whole_room = distance == -1 and float(p) == 1.0   # stochastic_convection_simulator.py:78-99
-    self.off = [] if self.whole_room else offsets(distance)
+    if distance == -1 and not self.whole_room:
+      distance = 1000                                       # :108-109
+    self.distance = distance
+    self.off = [] if self.whole_room else (offsets(distance) if distance <= 19 else None)   # None: more than 64 offsets, the wide window
     self.room = np.full(H * W, -1, dtype=np.int64)
     self.local = np.full(H * W, -1, dtype=np.int64)
     for z, cells in enumerate(self.zones):
@@ -80,12 +111,22 @@ class ConvectionOracle:
       if u[i] > self.p:
         continue
       x, y = divmod(int(cells[i]), self.W)
-      cand = []
-      for dx, dy in self.off:
-        xx, yy = x + dx, y + dy
-        if 0 <= xx < self.H and 0 <= yy < self.W and self.room[xx * self.W + yy] == z:
-          cand.append(int(self.local[xx * self.W + yy]))
-      other = cand[(int(w[1][i]) * len(cand)) >> 32]
+      if self.off is None:   # more than 64 offsets: rejection sampling (the device's wide path)
+        def accept(dx, dy, x=x, y=y):
+          xx, yy = x + dx, y + dy
+          if 0 <= xx < self.H and 0 <= yy < self.W and self.room[xx * self.W + yy] == z:
+            return int(self.local[xx * self.W + yy])
+          return -1
+        other = wide_partner(gb, call, int(cells[i]), self.seed, self.distance, accept)
+        if other is None:
+          other = i
+      else:
+        cand = []
+        for dx, dy in self.off:
+          xx, yy = x + dx, y + dy
+          if 0 <= xx < self.H and 0 <= yy < self.W and self.room[xx * self.W + yy] == z:
+            cand.append(int(self.local[xx * self.W + yy]))
+        other = cand[(int(w[1][i]) * len(cand)) >> 32]
       if other != i:
         seq.append((int(w[2][i]), i, other))
     seq.sort()

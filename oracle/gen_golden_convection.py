@@ -21,7 +21,10 @@ from oracle import refshim
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 H, W = 16, 20
-CASES = [(1.0, 5), (0.5, 5), (1.0, 2), (1.0, -1)]   # the last: the whole-room shuffle (:78-99)
+# (1.0, -1): the whole-room shuffle (:78-99); (0.5, -1): distance -1 with p < 1 falls into _shuffle_max_dist
+# with a 1000-cell window (:108-109: every cell within sqrt(1000) = 31.6 cells); (1.0, 20): a window of 69
+# offsets (squared distance <= 20).  New cases go at the END: a case's seed is 1234 + its index.
+CASES = [(1.0, 5), (0.5, 5), (1.0, 2), (1.0, -1), (0.5, -1), (1.0, 20)]
 TRIALS = 400
 
 

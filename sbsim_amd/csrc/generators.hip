@@ -104,6 +104,10 @@ struct ConvArgs {
   const ConvCell *cells; // every zone's cells, within a zone by increasing state index: lanes that
                          // read / write neighbouring cells of the list touch neighbouring memory
   int B, Z, W, n_off, max_room;
+  // windows of more than 64 offsets (distance >= 20; distance = -1 with p < 1 is the reference's 1000):
+  // the partner by rejection sampling inside the disc (oracle/convection_oracle.py wide_partner)
+  int wide, wide_r, wide_d, H, transposed;
+  const short *room; // [N] the cell's room in the handle's grid (-1: none)
   double p;
   uint64_t seed;
   long long first_building;
@@ -176,7 +180,25 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
           philox4x32_10(c, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
           const double u = (double)(c[0] >> 8) * (1.0 / 16777216.0);
           int other = i;
-          if (!(u > o.p)) { // :119
+          if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table
+            const int xh = cc[q].gh / o.W, yh = cc[q].gh - xh * o.W, span = 2 * o.wide_r + 1;
+            bool found = false;
+            for (int blk = 0; blk < 16 && !found; ++blk) {
+              uint32_t t[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc[q].g0 | ((uint32_t)(blk + 1) << 20)};
+              philox4x32_10(t, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int dx = (int)(((t[k] & 0xffffu) * (uint32_t)span) >> 16) - o.wide_r;
+                const int dy = (int)(((t[k] >> 16) * (uint32_t)span) >> 16) - o.wide_r;
+                const int hx = xh + (o.transposed ? dy : dx), hy = yh + (o.transposed ? dx : dy);
+                if (!found && dx * dx + dy * dy <= o.wide_d && hx >= 0 && hx < o.H && hy >= 0 && hy < o.W &&
+                    (int)o.room[hx * o.W + hy] == z) {
+                  other = o.local[hx * o.W + hy];
+                  found = true;
+                }
+              }
+            }
+          } else if (!(u > o.p)) { // :119
             const int cnt = __popcll(cc[q].mask);
             int pick = (int)(((unsigned long long)c[1] * (unsigned long long)cnt) >> 32); // uniform in [0, cnt)
             const int k = kth_set_bit(cc[q].mask, pick);
@@ -338,9 +360,10 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   if (first_building < 0) return fail(SB_ERR_INVALID, "sb_convection_attach: first_building must be >= 0");
   if (p == 0.0 || distance == 0) { h->conv_attached = false; return SB_OK; } // stochastic_convection_simulator.py:70-71
   const bool whole_room = distance == -1 && p == 1.0; // stochastic_convection_simulator.py:78: the special case
-  if (!whole_room && (distance < 0 || distance > 64))
-    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: distance must be 1..64, or -1 with p = 1 (the whole-room "
-                                    "shuffle; distance = -1 with p < 1 is a 1000-cell window in the reference: not implemented)");
+  if (distance == -1 && !whole_room) distance = 1000; // :108-109: then the window is 1000 cells
+  if (!whole_room && (distance < 0 || distance > 1000))
+    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: distance must be 1..1000, or -1 (p = 1: the whole-room shuffle, "
+                                    "p < 1: the reference's 1000-cell window)");
   SB_ON_DEVICE(h->device);
   const Dev &d = h->d;
   if (whole_room) distance = 0; // no offset window
@@ -348,15 +371,18 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   // (in the order of the caller's grid: the handle may hold the transposed floor plan)
   if (d.N >= (1 << 20)) return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: more than 2^20 grid cells");
   std::vector<int> odx, ody, offd; // offsets in the handle's coordinates, linear steps
-  for (int dx = -distance; dx < distance; ++dx)
-    for (int dy = -distance; dy < distance; ++dy)
-      if (dx * dx + dy * dy <= distance) {
+  const int reach = std::min(distance, 32); // dx^2 <= distance <= 1000
+  for (int dx = -reach; dx < reach; ++dx)
+    for (int dy = -reach; dy < reach; ++dy)
+      if (dx >= -distance && dy >= -distance && dx * dx + dy * dy <= distance) {
         odx.push_back(transposed ? dy : dx);
         ody.push_back(transposed ? dx : dy);
         offd.push_back(odx.back() * d.W + ody.back());
       }
-  if (offd.size() > 64)
-    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: more than 64 candidate offsets (distance <= 17)");
+  // more than 64 offsets (distance >= 20): no offset table, no per-cell mask -- the kernel samples the
+  // partner by rejection inside the disc (the half-open box [-d, d) no longer cuts it: sqrt(d) < d)
+  const bool wide = offd.size() > 64;
+  if (wide) { odx.clear(); ody.clear(); offd.assign(1, 0); }
   std::vector<int> room((size_t)d.N, -1), local((size_t)d.N, -1);
   for (int z = 0; z < d.Z; ++z)
     for (int i = h->h_zone_off[z]; i < h->h_zone_off[z + 1]; ++i) room[h->h_zone_cells[i]] = z;
@@ -390,6 +416,14 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   }
   if (max_room > kConvMaxRoom)
     return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: a room has more than 2047 cells");
+  {
+    std::vector<short> room16(room.size());
+    for (size_t i = 0; i < room.size(); ++i) room16[i] = (short)room[i];
+    if (h->conv_room.p) { (void)hipFree(h->conv_room.p); h->conv_room.p = nullptr; }
+    const int rc16 = upload(h->conv_room, room16.data(), room16.size());
+    if (rc16 != SB_OK) return rc16;
+  }
+  h->conv_wide = wide; h->conv_wide_d = distance; h->conv_transposed = transposed != 0;
   for (DevBuf<int> *buf : {&h->conv_local, &h->conv_off, &h->conv_by_rank}) {
     if (buf->p) (void)hipFree(buf->p); // attached before: replace
     buf->p = nullptr;
@@ -425,6 +459,8 @@ int sb_launch_convection(sb_handle *h, hipStream_t stream) {
   o.zone_off = h->zone_off.p; o.local = h->conv_local.p; o.off = h->conv_off.p; o.cells = h->conv_cells.p;
   o.B = d.B; o.Z = d.Z; o.W = d.W; o.n_off = h->conv_n_off; o.max_room = h->conv_max_room;
   o.p = h->conv_p; o.seed = h->conv_seed; o.first_building = h->conv_first; o.call = h->conv_calls++;
+  o.wide = h->conv_wide ? 1 : 0; o.wide_d = h->conv_wide_d; o.wide_r = (int)std::floor(std::sqrt((double)h->conv_wide_d));
+  o.H = d.H; o.transposed = h->conv_transposed ? 1 : 0; o.room = h->conv_room.p;
   const size_t lds = (size_t)o.max_room * (16 + 8 + 4);
   // cells per lane: workgroups of about 256 lanes; the grid is exactly what is resident at once
   // (the runtime's occupancy for this instantiation), so that every workgroup gets the same number

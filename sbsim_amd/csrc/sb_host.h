@@ -100,6 +100,9 @@ struct sb_handle {
   DevBuf<int> conv_local, conv_off; // per grid cell: index in its room's list; the offset table as linear steps
   DevBuf<int> conv_by_rank;         // whole-room shuffle: list index of the room's cell with raster rank r
   bool conv_whole_room = false;
+  bool conv_wide = false, conv_transposed = false; // a window of more than 64 offsets: rejection sampling
+  int conv_wide_d = 0;
+  DevBuf<short> conv_room;          // per grid cell: its room (-1: none)
   DevBuf<ConvCell> conv_cells;
   double conv_p = 0.0;
   int conv_n_off = 0, conv_max_room = 0;

@@ -31,9 +31,13 @@ def test_offset_window_is_the_reference_one():
   assert len(off) == 21 and (0, 0) in off and (2, 1) in off and (-1, -2) in off and (2, 2) not in off
   assert off == sorted(off)                       # (dx, dy) raster order = the reference's loop order
   assert len(offsets(2)) == 9 and offsets(1) == [(-1, 0), (0, -1), (0, 0)]    # the window is half-open: [-d, d)
+  # from distance 20 on the window has more than 64 offsets (the device then samples by rejection); the
+  # half-open box no longer cuts the disc: floor(sqrt(d)) < d
+  assert len(offsets(19)) == 61 and len(offsets(20)) == 69
+  assert all(max(abs(dx), abs(dy)) <= 4 for dx, dy in offsets(20)) and len(offsets(1000)) == 3149
 
 
-@pytest.mark.parametrize("case", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
 def test_restatement_matches_reference_displacement_statistics(case):
   """24,000 tracked values on each side.  Bin probabilities <= 0.25 -> sigma of a difference
   <= sqrt(2 * 0.25 * 0.75 / 24000) = 0.004; 0.02 is five sigma."""
@@ -79,10 +83,13 @@ def _need_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel,distance", [("reg", 5), ("lds", 5), ("reg", -1), ("lds-columns", -1)])
-def test_device_shuffle_equals_its_restatement_inside_a_rollout(kernel, distance, monkeypatch):
+@pytest.mark.parametrize("kernel,distance,prob", [("reg", 5, 1.0), ("lds", 5, 1.0), ("reg", -1, 1.0), ("lds-columns", -1, 1.0),
+                                                  ("reg", -1, 0.5), ("lds-columns", -1, 0.5), ("reg", 20, 1.0), ("lds-columns", 20, 0.7)])
+def test_device_shuffle_equals_its_restatement_inside_a_rollout(kernel, distance, prob, monkeypatch):
   """R9, SB1 physics, convection p = 1 / distance = 5 (sim_config.gin:36-39) -- or the whole-room
-  shuffle, distance = -1 (stochastic_convection_simulator.py:78-99) -- after every FD update: sweep
+  shuffle, distance = -1 (stochastic_convection_simulator.py:78-99); or a window of more than 64 offsets
+  (distance 20; distance = -1 with p < 1 = the reference's 1000-cell window, :108-109), where the device
+  samples the partner by rejection -- after every FD update: sweep
   counts, zone temperatures and the final grid against oracle twins whose grids get the
   restatement's shuffle after every step."""
   _need_gpu()
@@ -105,9 +112,9 @@ def test_device_shuffle_equals_its_restatement_inside_a_rollout(kernel, distance
                          orientation="columns" if kernel == "lds-columns" else "auto")
   assert sim.launch_info["path"] == (1 if kernel == "reg" else 0)
   assert sim.transposed or kernel != "lds-columns"     # the permutation is defined on the CALLER's raster order
-  sim.convection_attach(1.0, distance, seed=4242, first_building=first)
+  sim.convection_attach(prob, distance, seed=4242, first_building=first)
   sim.reset(temps=torch.tensor(init.reshape(B, -1), dtype=torch.float64, device="cuda"))
-  conv = ConvectionOracle(fp.zone_cell_lists(), 68, 98, 1.0, distance, seed=4242, first_building=first)
+  conv = ConvectionOracle(fp.zone_cell_lists(), 68, 98, prob, distance, seed=4242, first_building=first)
   plan, prm = oracle_plan(p), oracle_params(g["params_json"])
   twins = [orc.OracleBuilding(plan, prm, 0.0, reset_temps=init[b].reshape(-1)) for b in range(B)]
   obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
@@ -153,8 +160,9 @@ def test_convection_attach_argument_checks():
   sim.convection_attach(0.0, 5, seed=1)       # p == 0: the reference returns early -> detached
   sim.convection_attach(1.0, 0, seed=1)
   sim.convection_attach(1.0, -1, seed=1)      # the whole-room shuffle (stochastic_convection_simulator.py:78)
-  with pytest.raises(_ffi.SbsimError, match="whole-room"):
-    sim.convection_attach(0.5, -1, seed=1)    # distance = -1 with p < 1: the reference's 1000-cell window, not implemented
+  sim.convection_attach(0.5, -1, seed=1)      # distance = -1 with p < 1: the reference's 1000-cell window (:108-109)
+  with pytest.raises(_ffi.SbsimError, match="distance must be"):
+    sim.convection_attach(0.5, 1001, seed=1)
   with pytest.raises(_ffi.SbsimError, match=r"p must be in \[0, 1\]"):
     sim.convection_attach(1.5, 5, seed=1)
   sim.close()
