@@ -20,7 +20,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   done
 done
 python - "$tag" "$out" "$WARM" <<'PY'
-import sys, glob, csv, json
+import sys, glob, csv, json, re
 tag, out, warm = sys.argv[1], sys.argv[2], int(sys.argv[3])
 def vals(ctr, variant, kernel):
     v = []
@@ -44,7 +44,8 @@ kernel_name = kern
 for f in sorted(glob.glob(f"/tmp/prof_FETCH_SIZE_main_{tag}/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         if kern in r.get("Kernel_Name", ""):
-            kernel_name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sb::(anonymous namespace)::", "")
+            m = re.search(r"k_sweep\w*(<[^>]*>)?", r["Kernel_Name"])
+            kernel_name = m.group(0) if m else kern
             break
 res = {"tag": tag, "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB", "kernel": kernel_name,
        "sweep_kernel_id": li.get("kernel"), "state_bytes_per_building": state_bytes}
