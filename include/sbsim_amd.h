@@ -57,7 +57,8 @@ typedef enum sb_status {
   SB_ERR_INVALID = -1,    /* bad argument (reference: ValueError) */
   SB_ERR_NO_DEVICE = -2,  /* no HIP device / wrong architecture */
   SB_ERR_HIP = -3,        /* HIP runtime error, see sb_last_error() */
-  SB_ERR_TOO_LARGE = -4,  /* one building does not fit the 160 KiB LDS of a CU */
+  SB_ERR_TOO_LARGE = -4,  /* no sweep kernel holds the floor plan: more than 1,024 rows in this orientation, or seam rows
+                           * (rows / 64 x columns x 16 B) + zone sums beyond 160 KiB of LDS (step_stream.hip) */
   SB_ERR_UNSUPPORTED = -5 /* a reference option this library does not implement */
 } sb_status;
 

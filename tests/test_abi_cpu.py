@@ -84,6 +84,39 @@ def test_plan_info_picks_the_step_kernel_without_a_gpu():
   assert rc == 0 and one["path"] == 1 and one["waves_per_building"] == 1 and one["kernel"] == 1
 
 
+def test_plan_info_for_plans_beyond_one_cu_and_the_opt_in_kernel(monkeypatch):
+  """Host-only planning of this round's kernels: a 299 x 401 plan (0.96 MB of state) goes to the streaming
+  kernel on five wavefronts, its LDS (seam rows + zone sums) leaves room for two workgroups per CU; a plan
+  of more than 1,024 rows in one orientation still runs in the other and is SB_ERR_TOO_LARGE when both
+  are too long; SBSIM_BAND_PATH=1 puts a 107-row plan on two wavefronts (step_band.hip), two buildings per CU."""
+  import numpy as np
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  big = FloorPlan.from_file_input(rectangular_floor_plan((14, 9), (20, 43)), Materials.sb1(), 10.0, 300.0)
+  assert big.shape == (299, 401)
+  rc, info = _plan_info(big, n_obs=397, n_buildings=4096)
+  assert rc == 0 and info["path"] == 2 and info["kernel"] == 6 and info["waves_per_building"] == 5
+  assert info["sweep_steps"] == 64 * 4 + 400 + 63
+  assert 2 * ((info["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
+  assert info["workgroups"] == 512 and info["algorithmic_bytes_per_env_step"] == 8 * 299 * 401 + 24 * 126 + 8 + 4 * 397 + 44
+  tall = FloorPlan.from_file_input(rectangular_floor_plan((1, 1), (1119, 20)), Materials.sb1(), 10.0, 300.0)   # 1,125 x 26
+  rc, t_rows = _plan_info(tall, n_obs=22)
+  assert rc == -4 and b"1,024 rows" in _ffi.load().sb_last_error()      # SB_ERR_TOO_LARGE in this orientation ...
+  rc, t_cols = _plan_info(tall.transposed(), n_obs=22)
+  assert rc == 0 and t_cols["kernel"] == 6 and t_cols["waves_per_building"] == 1   # ... 24 rows x 1,123 columns in the other
+  huge = FloorPlan.from_file_input(rectangular_floor_plan((1, 1), (514, 1094)), Materials.sb1(), 10.0, 300.0)  # 520 x 1,100
+  rc, _ = _plan_info(huge, n_obs=22)
+  assert rc == -4 and b"seam rows" in _ffi.load().sb_last_error()        # nine wavefronts x 1,100 columns of seam rows: > 160 KiB
+  rc, _ = _plan_info(huge.transposed(), n_obs=22)
+  assert rc == -4 and b"1,024 rows" in _ffi.load().sb_last_error()
+  sb2 = FloorPlan.from_file_input(rectangular_floor_plan((8, 5), (12, 14)), Materials.sb1(), 10.0, 300.0)
+  rc, two = _plan_info(sb2, n_obs=3 * 40 + 19)
+  assert rc == 0 and two["kernel"] == 4
+  monkeypatch.setenv("SBSIM_BAND_PATH", "1")
+  rc, band = _plan_info(sb2, n_obs=3 * 40 + 19)
+  assert rc == 0 and band["kernel"] == 5 and band["waves_per_building"] == 2 and band["sweep_steps"] == 80
+  assert 2 * ((band["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
+
+
 def test_plan_checks_reject_bad_tables_without_a_gpu():
   """Host-side validation shared by sb_plan_info and sb_create: status codes, not crashes."""
   import numpy as np
