@@ -238,15 +238,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   constexpr int kNL = lds_slots(NR), kAS = a_stride(NR), kNAR = NR - kNL > 0 ? NR - kNL : 2;
 
   double *tabc = lds;                      // [kTS][4]: bU bD bL bR per coefficient set
-  double *tap = lds + 4 * kTS;             // [kTS] ap by class
-  double *gtab = lds + 5 * kTS;            // [kTS] g by class (this building)
+  double *tapg = lds + 4 * kTS;            // [kTS][2]: (ap, g) by class; g of this building -- one ds_read_b128 per cell of the A pass
   double *tE0 = lds + a.r_seam + 2;        // the first tail row by column ([2 guards | NR | 2 guards]): lane 63's lower neighbours
   double *A = lds + a.r_A;                 // [64][kAS]; after the sweeps: zone sums [Z+1][ZRS]
   // every byte of LDS starts finite: reads next to the arrays' ends are multiplied by 0
   for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0;
   __builtin_amdgcn_wave_barrier();
   for (int i = lane; i < 4 * kTS; i += 64) tabc[i] = i < 4 * a.ncset ? a.csetab[i] : 0.0;
-  if (lane < kTS) tap[lane] = lane <= a.ncls ? a.ctab[lane * 8 + 4] : 0.0; // row `ncls` is the pad class
+  if (lane < kTS) tapg[2 * lane] = lane <= a.ncls ? a.ctab[lane * 8 + 4] : 0.0; // row `ncls` is the pad class
   __builtin_amdgcn_wave_barrier();
 
   const sb_params &p = a.p;
@@ -332,7 +331,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // exterior-space cells outside the trim box all become t_now in the first sweep
     // (simulator.py:256-258); their largest |delta| follows from their extreme values
     const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0;
-    if (lane < kTS) gtab[lane] = nx_g;
+    if (lane < kTS) tapg[2 * lane + 1] = nx_g;
     double tv[kTailMax][2]; // the lane's tail cells: current values
 #pragma unroll
     for (int t = 0; t < kTailMax; ++t)
@@ -349,7 +348,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       for (int k = 0; k < 2; ++k)
         if (t < a.T && tactive) {
           const int c8 = (tcls8[t] >> (8 * k)) & 0xff;
-          At[t][k] = fma(*(const double *)((const char *)tap + c8), tv[t][k], *(const double *)((const char *)gtab + c8));
+          const d2 pg = *(const d2 *)((const char *)tapg + 2 * c8);
+          At[t][k] = fma(pg.x, tv[t][k], pg.y);
         }
 
     // A = ap*Tprev + g for every cell of the lane's row (E = Tprev before the first sweep); slot j
@@ -360,29 +360,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const unsigned long long(&cwa)[kASlots] = amapw;
       double *Aw = A + (size_t)R * kAS;
       // groups of 8, software-pipelined: the table reads of group g+1 are issued before the A
-      // values of group g are written (the compiler cannot prove that A and the tables do not alias)
+      // values of group g are written (the compiler cannot prove that A and the tables do not alias).
+      // One ds_read_b128 per cell ((ap, g) of its class); slots (j, j + 1), j odd, sit at the even
+      // position j + 1 of the rotated row: one ds_write_b128 per pair.
       constexpr int kGroups = (NR + 7) / 8;
-      double ap[2][8], gg[2][8];
-      auto fetch = [&](int g, double (&pa)[8], double (&pg)[8]) {
+      d2 pg[2][8];
+      auto fetch = [&](int g, d2 (&pp)[8]) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int j = min(8 * g + k, NR - 1);
-          const int c8 = (int)((cwa[j >> 3] >> (8 * (j & 7))) & 0xffull);
-          pa[k] = *(const double *)((const char *)tap + c8);
-          pg[k] = *(const double *)((const char *)gtab + c8);
+          const unsigned c16 = (unsigned)((cwa[j >> 3] >> (8 * (j & 7))) & 0xffull) * 2u;
+          pp[k] = *(const d2 *)((const char *)tapg + c16);
         }
       };
-      fetch(0, ap[0], gg[0]);
+      fetch(0, pg[0]);
+      double carry = 0.0; // A of an odd slot, waiting for its even partner
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
-        if (g + 1 < kGroups) fetch(g + 1, ap[(g + 1) & 1], gg[(g + 1) & 1]);
+        if (g + 1 < kGroups) fetch(g + 1, pg[(g + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (8 * g + k < NR) {
-            const double av = fma(ap[g & 1][k], e[8 * g + k], gg[g & 1][k]);
-            const int q = (8 * g + k + 1) % NR;
-            if (q < kNL) Aw[q] = av;
+            const int j = 8 * g + k;
+            const double av = fma(pg[g & 1][k].x, e[j], pg[g & 1][k].y);
+            const int q = (j + 1) % NR; // position in the rotated row
+            if (j % 2 == 1 && j + 1 < NR && q + 1 < kNL) carry = av;                    // (q even) with slot j + 1: one 16-byte write
+            else if (j % 2 == 0 && j > 0 && q < kNL && q - 1 >= 0 && (q - 1) % 2 == 0) *(d2 *)(Aw + q - 1) = d2{carry, av};
+            else if (q < kNL) Aw[q] = av;
             else Areg[q - kNL] = av;
           }
         __builtin_amdgcn_sched_barrier(0);
