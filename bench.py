@@ -361,8 +361,9 @@ def policy_config(args) -> None:
   and the host-side step inputs.  tf-agents is not installable here: the loop makes the same env API
   calls (`reset()`, `step(action)` -> TimeStep) a tf-agents driver would."""
   rank, local_rank, world = sd.env_rank_world()
+  local_rank = sd.device_index(local_rank)
   torch.cuda.set_device(local_rank)
-  distributed = sd.init_process_group("nccl")
+  distributed = sd.init_process_group(sd.backend_for_gpu())
   if distributed:
     import torch.distributed as dist
     if dist.get_world_size() != args.gpus:
@@ -485,8 +486,9 @@ def main() -> None:
     return policy_config(args)
 
   rank, local_rank, world = sd.env_rank_world()
+  local_rank = sd.device_index(local_rank)      # (SBSIM_BENCH_SHARE_GPU=1: ranks share the visible devices)
   torch.cuda.set_device(local_rank)
-  distributed = sd.init_process_group("nccl")   # "nccl" is RCCL on ROCm
+  distributed = sd.init_process_group(sd.backend_for_gpu())   # "nccl" is RCCL on ROCm
   if distributed:
     import torch.distributed as dist
     if dist.get_world_size() != args.gpus:
@@ -586,7 +588,8 @@ def main() -> None:
                                "(68x98 CVs, 9 zones), random setpoint actions, sinusoid weather",
                    "buildings_per_gpu": B, "grid": [H, Wd], "zones": Z,
                    "mean_sweeps_per_env_step": float(sweeps.item()) / (B * K),
-                   "parallelism": f"{world} x independent building shards, no data-path collective",
+                   "parallelism": f"{world} x independent building shards, no data-path collective"
+                                  + (" (SBSIM_BENCH_SHARE_GPU: ranks share a device, gloo -- a plumbing run, not a scaling number)" if sd.share_gpu() else ""),
                    "return_gather_ms": gather_ms, "launch": li},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,

@@ -46,6 +46,27 @@ def shard_seed(base_seed: int, rank: int) -> int:
   return base_seed + rank
 
 
+def share_gpu() -> bool:
+  """Developer / test mode (SBSIM_BENCH_SHARE_GPU=1): the ranks of one node share the visible GPUs
+  (rank -> device local_rank mod device count) and talk over gloo with host-staged collectives -- RCCL
+  refuses two ranks on one device.  Exercises the N > 1 code path of bench.py on a one-GPU box."""
+  return os.environ.get("SBSIM_BENCH_SHARE_GPU") == "1"
+
+
+def device_index(local_rank: int) -> int:
+  if share_gpu() and torch.cuda.is_available():
+    return local_rank % torch.cuda.device_count()
+  return local_rank
+
+
+def backend_for_gpu() -> str:
+  return "gloo" if share_gpu() else "nccl"   # "nccl" is RCCL on ROCm
+
+
+def _host_staged(t: torch.Tensor) -> bool:
+  return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def gather_returns(local_returns: torch.Tensor, n_buildings_total: int) -> torch.Tensor:
   """All-gathers the per-building episode returns into global building order.
 
@@ -60,17 +81,20 @@ def gather_returns(local_returns: torch.Tensor, n_buildings_total: int) -> torch
   widest = max(hi - lo for lo, hi in sizes)
   lo, hi = sizes[rank]
   assert local_returns.numel() == hi - lo, (local_returns.numel(), lo, hi)
-  padded = torch.zeros((widest,), dtype=local_returns.dtype, device=local_returns.device)
-  padded[: hi - lo] = local_returns
+  staged = _host_staged(local_returns)
+  src = local_returns.cpu() if staged else local_returns
+  padded = torch.zeros((widest,), dtype=src.dtype, device=src.device)
+  padded[: hi - lo] = src
   parts: List[torch.Tensor] = [torch.empty_like(padded) for _ in range(world)]
   dist.all_gather(parts, padded)
-  return torch.cat([p[: h - l] for p, (l, h) in zip(parts, sizes)])
+  out = torch.cat([p[: h - l] for p, (l, h) in zip(parts, sizes)])
+  return out.to(local_returns.device) if staged else out
 
 
 def max_over_ranks(seconds: float, device: torch.device) -> float:
   """Wall time of the slowest rank (bench.py contract)."""
   if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
     return seconds
-  t = torch.tensor([seconds], dtype=torch.float64, device=device)
+  t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
   dist.all_reduce(t, op=dist.ReduceOp.MAX)
   return float(t.item())

@@ -857,6 +857,19 @@ def test_bench_policy_config_line_and_its_twins():
   assert par["sweep_count_mismatches"] == 0 and par["max_abs_dT_zone_K"] < T_TOL, par
 
 
+def test_bench_two_ranks_sharing_one_gpu(monkeypatch):
+  """The N > 1 code path of bench.py on a one-GPU box (SBSIM_BENCH_SHARE_GPU=1: both ranks on device 0, gloo
+  with host-staged collectives instead of RCCL): self-launch under torch.distributed.run, per-rank shards
+  and seeds, barrier-bracketed timing, max over ranks, the gathered returns of both ranks, one JSON line."""
+  _need_gpu()
+  monkeypatch.setenv("SBSIM_BENCH_SHARE_GPU", "1")
+  d = _run_bench(["--gpus", "2", "--buildings", "8192", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"])
+  assert d["n_gpus"] == 2 and d["gathered_returns"] == 16384 and d["scaling"] == "weak"
+  assert d["config"]["buildings_per_gpu"] == 8192 and d["value"] > 1e6 and "share a device" in d["config"]["parallelism"]
+  p = _run_bench(["--config", "policy", "--gpus", "2", "--buildings", "4096", "--steps", "2", "--warmup", "1"])
+  assert p["n_gpus"] == 2 and p["gathered_returns"] == 8192
+
+
 def test_bench_two_gpus_when_the_box_has_them():
   """`bench.py --gpus 2` on a box with two devices: two ranks over RCCL, 131,072 gathered returns, a
   per-GPU rate within 5 % ... of the one-GPU line's (weak scaling: independent shards, one gather)."""
