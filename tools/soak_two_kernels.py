@@ -9,9 +9,13 @@ if os.environ.get("PLAN"):   # PLAN=SB2-synth / SB1-synth: the two-rows-per-lane
     _, rooms, shape = next(c for c in MIXED_CLASSES if c[0] == os.environ["PLAN"])
     plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
 envs = []
+# FIRST=band / stream: that kernel (step_band.hip / step_stream.hip) instead of the library's choice, against the LDS-grid kernel
+first = {"band": "SBSIM_BAND_PATH", "stream": "SBSIM_FORCE_STREAM_PATH"}.get(os.environ.get("FIRST", ""))
 for force in (False, True):
     if force: os.environ["SBSIM_FORCE_LDS_PATH"] = "1"
+    if first and not force: os.environ[first] = "1"
     e = BatchedEnvironment(plan, B, holiday_calendar="us", collect_info=True, num_days_in_episode=2)
+    if first: os.environ.pop(first, None)
     e.reset(); envs.append(e)
 gen = torch.Generator(device="cuda"); gen.manual_seed(3)
 mism = 0; worst = 0.0
