@@ -54,7 +54,7 @@ struct Dev {
   unsigned S_magic;        // floor(2^32 / S) + 1
   int nbands, fast;        // fast: register/DPP sweep is legal for this shape (LDS-grid kernel)
   int ts;                  // coefficient-table stride in entries (32, 128 or 256; > ncls on the register path)
-  int lds_wave_doubles;    // per-wave LDS region, in doubles (LDS-grid kernel)
+  int lds_wave_doubles;    // per-wave LDS region, in doubles (LDS-grid kernel; mode 3)
   int off_agtab, off_zscr, off_zmode; // offsets inside the per-wave region (doubles)
   // static tables
   const uint8_t *cls;      // [kPad + N + kPad], grid at +kPad
@@ -91,10 +91,11 @@ struct Dev {
   float pred_haste;        // mode 4: when may the next sweep overlap (step_two.hip may_roll)
   float pred_slack;
   int pred_first;          // mode 4: a step's first block rolls pred_first - 1 periods unseen when the previous step took >= 6 sweeps (1: never)
-  int lds_reg_bytes;       // dynamic LDS per workgroup (one building)
+  int lds_reg_bytes;       // dynamic LDS per workgroup (one building; mode 3: four)
   int wg_per_cu;
-  int r_seam, r_A, r_zscr, r_xchg, r_zoff, r_zmode; // LDS offsets in doubles
-  const unsigned long long *cmapS; // [P][maxch+3][64] class bytes by local step
+  int r_seam, r_A, r_zscr, r_xchg, r_zoff, r_zmode; // LDS offsets in doubles (mode 3: r_seam, r_A inside a wavefront's region of lds_wave_doubles)
+  int r_cmap;              // mode 3: the workgroup's shared class words [NR / 8][64]
+  const unsigned long long *cmapS; // [P][maxch+3][64] class bytes by local step (mode 3: [NR / 8][64] coefficient sets by step mod NR)
   const unsigned long long *amapS; // [P][ceil(NR/8)][64] class bytes by slot
   const unsigned long long *zmapS; // [P][ceil(NR/4)][64] 4 x u16 byte offsets into the zone-sum scratch
   const int *cell_state;   // [N] >= 0: index into the building's state; < 0: -(ring index + 1)
@@ -170,6 +171,7 @@ bool sweep_roll_supported(int NR);
 int sweep_roll_lds_slots(int NR);            // slots of A in LDS
 int sweep_roll_a_stride(int NR);             // row stride of A in LDS (doubles)
 int sweep_roll_seam_doubles(int NR, int T);  // LDS doubles of [pad | row 63 | pad][tail rows]
+int sweep_roll_waves();                      // wavefronts (= buildings) per workgroup
 
 // ---------------------------------------------------------------- wave helpers
 // DPP move of a double; lanes without a source (or outside row_mask) receive 0.

@@ -173,6 +173,7 @@ struct RegPlan {
   int lw[2] = {0, 0}, l0[2] = {0, 0}, rowbase[2] = {0, 0}, nch[2] = {0, 0};
   int lag = 0, nslots = 0, steps = 0;
   int r_seam = 0, r_A = 0, r_xchg = 0, lds_bytes = 0, wg_per_cu = 0, AS = 0;
+  int r_cmap = 0, wave_doubles = 0, waves_per_wg = 1; // mode 3: four buildings per workgroup share the class words
   std::vector<unsigned long long> cmapS, amapS, zmapS;
   std::vector<int> cell_state;
 };
@@ -610,16 +611,27 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   // stride spreads the 64 lanes over all banks (stride 96 doubles would put them all on one)
   // -- unless the extra column costs a resident building.
   auto layout = [&](int AS) {
+    r.AS = AS;
+    if (P == 3) { // step_roll.hip: [coefficient sets | class words] shared, then per wavefront [ap g | first tail row | A]
+      r.waves_per_wg = sweep_roll_waves();
+      r.r_cmap = 4 * TS;
+      r.r_seam = 2 * TS;
+      r.r_A = r.r_seam + ((sweep_roll_seam_doubles(NR, r.T) + 1) & ~1); // 16-byte aligned rows
+      r.wave_doubles = r.r_A + RS * nl_slots; // rows of AS slots, then [RS][nl_slots - AS]
+      r.lds_bytes = (r.r_cmap + (NR / 8) * 64 + r.waves_per_wg * r.wave_doubles) * 8;
+      if (const char *pad = getenv("SBSIM_DEBUG_LDS_PAD")) r.lds_bytes += atoi(pad);
+      r.wg_per_cu = r.lds_bytes <= kLdsCap ? 1 : 0;
+      return;
+    }
     int off = 5 * TS + TS;
     r.r_seam = off;
-    off += P == 2 ? 2 * (NR + 2 * kRegSeamPad) : (P == 3 ? sweep_roll_seam_doubles(NR, r.T) : 0);
+    off += P == 2 ? 2 * (NR + 2 * kRegSeamPad) : 0;
     r.r_A = off; off += RS * AS;
     r.r_xchg = off; off += 8;
-    r.AS = AS;
     r.lds_bytes = off * 8;
     if (const char *pad = getenv("SBSIM_DEBUG_LDS_PAD")) r.lds_bytes += atoi(pad); // developer knob: fewer buildings per CU
     // workgroups per CU: LDS, and the registers (4 SIMDs x wavefronts per SIMD / wavefronts per building)
-    const int by_regs = P == 3 ? 4 : 4 * sweep_reg_waves_per_simd(NR, P) / (P == 2 ? 2 : 1);
+    const int by_regs = 4 * sweep_reg_waves_per_simd(NR, P) / (P == 2 ? 2 : 1);
     r.wg_per_cu = std::min(by_regs, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule));
   };
   const int nl = nl_slots; // slots of A in LDS (the kernel keeps the rest in registers)
@@ -658,7 +670,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   };
   const int aslots = (NR + 7) / 8, zslots = (NR + 3) / 4;
   const int nw = P == 2 ? 2 : 1;
-  r.cmapS.assign((size_t)nw * (maxch + 3) * 64 * (P == 3 ? 2 : 1), 0);
+  r.cmapS.assign(P == 3 ? (size_t)(NR / 8) * 64 : (size_t)nw * (maxch + 3) * 64, 0);
   r.amapS.assign((size_t)nw * aslots * 64, 0);
   r.zmapS.assign((size_t)nw * zslots * 64, 0);
   r.tcls.assign((size_t)std::max(r.T, 1) * NR, (uint8_t)(8 * pad));
@@ -674,18 +686,15 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
       const bool valid = lp >= 0 && lp < r.lw[w];
       const int R = r.rowbase[w] + lp;
       if (P == 3) {
-        // step_roll.hip: one 16-bit field per step = the LDS byte offset of the cell's coefficient
-        // set (set * 32), four steps per word; steps >= NR + 63 belong to the next period (the
-        // field of step NR + 63 = step 63 closes the period's last word)
-        for (int ch = 0; ch < (maxch + 3) * 2; ++ch) {
+        // step_roll.hip: one byte per step = the cell's coefficient set (its LDS byte offset is set * 32),
+        // eight steps per word; at step s (of the ramp-up or of any period) the lane works on column
+        // (s - lane) mod NR
+        for (int ch = 0; ch < NR / 8; ++ch) {
           unsigned long long word = 0;
-          for (int k = 0; k < 4; ++k) {
-            int st = 4 * ch + k;
-            if (st >= NR + 63) st -= NR;
-            int col = st - lp;
-            if (col >= NR) col -= NR; // overlapped sweeps: the lane is in its next sweep
+          for (int k = 0; k < 8; ++k) {
+            const int col = ((8 * ch + k - lp) % NR + NR) % NR;
             const int c = valid ? cell_class(R, col) : pad;
-            word |= (unsigned long long)(set_of[c] * 32) << (16 * k);
+            word |= (unsigned long long)set_of[c] << (8 * k);
           }
           r.cmapS[(size_t)ch * 64 + lane] = word;
         }
@@ -815,8 +824,8 @@ void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan 
     out->path = 1;
     out->waves_per_building = (r.P == 2 || r.P == 5) ? 2 : 1;
     out->kernel = r.P; // sb_sweep_kernel: modes 1..5 are SB_KERNEL_REG .. SB_KERNEL_BAND
-    out->waves_per_workgroup = (r.P == 2 || r.P == 5) ? 2 : 1;
-    out->workgroups = std::max(1, std::min(n_buildings, cus * r.wg_per_cu));
+    out->waves_per_workgroup = (r.P == 2 || r.P == 5) ? 2 : r.waves_per_wg; // mode 3: four buildings per workgroup
+    out->workgroups = std::max(1, std::min((n_buildings + r.waves_per_wg - 1) / r.waves_per_wg, cus * r.wg_per_cu));
     out->lds_bytes_per_workgroup = r.lds_bytes;
     out->sweep_steps = r.steps;
     out->state_bytes_per_env_step = 16ll * r.state_doubles + rest;
@@ -949,6 +958,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.lag = r.lag; d.nslots = r.nslots; d.nsteps = r.steps;
     d.lds_reg_bytes = r.lds_bytes; d.wg_per_cu = r.wg_per_cu;
     d.r_seam = r.r_seam; d.r_A = r.r_A; d.r_xchg = r.r_xchg;
+    if (r.P == 3) { d.r_cmap = r.r_cmap; d.lds_wave_doubles = r.wave_doubles; }
     d.pred_haste = 1.0f; d.pred_slack = 1.0f; // measured (tools/bench_two_rows.py); developer knobs: speed only,
     if (const char *e = getenv("SBSIM_DEBUG_PRED_HASTE")) d.pred_haste = (float)atof(e); // never the result
     if (const char *e = getenv("SBSIM_DEBUG_PRED_SLACK")) d.pred_slack = (float)atof(e);
@@ -1083,8 +1093,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   SB_TRY(alloc_zero(h->next_b, 1));
 #undef SB_TRY
   d.next_b = h->next_b.p;
-  // buildings handed out statically before the draw counter: register path = workgroups, LDS-grid path = wavefronts
-  d.sweep_wgs = d.reg ? h->info.workgroups : h->info.workgroups * h->info.waves_per_workgroup;
+  // buildings handed out statically before the draw counter: register path = workgroups, LDS-grid path and mode 3 = wavefronts
+  d.sweep_wgs = (d.reg && d.P != 3) ? h->info.workgroups : h->info.workgroups * h->info.waves_per_workgroup;
   d.bld = h->bld.p; d.gtabg = h->gtabg.p; d.zsum = h->zsum.p; d.gsum = h->gsum.p; d.nsw = h->nsw.p;
   d.ctab = h->ctab.p; d.czone = h->czone.p; d.zone_off = h->zone_off.p;
   d.zone_cells_l = h->zone_cells_l.p; d.temp = h->temp.p; d.zmean = h->zmean.p;

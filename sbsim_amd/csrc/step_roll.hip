@@ -21,7 +21,11 @@
 //   * steps go in pairs: A = ap*Tprev + g of two neighbouring slots and the two seam values under
 //     lane 63 are one ds_read_b128 each (A rows are stored rotated by one slot so that the pair of
 //     an odd step is 16-byte aligned; row stride 70 doubles: conflict-free), one s_waitcnt per pair
-//   * the class bytes of all steps live in registers (AGPRs) for the whole kernel
+//   * four buildings = four wavefronts share a workgroup, and with it ONE table of the steps' coefficient
+//     sets in LDS (a byte per step and lane, 6 KB): a ds_read_b64 per eight steps.  (Read from global
+//     memory, a word per four steps, the class words cost 11 % of the step: a load is three issue slots,
+//     and behind another wavefront's hand-over in the CU's one vector-memory queue an L1 hit takes
+//     longer than the twelve steps the reads ran ahead -- tools/exp_fixed_sweeps.py)
 //   * window steps route |delta| to the accumulator of the lane's own sweep by its SIGN: a lane
 //     mask that one DPP shift per step maintains is OR-ed into the high word, one running max
 //     (sweep k) and one running min (sweep k+1) -- no lane compare, no select
@@ -40,11 +44,14 @@ constexpr int kWin = 63;      // steps of a period in which the lanes are in two
 constexpr int kTS = 32;       // entries of the per-class tables (ap, g) and of the coefficient-set table
 constexpr int kSeamPad = 8;
 
-// Slots of A = ap*Tprev + g kept in LDS (the rest: AGPRs).  70 of 96: a building needs 39.9 KB of
-// LDS, so four buildings -- one per SIMD -- share a CU.  Even (pairs), and the row stride
-// (= this) is 2 mod 4 doubles: rows are 16-byte aligned and 16 lanes' ds_read_b128 cover all banks.
-constexpr int lds_slots(int NR) { return NR == 96 ? 74 : ((NR / 2) % 2 ? NR : NR + 2); }
-constexpr int a_stride(int NR) { return NR == 96 ? 74 : ((NR / 2) % 2 ? NR : NR + 2); }
+// Slots of A = ap*Tprev + g kept in LDS (the rest: registers).  72 of 96: a building needs 38.2 KB of
+// LDS, so four buildings -- one per SIMD -- and the shared tables (7 KB) fill a CU's 160 KB.  Rows of
+// 70 slots (the stride is 2 mod 4 doubles: rows are 16-byte aligned and 16 lanes' ds_read_b128 cover
+// all banks) and a second array [64][2] with slots 70, 71 (a stride of 72 would be four-way conflicted,
+// 74 does not fit).
+constexpr int lds_slots(int NR) { return NR == 96 ? 72 : ((NR / 2) % 2 ? NR : NR + 2); }
+constexpr int a_stride(int NR) { return NR == 96 ? 70 : ((NR / 2) % 2 ? NR : NR + 2); }
+constexpr int kWaves = 4;     // wavefronts = buildings per workgroup
 constexpr int tail_row(int NR) { return NR + 4; } // tail rows in LDS: column c at [2 + c], zero guards around
 
 struct PairBuf { // LDS values of two consecutive steps
@@ -66,35 +73,31 @@ struct Acc {
 
 template <int NR>
 struct Ctx {
-  const double *Arow;  // the lane's row of A, rotated: slot j at [(j + 1) mod NR]
+  const double *Arow;  // the lane's row of A, rotated: slot j at position (j + 1) mod NR; positions < a_stride here,
+  const double *Aext;  // positions a_stride .. lds_slots - 1 here
   const double *seam;  // first tail row by step: the value under lane 63 at step s is seam[s]
-  const char *cmap;    // class words: a.cmapS (uniform)
-  unsigned voff;       // byte offset of the lane's NEXT class word: 8 * lane + 512 * word
-  unsigned long long w, wn, wnn, wn3; // class word (4 steps) in use / the next three, in flight
+  const unsigned long long *cw; // the lane's column of the class words in LDS: word k at [64 * k]
+  unsigned long long w, wn;     // class word (8 steps) in use / the next one, in flight
 };
 
-// Class words hold one 16-bit field per step: the LDS byte offset of the step's coefficient set
-// (set * 32; the table sits at LDS address 0), four steps per 64-bit word, read from global memory
-// (L1/L2 hits) one word ahead.  Word k covers steps 4k .. 4k+3; the field of step NR + 63 (= step
-// 63 of the next period) closes the last word of a period, so that words change every fourth step.
-template <int NR>
-__device__ __forceinline__ unsigned long long class_word(Ctx<NR> &x) { // global_load: SGPR base + 32-bit VGPR offset
-  return *(const unsigned long long *)(x.cmap + x.voff);
-}
+// Class words hold one byte per step: the step's coefficient set (its LDS byte offset is set * 32; the
+// table sits at LDS address 0), eight steps per 64-bit word, NR / 8 words per lane in LDS.  The set of a
+// step depends on (lane, step mod NR) only: word k covers the steps = 8k .. 8k+7 (mod NR) of the ramp-up
+// and of every period; it is read one word (eight steps) ahead.
 template <int NR, int S>
 __device__ __forceinline__ lds_d2 step_set(Ctx<NR> &x) {
-  if constexpr (S % 4 == 0) { // words are read three ahead (12 steps): under the hand-overs' HBM traffic an L2 hit can take > 8 steps
+  constexpr int j = S % NR;
+  static_assert(NR % 8 == 0, "whole class words per period");
+  if constexpr (j % 8 == 0) {
     x.w = x.wn;
-    x.wn = x.wnn;
-    x.wnn = x.wn3;
-    // after the period's last word comes step 64's (a running offset: not loop-invariant, nothing to hoist)
-    if constexpr (S == NR + kWin - 11) x.voff -= (unsigned)((NR + kWin - 3) / 4 - (kWin / 4 + 1)) * 512u;
-    else x.voff += 512u;
-    asm volatile("" : "+v"(x.voff)); // ... as far as the compiler can tell
-    x.wn3 = class_word<NR>(x);
+    x.wn = x.cw[((j / 8 + 1) % (NR / 8)) * 64];
   }
-  const unsigned h = S % 4 < 2 ? (unsigned)x.w : (unsigned)(x.w >> 32);
-  const unsigned off = S % 2 ? h >> 16 : h & 0xffffu;
+  const unsigned h = j % 8 < 4 ? (unsigned)x.w : (unsigned)(x.w >> 32);
+  unsigned off; // (byte j % 4 of h) << 5 in one instruction
+  if constexpr (j % 4 == 0) asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(h));
+  else if constexpr (j % 4 == 1) asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(h));
+  else if constexpr (j % 4 == 2) asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(h));
+  else asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(h));
   return (lds_d2)off;
 }
 
@@ -105,9 +108,10 @@ __device__ __forceinline__ void load_first(PairBuf &p, Ctx<NR> &x, const double 
   const lds_d2 ct = step_set<NR, S>(x);
   p.ud0 = ct[0];
   p.lr0 = ct[1];
-  constexpr int q = (S + 1) % NR, NL = lds_slots(NR);
-  static_assert(q % 2 == 0, "pairs start at odd steps");
-  if constexpr (q < NL) p.A = *(const d2 *)(x.Arow + q);
+  constexpr int q = (S + 1) % NR, NL = lds_slots(NR), AS = a_stride(NR);
+  static_assert(q % 2 == 0 && AS % 2 == 0, "pairs start at odd steps");
+  if constexpr (q < AS) p.A = *(const d2 *)(x.Arow + q);
+  else if constexpr (q < NL) p.A = *(const d2 *)(x.Aext + (q - AS));
   else p.A = d2{Areg[q - NL], Areg[q + 1 - NL]};
   if constexpr (SEAM && S >= kWin) p.sm = *(const d2 *)(x.seam + S);
   else p.sm = d2{0.0, 0.0};
@@ -218,12 +222,24 @@ __device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kW
     if constexpr (J + 1 < kWin) e[J + 1] = lanes_upto<J + 1>() ? bk[J + 1] : e[J + 1];
     const unsigned long long w = zw[(J / 4) % (kZA + 1)];
     const unsigned off0 = (unsigned)((w >> (16 * (J & 3))) & 0xffffull), off1 = (unsigned)((w >> (16 * ((J + 1) & 3))) & 0xffffull);
+#ifndef SB_EXP_NOMEM // timing experiment: the hand-over without its HBM traffic
+#ifdef SB_EXP_NT
+    __builtin_nontemporal_store(d2{e[J], e[J + 1]}, (d2 *)(tp + J * 64));
+#else
     *(d2 *)(tp + J * 64) = d2{e[J], e[J + 1]};
+#endif
+#endif
     __hip_atomic_fetch_add((double *)((char *)zs + off0), e[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_add((double *)((char *)zs + off1), e[J + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef SB_EXP_NOMEM
+#ifdef SB_EXP_NT
+    const d2 nv = __builtin_nontemporal_load((const d2 *)(np_ + J * 64));
+#else
     const d2 nv = *(const d2 *)(np_ + J * 64);
+#endif
     e[J] = nv.x;
     e[J + 1] = nv.y;
+#endif
     if constexpr ((J & 7) == 6) __builtin_amdgcn_sched_barrier(0);
     hand_over<NR, J + 2>(e, bk, zw, zmap, tp, np_, zs);
   }
@@ -232,21 +248,28 @@ __device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kW
 extern __shared__ __attribute__((aligned(16))) double lds[];
 
 template <int NR>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_roll(Dev a) {
+__global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_roll(Dev a) {
   const int lane = threadIdx.x & 63;
-  constexpr int kASlots = (NR + 7) / 8, kZSlots = (NR + 3) / 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); // one wavefront per SIMD, each with its own buildings
+  const int gw = (int)blockIdx.x * kWaves + wave;
+  constexpr int kASlots = (NR + 7) / 8, kZSlots = (NR + 3) / 4, kCW = NR / 8;
   constexpr int kNL = lds_slots(NR), kAS = a_stride(NR), kNAR = NR - kNL > 0 ? NR - kNL : 2;
 
+  // shared by the workgroup's wavefronts (read-only after this block):
   double *tabc = lds;                      // [kTS][4]: bU bD bL bR per coefficient set
-  double *tapg = lds + 4 * kTS;            // [kTS][2]: (ap, g) by class; g of this building -- one ds_read_b128 per cell of the A pass
-  double *tE0 = lds + a.r_seam + 2;        // the first tail row by column ([2 guards | NR | 2 guards]): lane 63's lower neighbours
-  double *A = lds + a.r_A;                 // [64][kAS]; after the sweeps: zone sums [Z+1][ZRS]
+  unsigned long long *ctab8 = (unsigned long long *)(lds + a.r_cmap); // [kCW][64]: the steps' coefficient sets, a byte each
+  // the wavefront's own region:
+  double *wl = lds + a.r_cmap + kCW * 64 + (size_t)wave * a.lds_wave_doubles;
+  double *tapg = wl;                       // [kTS][2]: (ap, g) by class; g of this building -- one ds_read_b128 per cell of the A pass
+  double *tE0 = wl + a.r_seam + 2;         // the first tail row by column ([2 guards | NR | 2 guards]): lane 63's lower neighbours
+  double *A = wl + a.r_A;                  // [64][kAS]; after the sweeps: zone sums [Z+1][ZRS]
   // every byte of LDS starts finite: reads next to the arrays' ends are multiplied by 0
   for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0;
-  __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < 4 * kTS; i += 64) tabc[i] = i < 4 * a.ncset ? a.csetab[i] : 0.0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * kTS; i += blockDim.x) tabc[i] = i < 4 * a.ncset ? a.csetab[i] : 0.0;
+  for (int i = threadIdx.x; i < kCW * 64; i += blockDim.x) ctab8[i] = a.cmapS[i];
   if (lane < kTS) tapg[2 * lane] = lane <= a.ncls ? a.ctab[lane * 8 + 4] : 0.0; // row `ncls` is the pad class
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads(); // the only barriers: from here on the wavefronts go their own ways
 
   const sb_params &p = a.p;
   const int R = lane;
@@ -254,10 +277,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   if ((unsigned)(size_t)(__attribute__((address_space(3))) double *)tabc != 0u) __builtin_trap(); // class words hold LDS addresses
   Ctx<NR> x;
   x.Arow = A + (size_t)R * kAS;
+  x.Aext = A + 64 * kAS + (size_t)R * (kNL - kAS);
   x.seam = tE0 - kWin; // lane 63 works on column s - 63 at step s
-  x.cmap = (const char *)a.cmapS;
-  x.voff = 0;
-  x.w = x.wn = x.wnn = x.wn3 = 0;
+  x.cw = ctab8 + lane;
+  x.w = x.wn = 0;
   // the lane's tail cells (static per floor plan): table offsets of their coefficient sets
   // (two 16-bit halves) and of their classes (two bytes)
   const bool tactive = tail_col<NR>(lane, 0) >= 0; // the lane owns two tail columns
@@ -277,7 +300,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const unsigned long long *zmap = a.zmapS + lane;
 
 // developer aid: cycle stamps of workgroup 0's 11th building (steady state, not the cold start)
-#define SB_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && iter == 10 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define SB_STAMP(i) do { if (a.dbg && gw == 0 && iter == 10 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
   // The lane's row of the NEXT building is loaded while this building's row is stored, slot by
   // slot, so the loop never waits on HBM latency; so are the building's small inputs.
@@ -294,20 +317,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
         if (t < a.T) nx_tail[t][k] = tt_[t * NR + tc0 + k];                                     \
   } while (0)
-  if ((int)blockIdx.x < a.B) {
-    const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles;
+  if (gw < a.B) {
+    const double *tp_ = a.temp + (size_t)gw * a.state_doubles;
 #pragma unroll
     for (int j = 0; j < NR; j += 2) { // state layout [NR / 2][64][2]
       const d2 v = *(const d2 *)(tp_ + j * 64 + 2 * R);
       e[j] = v.x;
       e[j + 1] = v.y;
     }
-    SB_LOAD_AUX(blockIdx.x);
+    SB_LOAD_AUX(gw);
   }
   // Buildings need different numbers of sweeps: after its first building a workgroup draws the
   // next one from a device counter (zeroed before every launch).
   int iter = 0;
-  for (int b = blockIdx.x, bn = 0; b < a.B; b = bn, ++iter) {
+  for (int b = gw, bn = 0; b < a.B; b = bn, ++iter) {
     // the draw of the NEXT building: issued here, read before the hand-over (an atomic's round trip
     // to L2 is 1-2 us: the sweeps hide it)
     int nb = 0;
@@ -318,12 +341,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const int o = opaque(0);
 #pragma unroll
       for (int g = 0; g < kASlots; ++g) amapw[g] = amap[o + g * 64];
-      x.voff = (unsigned)opaque(lane * 8);
-      x.wn = class_word<NR>(x); // the first three class words of the ramp-up
-      x.voff += 512u;
-      x.wnn = class_word<NR>(x);
-      x.voff += 512u;
-      x.wn3 = class_word<NR>(x);
+      x.wn = x.cw[0]; // the first class word of the ramp-up
     }
     double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 64; // [T][NR]
     __builtin_amdgcn_sched_barrier(0);
@@ -358,7 +376,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     Areg[0] = 0.0;
     {
       const unsigned long long(&cwa)[kASlots] = amapw;
-      double *Aw = A + (size_t)R * kAS;
+      double *Aw = A + (size_t)R * kAS, *Ax = A + 64 * kAS + (size_t)R * (kNL - kAS);
+      auto at = [&](int q) { return q < kAS ? Aw + q : Ax + (q - kAS); }; // position q of the lane's rotated row
       // groups of 8, software-pipelined: the table reads of group g+1 are issued before the A
       // values of group g are written (the compiler cannot prove that A and the tables do not alias).
       // One ds_read_b128 per cell ((ap, g) of its class); slots (j, j + 1), j odd, sit at the even
@@ -386,8 +405,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             const double av = fma(pg[g & 1][k].x, e[j], pg[g & 1][k].y);
             const int q = (j + 1) % NR; // position in the rotated row
             if (j % 2 == 1 && j + 1 < NR && q + 1 < kNL) carry = av;                    // (q even) with slot j + 1: one 16-byte write
-            else if (j % 2 == 0 && j > 0 && q < kNL && q - 1 >= 0 && (q - 1) % 2 == 0) *(d2 *)(Aw + q - 1) = d2{carry, av};
-            else if (q < kNL) Aw[q] = av;
+            else if (j % 2 == 0 && j > 0 && q < kNL && q - 1 >= 0 && (q - 1) % 2 == 0) *(d2 *)at(q - 1) = d2{carry, av};
+            else if (q < kNL) *at(q) = av;
             else Areg[q - kNL] = av;
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -422,7 +441,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma nounroll
       for (;;) { // simulator.py:348-368
         __builtin_amdgcn_sched_barrier(0);
-#define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 10 && n_sweeps == 1 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define SB_STAMP2(i) do { if (a.dbg && gw == 0 && iter == 10 && n_sweeps == 1 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
         SB_STAMP2(10);
         roll_pairs<NR, kWin, NR + kWin, true>(e, bk, Areg, pb, x, acc);
         SB_STAMP2(11);
@@ -448,7 +467,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         SB_STAMP2(14);
         ++n_sweeps;
         converged = md <= p.conv_threshold;
+#ifdef SB_EXP_DESYNC // timing experiments: sweep counts 1..9 by building number (mean 5), whatever the numbers are
+        if (n_sweeps >= 1 + (int)(((unsigned)b * 2654435761u >> 13) % 9u)) break;
+#else
         if (converged || n_sweeps >= p.iter_limit) break; // the started sweep is undone while the row is stored
+#endif
         // after the tail scan: the first tail row's new values under lane 63, for the pairs already read ahead
         pb[pair_buf(kWin)].sm = *(const d2 *)(x.seam + kWin);
         if constexpr (kDepth > 1) pb[pair_buf(kWin + 2)].sm = *(const d2 *)(x.seam + kWin + 2);
@@ -519,7 +542,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         a.nsw[b] = n_sweeps | (converged << 16);
       }
       SB_STAMP(8);
-      if (a.dbg && blockIdx.x == 0 && iter == 10 && lane == 0) a.dbg[9] = n_sweeps;
+      if (a.dbg && gw == 0 && iter == 10 && lane == 0) a.dbg[9] = n_sweeps;
     }
   }
 #undef SB_STAMP
@@ -532,6 +555,7 @@ bool sweep_roll_supported(int NR) { return NR == 96; }
 int sweep_roll_lds_slots(int NR) { return lds_slots(NR); }
 int sweep_roll_a_stride(int NR) { return a_stride(NR); }
 int sweep_roll_seam_doubles(int NR, int T) { (void)T; return tail_row(NR); } // the first tail row, by column
+int sweep_roll_waves() { return kWaves; }
 
 int prepare_sweep_roll(const Dev &d) {
   if (d.NR != 96) return (int)hipErrorInvalidValue;
@@ -541,7 +565,7 @@ int prepare_sweep_roll(const Dev &d) {
 
 int launch_sweep_roll(const Dev &d, hipStream_t stream) {
   if (d.NR != 96) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((k_sweep_roll<96>), dim3(d.sweep_wgs), dim3(64), (size_t)d.lds_reg_bytes, stream, d);
+  hipLaunchKernelGGL((k_sweep_roll<96>), dim3((d.sweep_wgs + kWaves - 1) / kWaves), dim3(64 * kWaves), (size_t)d.lds_reg_bytes, stream, d);
   return (int)hipGetLastError();
 }
 

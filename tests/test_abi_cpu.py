@@ -61,14 +61,15 @@ def _plan_info(fp, n_obs=46, n_buildings=1024):
 def test_plan_info_picks_the_step_kernel_without_a_gpu():
   """Host-only launch planning (sb_plan_info): R9 (68x98, 66x96 inside the exterior ring) runs
   on the register path either way -- lanes = rows: one wavefront owns rows 0..63 and the two
-  remaining wall rows are finished by a scan (four buildings per CU); lanes = columns: one
+  remaining wall rows are finished by a scan (four buildings = one workgroup per CU, sharing the steps'
+  class words in LDS); lanes = columns: one
   wavefront, two columns per lane, two buildings per CU; a 129-row plan: two rows per lane + one
   tail row; a small plan uses one wavefront per building."""
   from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
   r9 = FloorPlan.from_file_input(rectangular_floor_plan((3, 3), (20, 30)), Materials.sb1(), 10.0, 300.0)
   rc, rows = _plan_info(r9)
   assert rc == 0 and rows["path"] == 1 and rows["waves_per_building"] == 1 and rows["kernel"] == 3   # k_sweep_roll
-  assert 4 * ((rows["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
+  assert rows["waves_per_workgroup"] == 4 and rows["workgroups"] == 256 and rows["lds_bytes_per_workgroup"] <= 160 * 1024
   rc, cols = _plan_info(r9.transposed())
   assert rc == 0 and cols["path"] == 1 and cols["waves_per_building"] == 1 and cols["kernel"] == 4   # k_sweep_two
   assert cols["sweep_steps"] == 76 + 48 - 1            # step_two.hip: 66 columns -> 76 slots, 96 rows -> 48 lanes

@@ -41,12 +41,12 @@ extern __shared__ __attribute__((aligned(16))) double lds[];
   "v_mov_b32 v143, 0\n"
 
 #define TEST(NAME, NINSTR, BODY)                                                                   \
-  __global__ void __launch_bounds__(64) NAME(long long *out, int iters) {                          \
+  __global__ void __launch_bounds__(64) NAME(long long *out, int iters, const char *gbuf) {                          \
     unsigned lo, hi;                                                                               \
     if (threadIdx.x < 64) for (int i = threadIdx.x; i < 5000; i += 64) lds[i] = 1.0;               \
     __syncthreads();                                                                               \
     asm volatile(INIT                                                                              \
-                 "s_mov_b32 s22, %2\n"                                                             \
+                 "s_mov_b32 s22, %2\n s_mov_b32 s26, %3\n s_mov_b32 s27, %4\n"                     \
                  "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                 \
                  "s_memtime s[20:21]\n s_waitcnt lgkmcnt(0)\n"                                     \
                  "1:\n .rept 16\n" BODY ".endr\n"                                                  \
@@ -54,7 +54,7 @@ extern __shared__ __attribute__((aligned(16))) double lds[];
                  "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                 \
                  "s_memtime s[24:25]\n s_waitcnt lgkmcnt(0)\n"                                     \
                  "s_sub_u32 %0, s24, s20\n s_subb_u32 %1, s25, s21\n"                              \
-                 : "=s"(lo), "=s"(hi) : "s"(iters) : CLOB);                                        \
+                 : "=s"(lo), "=s"(hi) : "s"(iters), "s"((unsigned)(size_t)gbuf), "s"((unsigned)((size_t)gbuf >> 32)) : CLOB);                                        \
     if (threadIdx.x == 0) out[blockIdx.x] = ((long long)hi << 32) | lo;                            \
   }                                                                                                \
   static const int NAME##_n = NINSTR;
@@ -142,6 +142,26 @@ TEST(ds_2b64_same, 4,
      "ds_read2_b64 v[104:107], v143 offset1:32\n ds_read2_b64 v[108:111], v143 offset0:64 offset1:96\n"
      "ds_read2_b64 v[112:115], v143 offset1:32\n ds_read2_b64 v[116:119], v143 offset0:64 offset1:96\n")
 TEST(ds_w64, 4, "ds_write_b64 v140, v[100:101]\n ds_write_b64 v140, v[100:101] offset:512\n ds_write_b64 v140, v[100:101] offset:1024\n ds_write_b64 v140, v[100:101] offset:1536\n")
+TEST(ds_w128, 4, "ds_write_b128 v141, v[100:103]\n ds_write_b128 v141, v[100:103] offset:1024\n ds_write_b128 v141, v[100:103] offset:2048\n ds_write_b128 v141, v[100:103] offset:3072\n")
+TEST(ds_addf64, 4, "ds_add_f64 v140, v[102:103]\n ds_add_f64 v140, v[102:103] offset:512\n ds_add_f64 v140, v[102:103] offset:1024\n ds_add_f64 v140, v[102:103] offset:1536\n")
+TEST(ds_addf64_rtn, 4, "ds_add_rtn_f64 v[104:105], v140, v[102:103]\n ds_add_rtn_f64 v[106:107], v140, v[102:103] offset:512\n ds_add_rtn_f64 v[108:109], v140, v[102:103] offset:1024\n ds_add_rtn_f64 v[110:111], v140, v[102:103] offset:1536\n")
+// ---------------------------------------------------------------- VMEM issue: 512-byte loads that hit L1 (v140 = lane*8), base s[26:27]
+// (the salu_bfm / valu_salu_mix tests above clobber s[26:27]: these come first in the table)
+TEST(gld_only, 4, "global_load_dwordx2 v[104:105], v140, s[26:27]\n global_load_dwordx2 v[106:107], v140, s[26:27] offset:512\n"
+                  "global_load_dwordx2 v[108:109], v140, s[26:27] offset:1024\n global_load_dwordx2 v[110:111], v140, s[26:27] offset:1536\n")
+TEST(gld_1_fma12, 13, "global_load_dwordx2 v[120:121], v140, s[26:27]\n"
+     "v_fmac_f64 v[104:105], v[102:103], v[100:101]\n v_fmac_f64 v[106:107], v[102:103], v[100:101]\n v_fmac_f64 v[108:109], v[102:103], v[100:101]\n v_fmac_f64 v[110:111], v[102:103], v[100:101]\n"
+     "v_fmac_f64 v[112:113], v[102:103], v[100:101]\n v_fmac_f64 v[114:115], v[102:103], v[100:101]\n v_fmac_f64 v[116:117], v[102:103], v[100:101]\n v_fmac_f64 v[118:119], v[102:103], v[100:101]\n"
+     "v_fmac_f64 v[104:105], v[102:103], v[100:101]\n v_fmac_f64 v[106:107], v[102:103], v[100:101]\n v_fmac_f64 v[108:109], v[102:103], v[100:101]\n v_fmac_f64 v[110:111], v[102:103], v[100:101]\n")
+TEST(fma12, 12,
+     "v_fmac_f64 v[104:105], v[102:103], v[100:101]\n v_fmac_f64 v[106:107], v[102:103], v[100:101]\n v_fmac_f64 v[108:109], v[102:103], v[100:101]\n v_fmac_f64 v[110:111], v[102:103], v[100:101]\n"
+     "v_fmac_f64 v[112:113], v[102:103], v[100:101]\n v_fmac_f64 v[114:115], v[102:103], v[100:101]\n v_fmac_f64 v[116:117], v[102:103], v[100:101]\n v_fmac_f64 v[118:119], v[102:103], v[100:101]\n"
+     "v_fmac_f64 v[104:105], v[102:103], v[100:101]\n v_fmac_f64 v[106:107], v[102:103], v[100:101]\n v_fmac_f64 v[108:109], v[102:103], v[100:101]\n v_fmac_f64 v[110:111], v[102:103], v[100:101]\n")
+// the same load every 52 instructions with a wait three loads back, as in k_sweep_roll (one class word per four steps)
+TEST(gld_1_fma12_wait, 14, "global_load_dwordx2 v[120:121], v140, s[26:27]\n s_waitcnt vmcnt(3)\n"
+     "v_fmac_f64 v[104:105], v[102:103], v[100:101]\n v_fmac_f64 v[106:107], v[102:103], v[100:101]\n v_fmac_f64 v[108:109], v[102:103], v[100:101]\n v_fmac_f64 v[110:111], v[102:103], v[100:101]\n"
+     "v_fmac_f64 v[112:113], v[102:103], v[100:101]\n v_fmac_f64 v[114:115], v[102:103], v[100:101]\n v_fmac_f64 v[116:117], v[102:103], v[100:101]\n v_fmac_f64 v[118:119], v[102:103], v[100:101]\n"
+     "v_fmac_f64 v[104:105], v[102:103], v[100:101]\n v_fmac_f64 v[106:107], v[102:103], v[100:101]\n v_fmac_f64 v[108:109], v[102:103], v[100:101]\n v_fmac_f64 v[110:111], v[102:103], v[100:101]\n")
 // ---------------------------------------------------------------- the sweep step
 // current order (k_sweep_reg round 1): sdwa add, 2 ds_read2_b64 + 2 ds_read_b64 (used two steps later: here the
 // previous body's), dpp D, fmac bD, fmac bR, dpp U, fmac bL, fmac bU, add, max.
@@ -198,21 +218,24 @@ TEST(step_r1_window, 21, STEP_LOADS_B128 "s_waitcnt lgkmcnt(8)\n" STEP_MATH_R1
      "v_cndmask_b32 v126, 0, v123, s[26:27]\n v_cndmask_b32 v127, v123, 0, s[26:27]\n"
      "v_max_f64 v[128:129], v[128:129], |v[126:127]|\n")
 
-struct T { const char *name; void (*fn)(long long *, int); int n; };
+struct T { const char *name; void (*fn)(long long *, int, const char *); int n; };
 #define E(NAME) {#NAME, NAME, NAME##_n}
 int main(int argc, char **argv) {
   const int blocks = argc > 1 ? atoi(argv[1]) : 1024, iters = 400;
-  T tests[] = {E(nop8), E(fma_indep), E(fma_dep), E(fma_dep2), E(fma_dep3), E(mov32_indep), E(mov64_indep), E(dpp_indep), E(rowdpp_indep),
+  T tests[] = {E(gld_only), E(gld_1_fma12), E(fma12), E(gld_1_fma12_wait), E(nop8), E(fma_indep), E(fma_dep), E(fma_dep2), E(fma_dep3), E(mov32_indep), E(mov64_indep), E(dpp_indep), E(rowdpp_indep),
                E(chain_dpp_fma), E(chain_dpp_fma2), E(add_max_dep), E(acc_write), E(salu_bfm), E(valu_salu_mix), E(fma_mov32_mix),
-               E(ds_b64), E(ds_2b64), E(ds_b128), E(ds_b128_same), E(ds_2b64_same), E(ds_w64),
+               E(ds_b64), E(ds_2b64), E(ds_b128), E(ds_b128_same), E(ds_2b64_same), E(ds_w64), E(ds_w128), E(ds_addf64), E(ds_addf64_rtn),
                E(step_r1_2b64), E(step_r1_b128), E(step_r1_noloads), E(step_il_b128), E(step_il_noloads), E(step_il_spread), E(step_r1_window)};
   long long *d;
   hipMalloc(&d, 8 * blocks);
+  char *gbuf;
+  hipMalloc(&gbuf, 1 << 20);
+  hipMemset(gbuf, 0, 1 << 20);
   printf("%d workgroups x 64 threads, 40 KB LDS each (four per CU), %d x 16 bodies\n", blocks, iters);
   for (const T &t : tests) {
     hipFuncSetAttribute((const void *)t.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 40960);
     for (int rep = 0; rep < 2; ++rep) {
-      hipLaunchKernelGGL(t.fn, dim3(blocks), dim3(64), 40960, 0, d, iters);
+      hipLaunchKernelGGL(t.fn, dim3(blocks), dim3(64), 40960, 0, d, iters, gbuf);
       hipDeviceSynchronize();
     }
     std::vector<long long> h(blocks);
