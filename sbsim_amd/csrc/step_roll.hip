@@ -223,20 +223,12 @@ __device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kW
     const unsigned long long w = zw[(J / 4) % (kZA + 1)];
     const unsigned off0 = (unsigned)((w >> (16 * (J & 3))) & 0xffffull), off1 = (unsigned)((w >> (16 * ((J + 1) & 3))) & 0xffffull);
 #ifndef SB_EXP_NOMEM // timing experiment: the hand-over without its HBM traffic
-#ifdef SB_EXP_NT
-    __builtin_nontemporal_store(d2{e[J], e[J + 1]}, (d2 *)(tp + J * 64));
-#else
-    *(d2 *)(tp + J * 64) = d2{e[J], e[J + 1]};
-#endif
+    __builtin_nontemporal_store(d2{e[J], e[J + 1]}, (d2 *)(tp + J * 64)); // the state streams: read once, written once per launch
 #endif
     __hip_atomic_fetch_add((double *)((char *)zs + off0), e[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_add((double *)((char *)zs + off1), e[J + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef SB_EXP_NOMEM
-#ifdef SB_EXP_NT
     const d2 nv = __builtin_nontemporal_load((const d2 *)(np_ + J * 64));
-#else
-    const d2 nv = *(const d2 *)(np_ + J * 64);
-#endif
     e[J] = nv.x;
     e[J + 1] = nv.y;
 #endif
@@ -321,7 +313,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     const double *tp_ = a.temp + (size_t)gw * a.state_doubles;
 #pragma unroll
     for (int j = 0; j < NR; j += 2) { // state layout [NR / 2][64][2]
-      const d2 v = *(const d2 *)(tp_ + j * 64 + 2 * R);
+      const d2 v = __builtin_nontemporal_load((const d2 *)(tp_ + j * 64 + 2 * R));
       e[j] = v.x;
       e[j + 1] = v.y;
     }
