@@ -246,7 +246,7 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
   auto cell_class = [&](int R, int col) { // trimmed coordinates
     return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? (int)plan->cell_class[(x0 + R) * W + (y0 + col)] : pad;
   };
-  const int NW = NR + 63, NWD = (NE + 3) / 4;
+  const int NW = NR / 4, NWD = (NE + 3) / 4; // step_two.hip: class words of four steps, NR / 4 per lane
   r.cmapS.assign((size_t)NW * 64, 0);
   r.amapS.assign((size_t)NWD * 64, 0);
   r.zmapS.assign((size_t)NWD * 64, 0);
@@ -262,11 +262,14 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
       const int R = 2 * lane + k;
       return (R < Hw && col >= 0 && col < NR) ? cell_class(R, col) : pad;
     };
-    for (int st = 0; st < NW; ++st) { // one word per step: (upper, lower) set offsets in its halves
-      int col = st - lane;
-      if (col >= NR) col -= NR; // rolling periods: the lane is in its next sweep
-      r.cmapS[(size_t)st * 64 + lane] = (unsigned long long)(set_of[row_class(0, col)] * 32) |
-                                        ((unsigned long long)(set_of[row_class(1, col)] * 32) << 32);
+    for (int wd = 0; wd < NW; ++wd) { // a byte per cell and step: the coefficient sets of the lane's (upper, lower) cell
+      unsigned long long word = 0;
+      for (int k = 0; k < 4; ++k) { // at step s (of a ramp-up or of any period) the lane works on column (s - lane) mod NR
+        const int col = ((4 * wd + k - lane) % NR + NR) % NR;
+        word |= (unsigned long long)set_of[row_class(0, col)] << (16 * k);
+        word |= (unsigned long long)set_of[row_class(1, col)] << (16 * k + 8);
+      }
+      r.cmapS[(size_t)wd * 64 + lane] = word;
     }
     for (int g = 0; g < NWD; ++g) { // register J = 2 * slot + (row & 1)
       unsigned long long aword = 0, zword = 0;

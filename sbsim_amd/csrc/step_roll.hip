@@ -205,22 +205,28 @@ __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], 
 // The end of a building's step, slot by slot: undo the started sweep (lanes <= J restore slot J
 // from the window's copies), store the slot, add it to its zone sum (LDS), load the same slot of
 // the next building.  The loop runs at the pace of the memory pipe; the restores cost nothing there.
-// zw: the zone-sum offsets, four slots per word, read kZA words (32 slots = 64 memory
-// operations) ahead: memory operations return in order, so waiting for a word that is only a few
-// slots old would drain the queue of row loads in front of it.
-constexpr int kZA = 8;
+// zw: the zone-sum offsets, four slots per word -- read before the loop (into the registers A's slots
+// leave free after the sweeps): memory operations return in order, so a word read inside the loop would
+// wait for the row loads of the next building issued before it, i.e. for HBM (that paced the loop at 125
+// cycles per pair of slots where its instructions issue in 35).
+#ifndef SB_ZPRE
+#define SB_ZPRE 16
+#endif
+constexpr int kZPre = SB_ZPRE; // zone-offset words read before the loop
 // HBM state layout: [NR / 2][64 lanes][2] -- a lane's two neighbouring slots are 16 bytes, so the
 // loop moves a building with NR / 2 stores and NR / 2 loads of 16 bytes per lane (a wavefront has
 // at most 63 memory operations in flight: the count of operations, not their size, paces the loop).
 template <int NR, int J>
-__device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kWin], unsigned long long (&zw)[kZA + 1],
+__device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kWin], unsigned long long (&zw)[(NR + 3) / 4],
                                           const unsigned long long *zmap, double *tp, const double *np_, double *zs) {
   static_assert(NR % 2 == 0, "slot pairs");
   if constexpr (J < NR) {
-    if constexpr (J % 4 == 0 && J / 4 + kZA < (NR + 3) / 4) zw[(J / 4 + kZA) % (kZA + 1)] = zmap[(J / 4 + kZA) * 64];
+    // the last words: read in the loop's first iterations (into the registers the restored copies leave free);
+    // their wait, at slot 4 * kZPre, is for the first rows of the next building -- which the A pass needs anyway
+    if constexpr (J % 4 == 0 && J >= 8 && kZPre + (J - 8) / 4 < (NR + 3) / 4) zw[kZPre + (J - 8) / 4] = zmap[(kZPre + (J - 8) / 4) * 64];
     if constexpr (J < kWin) e[J] = lanes_upto<J>() ? bk[J] : e[J];
     if constexpr (J + 1 < kWin) e[J + 1] = lanes_upto<J + 1>() ? bk[J + 1] : e[J + 1];
-    const unsigned long long w = zw[(J / 4) % (kZA + 1)];
+    const unsigned long long w = zw[J / 4];
     const unsigned off0 = (unsigned)((w >> (16 * (J & 3))) & 0xffffull), off1 = (unsigned)((w >> (16 * ((J + 1) & 3))) & 0xffffull);
 #ifndef SB_EXP_NOMEM // timing experiment: the hand-over without its HBM traffic
     __builtin_nontemporal_store(d2{e[J], e[J + 1]}, (d2 *)(tp + J * 64)); // the state streams: read once, written once per launch
@@ -483,10 +489,10 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     double *zs = A;
     const int ZRS = a.ZRS;
     {
-      unsigned long long zw[kZA + 1]; // zone-sum offsets, four slots per word
+      unsigned long long zw[kZSlots]; // zone-sum offsets, four slots per word
       const unsigned long long *zm = zmap + opaque(0);
 #pragma unroll
-      for (int g = 0; g < kZA; ++g) zw[g] = zm[g * 64];
+      for (int g = 0; g < (kZPre < kZSlots ? kZPre : kZSlots); ++g) zw[g] = zm[g * 64];
       __builtin_amdgcn_sched_barrier(0);
       double *tp = a.temp + (size_t)b * a.state_doubles;
       for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + R] = 0.0;

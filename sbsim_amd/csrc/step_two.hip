@@ -38,7 +38,7 @@ namespace {
 using namespace sweep;
 
 constexpr int kSets = 32;  // entries of the coefficient-set table (at LDS address 0)
-constexpr int kWA = 7;     // class words (one step each) are read this many words ahead
+constexpr int kWA = 3;     // class words (four steps each) are read this many words ahead
 constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in the hand-over
 
 // Slots of A kept in LDS (the rest in registers): with them a building needs < 80 KB of LDS -- two
@@ -65,7 +65,7 @@ struct Ctx {
   unsigned seam;      // LDS byte address of the first tail row by step: the value under lane 63 at step s is [s]
   const char *cmap;   // class words (uniform)
   unsigned voff;      // byte offset of the lane's last-read class word: 8 * lane + 512 * word
-  unsigned long long w[kWA + 1];
+  unsigned long long w[kWA + 1]; // the word in use and the next kWA, in flight
 };
 
 // The lane's 2 NR grid registers: register J = 2 * slot + (row & 1).  The first 2 * kNV live in
@@ -150,42 +150,56 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
-// Class words: one 64-bit word per step -- the LDS byte offsets (set * 32) of the coefficient sets of
-// the lane's upper (low half) and lower cell (high half): the halves ARE the ds_read addresses, no
-// instruction to extract them -- read from global memory (L2 hits) kWA steps ahead.
+// Class words: a byte per cell and step -- the coefficient set (its LDS byte offset is set * 32) of the
+// lane's upper (even bytes) and lower cell (odd bytes), four steps per 64-bit word.  The sets of a step
+// depend on (lane, step mod NR) only, so the table has NR / 4 words per lane (10 KB: L1 hits) and a
+// rolling period continues where the last one stopped; read kWA words = 12 steps ahead.  (One word per
+// step with the two LDS addresses ready-made cost no instruction to decode, but a load per step from a
+// 71 KB table: a quarter of the sweep's time, tools/exp_fixed_sweeps.py with PLAN=SB1-synth.)
 template <int NR>
-constexpr int words_per_sweep() { return NR + 63; }
+constexpr int class_words() { return NR / 4; }
 __device__ __forceinline__ unsigned long long class_word(const Ctx &x) {
   return *(const unsigned long long *)(x.cmap + x.voff);
 }
-__device__ __forceinline__ void first_words(Ctx &x, int lane) { // words 0 .. kWA-1 of a sweep
-  x.voff = (unsigned)opaque(lane * 8);
+// Before load_step<S0>: the words of steps S0 .. (a word boundary at S0 rotates first).
+template <int NR, int S0>
+__device__ __forceinline__ void enter_words(Ctx &x, int lane) {
+  static_assert(NR % 4 == 0, "whole class words per sweep");
+  constexpr int j = S0 % NR, wi = j / 4, first = j % 4 == 0 ? 1 : 0, NW = class_words<NR>();
 #pragma unroll
-  for (int k = 0; k < kWA; ++k) {
+  for (int k = first; k <= kWA; ++k) {
+    x.voff = (unsigned)opaque(lane * 8 + 512 * ((wi + k - first) % NW));
     x.w[k] = class_word(x);
-    if (k + 1 < kWA) x.voff += 512u;
   }
 }
+template <int NR>
+__device__ __forceinline__ void first_words(Ctx &x, int lane) { enter_words<NR, 0>(x, lane); }
 
-// A rolling period starts at step 63; load_step<63> continues with word 63 + kWA.
-__device__ __forceinline__ void period_words(Ctx &x, int lane) {
-  x.voff = (unsigned)opaque(lane * 8 + 63 * 512);
-#pragma unroll
-  for (int k = 0; k < kWA; ++k) {
-    x.w[(63 + k) % (kWA + 1)] = class_word(x);
-    if (k + 1 < kWA) x.voff += 512u;
-  }
+template <int byte>
+__device__ __forceinline__ unsigned set_offset(unsigned h) { // (byte of h) << 5 in one instruction
+  unsigned off;
+  if constexpr (byte == 0) asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(h));
+  else if constexpr (byte == 1) asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(h));
+  else if constexpr (byte == 2) asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(h));
+  else asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(h));
+  return off;
 }
 
 template <int NR, int S, bool TAIL, int NAR>
 __device__ __forceinline__ void load_step(StepBuf &p, Ctx &x, const double (&Areg)[NAR]) {
-  if constexpr (S + kWA < words_per_sweep<NR>()) {
-    x.voff += 512u;
+  constexpr int j = S % NR, wi = j / 4, pos = j % 4, NW = class_words<NR>();
+  if constexpr (pos == 0) { // a new word: the next ones move up, one more is asked for
+#pragma unroll
+    for (int k = 0; k < kWA; ++k) x.w[k] = x.w[k + 1];
+#ifndef SB_EXP_NOCW // timing experiment: no class-word loads inside the sweeps (wrong coefficients)
+    if constexpr ((wi + kWA) % NW == 0) x.voff -= 512u * (NW - 1);
+    else x.voff += 512u;
     asm volatile("" : "+v"(x.voff)); // a running offset: nothing for the compiler to hoist
-    x.w[(S + kWA) % (kWA + 1)] = class_word(x);
+    x.w[kWA] = class_word(x);
+#endif
   }
-  const unsigned long long wd = x.w[S % (kWA + 1)];
-  const lds_d2 sa = (lds_d2)(unsigned)wd, sb = (lds_d2)(unsigned)(wd >> 32);
+  const unsigned h = pos < 2 ? (unsigned)x.w[0] : (unsigned)(x.w[0] >> 32);
+  const lds_d2 sa = (lds_d2)set_offset<2 * (pos & 1)>(h), sb = (lds_d2)set_offset<2 * (pos & 1) + 1>(h);
   // A last: the step's first FMA needs it, so its one s_waitcnt covers every read of the step
   if constexpr (TAIL && S >= 63) p.sm = *(const double __attribute__((address_space(3))) *)(x.seam + 8u * S);
   else p.sm = 0.0;
@@ -419,7 +433,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       bn = __builtin_amdgcn_readfirstlane(nb);
     }
     SB_STAMP(0);
-    first_words(x, lane);
+    first_words<NR>(x, lane);
     double *Ttail = a.temp + (size_t)b * a.state_doubles + NE * 64; // [T][NR]
     const double t_now = nx_tnow;
     // exterior-space cells outside the trim box all become t_now in the first sweep
@@ -524,7 +538,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             __builtin_amdgcn_sched_barrier(0);
             run_steps<NR, 63, NR + 63, TAIL, true>(g, w, Areg, pb, x, acc, last_step);
             __builtin_amdgcn_sched_barrier(0);
-            period_words(x, lane);
             md = sweep_end();
             d1 = d0;
             d0 = (float)md;
@@ -553,13 +566,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             for (int k = 0; k < 2; ++k)
               if (TAIL && t < a.T) tv[t][k] = Ttail[t * NR + tc0 + k];
           if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
-          first_words(x, lane);
+          first_words<NR>(x, lane);
           __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
         run_steps<NR, 63, NR + 63, TAIL, false>(g, w, Areg, pb, x, acc, last_step); // the block's last sweep
         __builtin_amdgcn_sched_barrier(0);
-        first_words(x, lane); // the next block's first class words
+        first_words<NR>(x, lane); // the next block's first class words
         SB_STAMP2(11);
         md = sweep_end();
         SB_STAMP2(12);

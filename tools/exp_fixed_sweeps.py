@@ -9,6 +9,11 @@ from bench import r9_plan
 
 B = int(os.environ.get("B", 65536))
 plan = r9_plan()
+if os.environ.get("PLAN"):   # PLAN=SB2-synth / SB1-synth: bench.py's mixed classes (B=21845)
+  import bench
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  name, rooms, shape = [c for c in bench.MIXED_CLASSES if c[0] == os.environ["PLAN"]][0]
+  plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
 res = []
 for lim in [int(x) for x in os.environ.get("LIMS", "1,3,5,9").split(",")]:
   env = BatchedEnvironment(plan, B, config=SimConfig(iteration_limit=lim, convergence_threshold=-1.0), holiday_calendar=None,
