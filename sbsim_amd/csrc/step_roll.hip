@@ -378,8 +378,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
       auto at = [&](int q) { return q < kAS ? Aw + q : Ax + (q - kAS); }; // position q of the lane's rotated row
       // groups of 8, software-pipelined: the table reads of group g+1 are issued before the A
       // values of group g are written (the compiler cannot prove that A and the tables do not alias).
-      // One ds_read_b128 per cell ((ap, g) of its class); slots (j, j + 1), j odd, sit at the even
-      // position j + 1 of the rotated row: one ds_write_b128 per pair.
+      // One ds_read_b128 per cell ((ap, g) of its class), one ds_write_b64.
       constexpr int kGroups = (NR + 7) / 8;
       d2 pg[2][8];
       auto fetch = [&](int g, d2 (&pp)[8]) {
@@ -402,9 +401,12 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
             const int j = 8 * g + k;
             const double av = fma(pg[g & 1][k].x, e[j], pg[g & 1][k].y);
             const int q = (j + 1) % NR; // position in the rotated row
-            if (j % 2 == 1 && j + 1 < NR && q + 1 < kNL) carry = av;                    // (q even) with slot j + 1: one 16-byte write
+#ifdef SB_A_WRITE_B128 // one 16-byte write per pair: the compiler assembles the pair with two v_mov -- three instructions and 13 LDS cycles against two and 12
+            if (j % 2 == 1 && j + 1 < NR && q + 1 < kNL) carry = av;
             else if (j % 2 == 0 && j > 0 && q < kNL && q - 1 >= 0 && (q - 1) % 2 == 0) *(d2 *)at(q - 1) = d2{carry, av};
-            else if (q < kNL) *at(q) = av;
+            else
+#endif
+            if (q < kNL) *at(q) = av;
             else Areg[q - kNL] = av;
           }
         __builtin_amdgcn_sched_barrier(0);
