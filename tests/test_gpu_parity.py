@@ -420,6 +420,47 @@ def test_full_size_batch_register_and_lds_kernels_agree(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 3, 5, 1030])
+def test_roll_kernel_workgroups_with_idle_and_drawing_wavefronts(B, monkeypatch):
+  """k_sweep_roll runs four buildings = four wavefronts per workgroup that share the steps' class words
+  in LDS: batches that leave wavefronts of the last workgroup without a building (1, 3, 5) and one just
+  above the 1,024 resident wavefronts (the first draws from the device counter) against the LDS-grid
+  kernel -- equal sweep counts for every building, grids within 1e-9 K."""
+  _need_gpu()
+  T = 8
+  p = load("plan_r9_sb1.npz")
+  g = load("h2_sb1_r9_random.npz")
+  gen = torch.Generator(device="cuda")
+  gen.manual_seed(11 + B)
+  t0 = (294.0 + torch.randn((B, 1), generator=gen, device="cuda", dtype=torch.float64)).clamp(285.0, 305.0)
+  init = (t0 + 0.05 * torch.randn((B, 68 * 98), generator=gen, device="cuda", dtype=torch.float64)).contiguous()
+  acts = torch.rand((T, B, 2), generator=gen, device="cuda", dtype=torch.float32) * 2.0 - 1.0
+  sims = []
+  for force_lds in (False, True):
+    if force_lds:
+      monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
+    sim = BatchedSimulator(_plan(p), SimConfig.sb1(), B, float(g["h_conv"]))
+    assert sim.launch_info["path"] == (0 if force_lds else 1)
+    if not force_lds:
+      assert sim.launch_info["kernel"] == 3 and sim.launch_info["waves_per_workgroup"] == 4
+      assert sim.launch_info["workgroups"] == min((B + 3) // 4, 256)
+    sim.reset(temps=init)
+    sims.append(sim)
+  obs = [torch.zeros((B, s.O), dtype=torch.float32, device="cuda") for s in sims]
+  rew = [torch.zeros((B,), dtype=torch.float32, device="cuda") for _ in sims]
+  info = [torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda") for _ in sims]
+  for t in range(T):
+    si = _step_in(g, 100 + t)
+    for k, sim in enumerate(sims):
+      sim.step(acts[t], si, obs[k], rew[k], info[k])
+    assert torch.equal(info[0][:, 4], info[1][:, 4]), t
+    assert float((sims[0].zone_temps() - sims[1].zone_temps()).abs().max()) < 1e-9, t
+  assert float((sims[0].temps() - sims[1].temps()).abs().max()) < 1e-9
+  for sim in sims:
+    sim.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("band", [False, True])
 @pytest.mark.parametrize("rooms,room_shape,B", [((8, 5), (12, 14), 21845), ((14, 9), (8, 7), 21845)])
 def test_mixed_classes_at_size_block_and_lds_kernels_agree(rooms, room_shape, B, band, monkeypatch):
