@@ -188,7 +188,7 @@ typedef enum sb_sweep_kernel {
 
 /* Launch geometry chosen for the floor plan (reported for DESIGN.md / bench.py). */
 typedef struct sb_launch_info {
-  int32_t waves_per_workgroup, workgroups, lds_bytes_per_workgroup, sweep_steps;
+  int32_t waves_per_workgroup, workgroups, lds_bytes_per_workgroup, sweep_steps; /* SB_KERNEL_ROLL: four wavefronts = four buildings per workgroup (they share the steps' class words in LDS) */
   int64_t algorithmic_bytes_per_env_step; /* 8HW+24Z+4A+4O+44 (fp32 state) */
   int64_t state_bytes_per_env_step;       /* what this build really moves: fp64 grid r+w */
   int32_t path;               /* 1: grid in registers, 0: grid in LDS (step_lds.hip), 2: grid in global memory (step_stream.hip) */
