@@ -26,31 +26,41 @@ def offsets(distance: int):
           if dx * dx + dy * dy <= distance]
 
 
-WIDE_TRIAL_BLOCKS = 16   # rejection sampling: 4 candidates per Philox block
+WIDE_MAX_BLOCKS = 4095   # Philox blocks (four candidates each) a wide-window draw may use: the counter word has 12 bits for it
 
 
-def wide_partner(gb: int, call: int, g0: int, seed: int, distance: int, accept):
+def wide_partner(gb: int, call: int, g0: int, seed: int, distance: int, accept, ranked=None, W: int = 0):
   """The device's partner choice for windows of more than 64 offsets (distance >= 20; distance = -1
-  with p < 1 is the reference's 1000: stochastic_convection_simulator.py:108-109): rejection sampling --
-  (dx, dy) uniform in [-R, R]^2, R = floor(sqrt(distance)), accepted when dx^2 + dy^2 <= distance and
-  the cell is in the room (`accept(dx, dy)` -> the partner's index in the room, or -1).  Uniform over the
-  reference's candidate list (the window [-d, d) does not cut the disc: R < d).  Draws: Philox blocks
-  with counter word 3 = g0 | (block + 1) << 20, each word one candidate; no candidate accepted after
-  WIDE_TRIAL_BLOCKS blocks: the cell stays (None)."""
+  with p < 1 is the reference's 1000: stochastic_convection_simulator.py:108-109): rejection sampling,
+  uniform over the reference's candidate list (:122-131; the window [-d, d) does not cut the disc:
+  floor(sqrt(d)) < d).  A room with fewer cells than the window's box (2R + 1)^2, R = floor(sqrt(distance)):
+  a cell of the room, uniform by its rank in raster order (`ranked`: the room's grid indices, sorted), kept
+  when dx^2 + dy^2 <= distance -> its grid index.  Otherwise: (dx, dy) uniform in [-R, R]^2, kept when inside
+  the disc and in the room (`accept(dx, dy)` -> the partner's index in the room, or -1).  The cell itself is a
+  candidate, so a draw is accepted sooner or later (after WIDE_MAX_BLOCKS blocks the cell stays: None).
+  Draws: Philox blocks with counter word 3 = g0 | (block + 1) << 20, each word one candidate."""
   M = 0xFFFFFFFF
   R = int(np.floor(np.sqrt(distance)))
   one = lambda v: np.array([v], dtype=np.uint64)
-  for blk in range(WIDE_TRIAL_BLOCKS):
+  by_rank = ranked is not None and len(ranked) < (2 * R + 1) ** 2
+  x0, y0 = divmod(g0, W) if by_rank else (0, 0)
+  for blk in range(WIDE_MAX_BLOCKS):
     w = philox4x32_10(one(gb & M), one(gb >> 32), one(call), one(g0 | ((blk + 1) << 20)), seed & M, (seed >> 32) & M)
     for k in range(4):
       x = int(w[k][0])
+      if by_rank:
+        g = int(ranked[(x * len(ranked)) >> 32])
+        xx, yy = divmod(g, W)
+        if (xx - x0) ** 2 + (yy - y0) ** 2 <= distance:
+          return ("cell", g)
+        continue
       dx = (((x & 0xFFFF) * (2 * R + 1)) >> 16) - R
       dy = (((x >> 16) * (2 * R + 1)) >> 16) - R
       if dx * dx + dy * dy > distance:
         continue
       j = accept(dx, dy)
       if j >= 0:
-        return j
+        return ("index", j)
   return None
 
 
@@ -96,6 +106,7 @@ class ConvectionOracle:
     for z, cells in enumerate(self.zones):
       self.room[cells] = z
       self.local[cells] = np.arange(len(cells))
+    self.ranked = [np.sort(c) for c in self.zones]          # a room's cells by rank = raster order of the caller's grid
     self.call = 0
 
   def swaps(self, b: int, z: int, call: int):
@@ -117,9 +128,8 @@ class ConvectionOracle:
           if 0 <= xx < self.H and 0 <= yy < self.W and self.room[xx * self.W + yy] == z:
             return int(self.local[xx * self.W + yy])
           return -1
-        other = wide_partner(gb, call, int(cells[i]), self.seed, self.distance, accept)
-        if other is None:
-          other = i
+        hit = wide_partner(gb, call, int(cells[i]), self.seed, self.distance, accept, ranked=self.ranked[z], W=self.W)
+        other = i if hit is None else (int(self.local[hit[1]]) if hit[0] == "cell" else hit[1])
       else:
         cand = []
         for dx, dy in self.off:

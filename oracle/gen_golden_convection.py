@@ -6,7 +6,9 @@ TEST INFRASTRUCTURE -- runs only in the build container: imports the REFERENCE
 16 x 20 grid with one 14 x 18 room whose temperatures are the cells' own indices, many times.
 Recorded per (p, distance): the probability that a value starting at least 4 cells away from the
 walls ends at offset (dx, dy), dx, dy in -8..8; the fraction of ALL room values that do not move;
-the mean squared displacement of all room values.  Output: tests/golden/convection_stats.npz.
+the mean squared displacement of all room values.  A second layout holds rooms of 9, 60 and 100 cells under
+the wide windows (distance = -1 with p < 1; distance 30): per room, the fraction of values that stay and the
+mean squared displacement.  Output: tests/golden/convection_stats.npz.
 
     python -m oracle.gen_golden_convection
 """
@@ -26,6 +28,11 @@ H, W = 16, 20
 # offsets (squared distance <= 20).  New cases go at the END: a case's seed is 1234 + its index.
 CASES = [(1.0, 5), (0.5, 5), (1.0, 2), (1.0, -1), (0.5, -1), (1.0, 20)]
 TRIALS = 400
+# a second layout: rooms of 9, 60 and 100 cells (x0, y0, height, width) in a 14 x 26 grid, wide windows only
+SMALL_H, SMALL_W = 14, 26
+SMALL_ROOMS = [(1, 1, 3, 3), (5, 1, 6, 10), (1, 13, 10, 10)]
+SMALL_CASES = [(0.5, -1), (1.0, 30)]
+SMALL_TRIALS = 800
 
 
 def main() -> None:
@@ -62,6 +69,35 @@ def main() -> None:
     out[f"fixed_{ci}"] = np.array(fixed / (TRIALS * len(room)))
     out[f"msd_{ci}"] = np.array(msd / (TRIALS * len(room)))
     print(p, dist, "fixed", out[f"fixed_{ci}"], "msd", out[f"msd_{ci}"], "inner samples", n_inner)
+  # Rooms SMALLER than a wide window: the reference always draws from the room's candidate list
+  # (:108-131), so a 9-cell room mixes as thoroughly as a 100-cell one.  Per room: the fraction of values
+  # that do not move and the mean squared displacement.
+  room_dict = {"exterior_space": [], "interior_wall": []}
+  for ri, (x0, y0, h, w) in enumerate(SMALL_ROOMS):
+    room_dict[f"room_{ri + 1}"] = [(x, y) for x in range(x0, x0 + h) for y in range(y0, y0 + w)]
+  ids = np.arange(SMALL_H * SMALL_W, dtype=np.float64).reshape(SMALL_H, SMALL_W)
+  out["small_shape"] = np.array([SMALL_H, SMALL_W])
+  out["small_rooms"] = np.array(SMALL_ROOMS)
+  out["small_cases"] = np.array(SMALL_CASES, dtype=np.float64)
+  out["small_trials"] = np.array(SMALL_TRIALS)
+  for ci, (p, dist) in enumerate(SMALL_CASES):
+    sim = scs.StochasticConvectionSimulator(p=p, distance=dist, seed=4321 + ci)
+    fixed = np.zeros(len(SMALL_ROOMS))
+    msd = np.zeros(len(SMALL_ROOMS))
+    for _ in range(SMALL_TRIALS):
+      temp = ids.copy()
+      sim.apply_convection(room_dict, temp)
+      for ri, (x0, y0, h, w) in enumerate(SMALL_ROOMS):
+        blk = temp[x0:x0 + h, y0:y0 + w].astype(np.int64)
+        sx, sy = np.divmod(blk, SMALL_W)
+        x, y = np.meshgrid(np.arange(x0, x0 + h), np.arange(y0, y0 + w), indexing="ij")
+        assert ((sx >= x0) & (sx < x0 + h) & (sy >= y0) & (sy < y0 + w)).all()   # values stay in their room
+        fixed[ri] += ((sx == x) & (sy == y)).sum()
+        msd[ri] += ((sx - x) ** 2 + (sy - y) ** 2).sum()
+    n = np.array([h * w for _, _, h, w in SMALL_ROOMS], dtype=np.float64) * SMALL_TRIALS
+    out[f"small_fixed_{ci}"] = fixed / n
+    out[f"small_msd_{ci}"] = msd / n
+    print("small rooms", p, dist, "fixed", out[f"small_fixed_{ci}"], "msd", out[f"small_msd_{ci}"])
   np.savez_compressed(os.path.join(GOLD, "convection_stats.npz"), **out)
 
 

@@ -108,6 +108,7 @@ struct ConvArgs {
   // the partner by rejection sampling inside the disc (oracle/convection_oracle.py wide_partner)
   int wide, wide_r, wide_d, H, transposed;
   const short *room; // [N] the cell's room in the handle's grid (-1: none)
+  const int *by_rank; // by_rank[zone_off[z] + r]: index (in the zone's cell list) of the room's r-th cell in the CALLER's raster order
   double p;
   uint64_t seed;
   long long first_building;
@@ -115,6 +116,7 @@ struct ConvArgs {
 };
 
 constexpr int kConvMaxThreads = 512, kConvMaxPerLane = 8;
+constexpr int kWideMaxBlocks = 4095; // Philox blocks of four candidates a wide-window draw may use (the counter word has 12 bits for it)
 
 // The whole-room shuffle (distance = -1, p = 1: stochastic_convection_simulator.py:78-99,
 // _shuffle_no_max_dist): the values of a room's cells are permuted uniformly at random
@@ -180,21 +182,39 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
           philox4x32_10(c, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
           const double u = (double)(c[0] >> 8) * (1.0 / 16777216.0);
           int other = i;
-          if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table
-            const int xh = cc[q].gh / o.W, yh = cc[q].gh - xh * o.W, span = 2 * o.wide_r + 1;
+          if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table: the partner by rejection --
+            // uniform over the reference's candidate list (:122-131; the cell itself is a candidate, so a draw is
+            // accepted sooner or later; after kWideMaxBlocks Philox blocks -- never, for a room that is not a
+            // single cell of a 2047-cell comb -- the cell stays)
+            const int span = 2 * o.wide_r + 1, W0 = o.transposed ? o.H : o.W; // W0: row length of the caller's grid
             bool found = false;
-            for (int blk = 0; blk < 16 && !found; ++blk) {
-              uint32_t t[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc[q].g0 | ((uint32_t)(blk + 1) << 20)};
-              philox4x32_10(t, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
+            if (n < span * span) { // the room has fewer cells than the window's box: a cell of the room (by rank), kept when inside the disc
+              const int x0 = cc[q].g0 / W0, y0 = cc[q].g0 - x0 * W0;
+              for (int blk = 0; blk < kWideMaxBlocks && !found; ++blk) {
+                uint32_t t[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc[q].g0 | ((uint32_t)(blk + 1) << 20)};
+                philox4x32_10(t, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const int dx = (int)(((t[k] & 0xffffu) * (uint32_t)span) >> 16) - o.wide_r;
-                const int dy = (int)(((t[k] >> 16) * (uint32_t)span) >> 16) - o.wide_r;
-                const int hx = xh + (o.transposed ? dy : dx), hy = yh + (o.transposed ? dx : dy);
-                if (!found && dx * dx + dy * dy <= o.wide_d && hx >= 0 && hx < o.H && hy >= 0 && hy < o.W &&
-                    (int)o.room[hx * o.W + hy] == z) {
-                  other = o.local[hx * o.W + hy];
-                  found = true;
+                for (int k = 0; k < 4; ++k) {
+                  const int j = o.by_rank[c0 + (int)(((unsigned long long)t[k] * (unsigned long long)n) >> 32)];
+                  const int gj = o.cells[c0 + j].g0, dx = gj / W0 - x0, dy = gj - (gj / W0) * W0 - y0;
+                  if (!found && dx * dx + dy * dy <= o.wide_d) { other = j; found = true; }
+                }
+              }
+            } else { // a square of the box, kept when inside the disc and in the room
+              const int xh = cc[q].gh / o.W, yh = cc[q].gh - xh * o.W;
+              for (int blk = 0; blk < kWideMaxBlocks && !found; ++blk) {
+                uint32_t t[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc[q].g0 | ((uint32_t)(blk + 1) << 20)};
+                philox4x32_10(t, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int dx = (int)(((t[k] & 0xffffu) * (uint32_t)span) >> 16) - o.wide_r;
+                  const int dy = (int)(((t[k] >> 16) * (uint32_t)span) >> 16) - o.wide_r;
+                  const int hx = xh + (o.transposed ? dy : dx), hy = yh + (o.transposed ? dx : dy);
+                  if (!found && dx * dx + dy * dy <= o.wide_d && hx >= 0 && hx < o.H && hy >= 0 && hy < o.W &&
+                      (int)o.room[hx * o.W + hy] == z) {
+                    other = o.local[hx * o.W + hy];
+                    found = true;
+                  }
                 }
               }
             }
@@ -408,7 +428,7 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
       by_rank[(size_t)c0 + rank_of[g]] = i;
       ConvCell &c = cells[(size_t)c0 + i];
       c.gh = g; c.g0 = transposed ? y * d.H + x : g; c.sidx = h->h_state_index[g]; c.pad = rank_of[g]; c.mask = 0;
-      for (size_t k = 0; k < offd.size(); ++k) {
+      for (size_t k = 0; k < odx.size(); ++k) { // (wide: no offset table, no mask)
         const int xx = x + odx[k], yy = y + ody[k];
         if (xx >= 0 && xx < d.H && yy >= 0 && yy < d.W && room[xx * d.W + yy] == z) c.mask |= 1ull << k;
       }
@@ -460,7 +480,7 @@ int sb_launch_convection(sb_handle *h, hipStream_t stream) {
   o.B = d.B; o.Z = d.Z; o.W = d.W; o.n_off = h->conv_n_off; o.max_room = h->conv_max_room;
   o.p = h->conv_p; o.seed = h->conv_seed; o.first_building = h->conv_first; o.call = h->conv_calls++;
   o.wide = h->conv_wide ? 1 : 0; o.wide_d = h->conv_wide_d; o.wide_r = (int)std::floor(std::sqrt((double)h->conv_wide_d));
-  o.H = d.H; o.transposed = h->conv_transposed ? 1 : 0; o.room = h->conv_room.p;
+  o.H = d.H; o.transposed = h->conv_transposed ? 1 : 0; o.room = h->conv_room.p; o.by_rank = h->conv_by_rank.p;
   const size_t lds = (size_t)o.max_room * (16 + 8 + 4);
   // cells per lane: workgroups of about 256 lanes; the grid is exactly what is resident at once
   // (the runtime's occupancy for this instantiation), so that every workgroup gets the same number

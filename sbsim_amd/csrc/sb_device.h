@@ -116,6 +116,13 @@ struct Dev {
   int *nsw;                // [B] sweeps | converged << 16
   int *next_b;             // draw counter of the sweep kernel (zeroed before every launch)
   int sweep_wgs;           // buildings handed out statically (one per workgroup / wavefront) before the draws
+  // mode 3 (step_roll.hip): buildings whose stopping decision the fast kernel's 32-bit maximum cannot make
+  int *redo_ctr;           // [0] entries of redo_list, [1] the exact kernel's draw counter (both zeroed with next_b)
+  int *redo_list;          // [B]
+  double *redo_scratch;    // [wavefronts][state_doubles]: where such a building's rows go instead of its state
+  int redo_mode;           // 1 in the exact kernel's launch on the list
+  int roll_exact;          // SBSIM_ROLL_EXACT=1: the exact kernel alone (cross-check)
+  int dbg_redo_mod;        // SBSIM_DEBUG_FORCE_REDO=m: every m-th building goes through the redo list (tests)
   // observation layout (sb_obs_layout): sources in sorted (device, field) order
   int O, col_ahu, col_blr, col_aux;
   const int *col_zone;

@@ -144,7 +144,10 @@ __global__ void k_copy_scalars(Dev a, double *out) {
 // Per-building algebra before / after the sweep kernel: one thread per building (sb_device.h).
 // only >= 0: that building alone (the known-answer taps).
 __global__ void __launch_bounds__(64) k_pre(Dev a, StepArgs s, int only) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_b = 0; // the sweep kernel's draw counter
+  if (blockIdx.x == 0 && threadIdx.x == 0) { // the sweep kernel's draw counter; mode 3: the redo list's counters
+    *a.next_b = 0;
+    if (a.redo_ctr) a.redo_ctr[0] = a.redo_ctr[1] = 0;
+  }
   if (only >= 0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) pre_building(a, s, only);
     return;
@@ -1094,6 +1097,15 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   SB_TRY(alloc_zero(h->gsum, (size_t)d.B));
   SB_TRY(alloc_zero(h->nsw, (size_t)d.B));
   SB_TRY(alloc_zero(h->next_b, 1));
+  d.redo_ctr = nullptr; d.redo_list = nullptr; d.redo_scratch = nullptr; d.redo_mode = 0; d.roll_exact = 0; d.dbg_redo_mod = 0;
+  if (d.reg && d.P == 3) { // step_roll.hip: the list of buildings the fast kernel leaves to the exact one
+    SB_TRY(alloc_zero(h->redo_ctr, 2));
+    SB_TRY(alloc_zero(h->redo_list, (size_t)d.B));
+    SB_TRY(alloc_zero(h->redo_scratch, (size_t)h->info.workgroups * h->info.waves_per_workgroup * d.state_doubles));
+    d.redo_ctr = h->redo_ctr.p; d.redo_list = h->redo_list.p; d.redo_scratch = h->redo_scratch.p;
+    if (const char *e = getenv("SBSIM_ROLL_EXACT")) d.roll_exact = atoi(e) != 0;
+    if (const char *e = getenv("SBSIM_DEBUG_FORCE_REDO")) d.dbg_redo_mod = std::max(0, atoi(e));
+  }
 #undef SB_TRY
   d.next_b = h->next_b.p;
   // buildings handed out statically before the draw counter: register path = workgroups, LDS-grid path and mode 3 = wavefronts
@@ -1183,6 +1195,7 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   if (phases & SB_PHASE_SWEEP) {
     if (!(phases & SB_PHASE_PRE)) // k_pre zeroes the sweep kernel's draw counter; without it in this call:
       SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream));
+    if (!(phases & SB_PHASE_PRE) && d.redo_ctr) SB_HIP(hipMemsetAsync(d.redo_ctr, 0, 2 * sizeof(int), (hipStream_t)stream));
     const int e = d.reg ? (d.P == 6   ? launch_sweep_stream(d, h->abuf.p, h->info.waves_per_workgroup, (hipStream_t)stream)
                        : d.P == 5 ? launch_sweep_band(d, (hipStream_t)stream)
                        : d.P == 4 ? launch_sweep_two(d, (hipStream_t)stream)

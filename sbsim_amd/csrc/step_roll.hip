@@ -61,9 +61,19 @@ struct PairBuf { // LDS values of two consecutive steps
 };
 
 struct Acc {
+  // EXACT: float64 maxima, routed by sign in the window steps
   double cur; // max |delta| of the sweep the lanes are finishing
   double neg; // -(max |delta|) of the sweep the lanes have started (window steps)
   int sg;     // 0x80000000 in the lanes that have started the next sweep
+  // !EXACT: the TRAVELLING maximum.  Column c of a sweep is worked on by lane l at step c + l (+ sweep * NR):
+  // an accumulator that moves one lane down per step stays in ONE column of ONE sweep, enters lane 0 as 0
+  // and leaves lane 63 as that column's max |delta| -- no lane ever mixes two sweeps, so the window steps
+  // need no routing.  It carries the HIGH WORD of |delta| (as a float: the order of positive doubles is the
+  // order of their high words is the order of those words read as floats), so moving and accumulating is
+  // one v_max_f32_dpp; lane 63 collects what leaves in `fin` (its sweep ends exactly at the period's end).
+  // 20 mantissa bits decide every sweep whose max |delta| is not within 6e-8 K of the threshold; the rest
+  // (high words equal) are handed to the EXACT instantiation (k_sweep_roll<NR, true>, the redo list).
+  int tr, fin;
   // Row 63's new values on their way to the tail scan (lanes = columns there): lane 63's result of
   // the previous step reaches lane 0 as its "upper neighbour" (wave_ror; row 0's bU is 0), from
   // where two shift registers -- even / odd columns -- carry it one lane further per insertion.
@@ -78,6 +88,9 @@ struct Ctx {
   const double *seam;  // first tail row by step: the value under lane 63 at step s is seam[s]
   const unsigned long long *cw; // the lane's column of the class words in LDS: word k at [64 * k]
   unsigned long long w, wn;     // class word (8 steps) in use / the next one, in flight
+#ifdef SB_EXP_NOCOEF
+  d2 kc;
+#endif
 };
 
 // Class words hold one byte per step: the step's coefficient set (its LDS byte offset is set * 32; the
@@ -105,9 +118,18 @@ __device__ __forceinline__ lds_d2 step_set(Ctx<NR> &x) {
 // seam values.  Position of slot j in the lane's A row: (j + 1) mod NR -- even for odd S.
 template <int NR, int S, bool SEAM, int NAR>
 __device__ __forceinline__ void load_first(PairBuf &p, Ctx<NR> &x, const double (&Areg)[NAR]) {
+#ifdef SB_EXP_NOCOEF // timing experiment: coefficients from registers, no table reads
+  p.ud0 = p.lr0 = x.kc;
+  const lds_d2 ct = nullptr;
+#else
   const lds_d2 ct = step_set<NR, S>(x);
   p.ud0 = ct[0];
+#endif
+#if defined(SB_EXP_ONECOEF)
+  p.lr0 = p.ud0;
+#elif !defined(SB_EXP_NOCOEF)
   p.lr0 = ct[1];
+#endif
   constexpr int q = (S + 1) % NR, NL = lds_slots(NR), AS = a_stride(NR);
   static_assert(q % 2 == 0 && AS % 2 == 0, "pairs start at odd steps");
   if constexpr (q < AS) p.A = *(const d2 *)(x.Arow + q);
@@ -118,9 +140,17 @@ __device__ __forceinline__ void load_first(PairBuf &p, Ctx<NR> &x, const double 
 }
 template <int NR, int S>
 __device__ __forceinline__ void load_second(PairBuf &p, Ctx<NR> &x) {
+#ifdef SB_EXP_NOCOEF
+  p.ud1 = p.lr1 = x.kc;
+#else
   const lds_d2 ct = step_set<NR, S>(x);
   p.ud1 = ct[0];
+#ifdef SB_EXP_ONECOEF // timing experiment: one coefficient read per step
+  p.lr1 = p.ud1;
+#else
   p.lr1 = ct[1];
+#endif
+#endif
 }
 
 // One Gauss-Seidel update of every lane's current cell at step S of the overlapped schedule:
@@ -128,7 +158,19 @@ __device__ __forceinline__ void load_second(PairBuf &p, Ctx<NR> &x) {
 //   63 <= S < NR      all 64 lanes are in the same sweep
 //   NR <= S < NR + 63 window: lanes <= S - NR are in the next sweep
 // Association order of the four products as in step_reg.hip / step_lds.hip.
-template <int NR, int S>
+// |d|'s high word joins the travelling maximum (which moves one lane down); lane 63 collects what arrived
+// with the PREVIOUS step first (the hazard recogniser puts a wait state between an inline-asm result and the
+// next instruction if that reads it -- gfx950's dst_sel forwarding rule, assumed of every asm -- so the two
+// instructions must not be producer and consumer back to back; the period's end collects the last step's)
+__device__ __forceinline__ void track(Acc &acc, double d) {
+#ifdef SB_EXP_NOTRACK // timing experiment: no max |delta|
+  return;
+#endif
+  asm("v_max_f32 %0, %0, %1" : "+v"(acc.fin) : "v"(acc.tr));
+  asm("v_max_f32_dpp %0, %0, |%1| wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc.tr) : "v"(__double2hiint(d)));
+}
+
+template <int NR, int S, bool EXACT>
 __device__ __forceinline__ void step(double (&e)[NR], double (&bk)[kWin], d2 ud, d2 lr, double A,
                                      double sm, Acc &acc) {
   constexpr int r = S % NR, rm = (S + NR - 1) % NR, rp = (S + 1) % NR;
@@ -141,16 +183,27 @@ __device__ __forceinline__ void step(double (&e)[NR], double (&bk)[kWin], d2 ud,
   const double U = wave_shift1<0x13c, false>(e[rm], 0.0); // wave_ror:1: lane 0 sees row 63's latest value (times bU = 0)
   t = fma(lr.x, e[rm], t);
   const double nv = fma(ud.x, U, t);
+#ifndef SB_EXP_NOSR // timing experiment: row 63 is not published
   if constexpr (S > kWin) { // lane 0's U is column S - 64 of row 63: into the shift register of its parity
     double &sr = (S - kWin - 1) % 2 == 0 ? acc.sre : acc.sro;
     sr = wave_shift1<0x138, true>(sr, U);
   }
+#endif
   if constexpr (S < kWin) {
     const double sel = lanes_upto<S>() ? nv : e[r];
-    acc.cur = fmax(acc.cur, fabs(sel - e[r]));
+    if constexpr (EXACT) acc.cur = fmax(acc.cur, fabs(sel - e[r]));
+    else track(acc, sel - e[r]);
     e[r] = sel;
   } else if constexpr (S < NR) {
-    acc.cur = fmax(acc.cur, fabs(nv - e[r]));
+    if constexpr (EXACT) acc.cur = fmax(acc.cur, fabs(nv - e[r]));
+    else track(acc, nv - e[r]);
+    e[r] = nv;
+  } else if constexpr (!EXACT) {
+    constexpr int J = S - NR;
+    track(acc, nv - e[r]);
+#ifndef SB_EXP_NOCOPY // timing experiment: the window keeps no copies
+    bk[J] = e[r];
+#endif
     e[r] = nv;
   } else {
     constexpr int J = S - NR;
@@ -179,7 +232,7 @@ constexpr int kBufs = kDepth + 1;         // 48 pairs per period: kBufs must div
 static_assert(48 % kBufs == 0, "pair buffers rotate through a whole period");
 constexpr int pair_buf(int S) { return ((S - 1) / 2) % kBufs; }
 
-template <int NR, int S, int S1, bool WRAP, int NAR>
+template <int NR, int S, int S1, bool WRAP, bool EXACT, int NAR>
 __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], const double (&Areg)[NAR],
                                            PairBuf (&pb)[kBufs], Ctx<NR> &x, Acc &acc) {
   if constexpr (S < S1) {
@@ -192,13 +245,13 @@ __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], 
 #endif
     load_first<NR, N, !wrapped>(nxt, x, Areg);
     __builtin_amdgcn_sched_barrier(0);
-    step<NR, S>(e, bk, cur.ud0, cur.lr0, cur.A.x, cur.sm.x, acc);
+    step<NR, S, EXACT>(e, bk, cur.ud0, cur.lr0, cur.A.x, cur.sm.x, acc);
     __builtin_amdgcn_sched_barrier(0);
     load_second<NR, N + 1>(nxt, x);
     __builtin_amdgcn_sched_barrier(0);
-    step<NR, S + 1>(e, bk, cur.ud1, cur.lr1, cur.A.y, cur.sm.y, acc);
+    step<NR, S + 1, EXACT>(e, bk, cur.ud1, cur.lr1, cur.A.y, cur.sm.y, acc);
     __builtin_amdgcn_sched_barrier(0);
-    roll_pairs<NR, S + 2, S1, WRAP>(e, bk, Areg, pb, x, acc);
+    roll_pairs<NR, S + 2, S1, WRAP, EXACT>(e, bk, Areg, pb, x, acc);
   }
 }
 
@@ -245,8 +298,14 @@ __device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kW
 
 extern __shared__ __attribute__((aligned(16))) double lds[];
 
-template <int NR>
+// EXACT = false: the library's kernel (travelling max |delta| on high words; a sweep whose decision those 32
+// bits cannot make puts its building on the redo list and leaves its state alone).  EXACT = true: float64
+// maxima; launched after the fast kernel on the redo list (a.redo_mode: building numbers come from the list),
+// or as the only kernel (SBSIM_ROLL_EXACT=1: the cross-check).
+template <int NR, bool EXACT>
 __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_roll(Dev a) {
+  const int nB = a.redo_mode ? __builtin_amdgcn_readfirstlane(a.redo_ctr[0]) : a.B; // buildings of this launch
+  if (nB == 0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); // one wavefront per SIMD, each with its own buildings
   const int gw = (int)blockIdx.x * kWaves + wave;
@@ -279,6 +338,9 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
   x.seam = tE0 - kWin; // lane 63 works on column s - 63 at step s
   x.cw = ctab8 + lane;
   x.w = x.wn = 0;
+#ifdef SB_EXP_NOCOEF
+  x.kc = d2{0.2 + 1e-9 * opaque(lane), 0.2};
+#endif
   // the lane's tail cells (static per floor plan): table offsets of their coefficient sets
   // (two 16-bit halves) and of their classes (two bytes)
   const bool tactive = tail_col<NR>(lane, 0) >= 0; // the lane owns two tail columns
@@ -315,24 +377,27 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
       _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
         if (t < a.T) nx_tail[t][k] = tt_[t * NR + tc0 + k];                                     \
   } while (0)
-  if (gw < a.B) {
-    const double *tp_ = a.temp + (size_t)gw * a.state_doubles;
+  // launch slot -> building: the redo launch walks the list the fast kernel wrote
+  auto building = [&](int s) { return a.redo_mode ? __builtin_amdgcn_readfirstlane(a.redo_list[s]) : s; };
+  const int b_first = gw < nB ? building(gw) : 0;
+  if (gw < nB) {
+    const double *tp_ = a.temp + (size_t)b_first * a.state_doubles;
 #pragma unroll
     for (int j = 0; j < NR; j += 2) { // state layout [NR / 2][64][2]
       const d2 v = __builtin_nontemporal_load((const d2 *)(tp_ + j * 64 + 2 * R));
       e[j] = v.x;
       e[j + 1] = v.y;
     }
-    SB_LOAD_AUX(gw);
+    SB_LOAD_AUX(b_first);
   }
   // Buildings need different numbers of sweeps: after its first building a workgroup draws the
   // next one from a device counter (zeroed before every launch).
   int iter = 0;
-  for (int b = gw, bn = 0; b < a.B; b = bn, ++iter) {
+  for (int s = gw, sn = 0, b = b_first, bn = 0; s < nB; s = sn, b = bn, ++iter) {
     // the draw of the NEXT building: issued here, read before the hand-over (an atomic's round trip
     // to L2 is 1-2 us: the sweeps hide it)
     int nb = 0;
-    if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
+    if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1); // (the redo launch: its own counter and wavefront count)
     SB_STAMP(0);
     unsigned long long amapw[kASlots]; // issued here, used by the A pass: the setup hides the latency
     {
@@ -341,7 +406,6 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
       for (int g = 0; g < kASlots; ++g) amapw[g] = amap[o + g * 64];
       x.wn = x.cw[0]; // the first class word of the ramp-up
     }
-    double *Ttail = a.temp + (size_t)b * a.state_doubles + NR * 64; // [T][NR]
     __builtin_amdgcn_sched_barrier(0);
     const double t_now = nx_tnow;
     // exterior-space cells outside the trim box all become t_now in the first sweep
@@ -416,12 +480,13 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(2);
 
-    int n_sweeps = 0, converged = 0;
+    int n_sweeps = 0, converged = 0, redo = 0;
     double bk[kWin]; // the window's copies: what the started sweep overwrote
     {
       PairBuf pb[kBufs];
       Acc acc;
       acc.cur = 0.0; acc.neg = 0.0; acc.sg = lane == 0 ? (int)0x80000000 : 0;
+      acc.tr = acc.fin = 0;
       acc.sre = acc.sro = 0.0;
       // step 0 (lane 0, column 0) on its own: pairs start at odd steps
       {
@@ -434,16 +499,16 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
           load_second<NR, 4>(pb[pair_buf(3)], x);
         }
         static_assert(kDepth <= 2, "initial fill of the pair buffers");
-        step<NR, 0>(e, bk, ud, lr, x.Arow[1], 0.0, acc);
+        step<NR, 0, EXACT>(e, bk, ud, lr, x.Arow[1], 0.0, acc);
       }
       __builtin_amdgcn_sched_barrier(0);
-      roll_pairs<NR, 1, kWin, false>(e, bk, Areg, pb, x, acc); // ramp-up; reads ahead for the first pairs of the period
+      roll_pairs<NR, 1, kWin, false, EXACT>(e, bk, Areg, pb, x, acc); // ramp-up; reads ahead for the first pairs of the period
 #pragma nounroll
       for (;;) { // simulator.py:348-368
         __builtin_amdgcn_sched_barrier(0);
 #define SB_STAMP2(i) do { if (a.dbg && gw == 0 && iter == 10 && n_sweeps == 1 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
         SB_STAMP2(10);
-        roll_pairs<NR, kWin, NR + kWin, true>(e, bk, Areg, pb, x, acc);
+        roll_pairs<NR, kWin, NR + kWin, true, EXACT>(e, bk, Areg, pb, x, acc);
         SB_STAMP2(11);
         // row 63's last column (lane 63's result of the period's last step) enters its shift register;
         // then both are reversed: lane l holds columns 2 (l - L0), 2 (l - L0) + 1, the tail scan's layout
@@ -460,13 +525,22 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
                                 __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sro)));
         }
         SB_STAMP2(12);
-        const double dm = fmax(acc.cur, tail_pass<NR>(a.T, tactive, tE0 + tc0, U0, U1, tv, tset, At));
+        const double dt_ = tail_pass<NR>(a.T, tactive, tE0 + tc0, U0, U1, tv, tset, At);
         SB_STAMP2(13);
-        double md = wave_max(dm);
+        double md = wave_max(EXACT ? fmax(acc.cur, dt_) : dt_);
         if (n_sweeps == 0) md = fmax(md, ring_d);
         SB_STAMP2(14);
         ++n_sweeps;
         converged = md <= p.conv_threshold;
+        if constexpr (!EXACT) { // the wavefront's rows: lane 63 has collected every column's maximum (high words)
+          asm("v_max_f32 %0, %0, %1" : "+v"(acc.fin) : "v"(acc.tr)); // the period's last step
+          const int m_hi = __builtin_amdgcn_readlane(acc.fin, 63), thr_hi = __double2hiint(p.conv_threshold);
+          acc.fin = 0;
+          acc.tr = lanes_upto<62>() ? acc.tr : 0; // lane 63's was this sweep's last column: the next step's collect must not see it again
+          const bool undecided = m_hi == thr_hi || (a.dbg_redo_mod > 0 && b % a.dbg_redo_mod == 0); // (a test hook)
+          if (converged && undecided) { redo = 1; break; } // 32 bits cannot tell: the exact kernel takes the building
+          converged = converged && m_hi < thr_hi;
+        }
 #ifdef SB_EXP_DESYNC // timing experiments: sweep counts 1..9 by building number (mean 5), whatever the numbers are
         if (n_sweeps >= 1 + (int)(((unsigned)b * 2654435761u >> 13) % 9u)) break;
 #else
@@ -482,7 +556,8 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(3);
-    bn = __builtin_amdgcn_readfirstlane(nb);
+    sn = __builtin_amdgcn_readfirstlane(nb);
+    bn = sn < nB ? building(sn) : 0;
     SB_STAMP(4);
 
     // grid back to HBM.  Zone sums (A is dead now): every lane adds its cells into its own
@@ -496,7 +571,9 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
 #pragma unroll
       for (int g = 0; g < (kZPre < kZSlots ? kZPre : kZSlots); ++g) zw[g] = zm[g * 64];
       __builtin_amdgcn_sched_barrier(0);
-      double *tp = a.temp + (size_t)b * a.state_doubles;
+      // a building on its way to the redo list keeps its state: its rows go to the wavefront's scratch
+      double *tp = redo ? a.redo_scratch + (size_t)gw * a.state_doubles : a.temp + (size_t)b * a.state_doubles;
+      double *Ttail = tp + NR * 64; // [T][NR]
       for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + R] = 0.0;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -505,13 +582,13 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
           *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
           zs[(size_t)a.Z * ZRS + lane] += tv[t][0] + tv[t][1]; // the lane's own column of the scratch
         }
-      const double *np_ = a.temp + (size_t)(bn < a.B ? bn : b) * a.state_doubles;
+      const double *np_ = a.temp + (size_t)(sn < nB ? bn : b) * a.state_doubles;
       static_assert(RS == 64, "hand_over: slot stride");
       hand_over<NR, 0>(e, bk, zw, zm, tp + 2 * R, np_ + 2 * R, zs);
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(5);
-    if (bn < a.B) SB_LOAD_AUX(bn);
+    if (sn < nB) SB_LOAD_AUX(bn);
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(6);
     __builtin_amdgcn_wave_barrier();
@@ -533,14 +610,15 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
         if (zz > a.Z) v = 0.0;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (lane < 16 && zz < a.Z) a.zsum[(size_t)b * a.Z + zz] = v;
+        if (lane < 16 && zz < a.Z && !redo) a.zsum[(size_t)b * a.Z + zz] = v;
         if (lane < 16 && zz <= a.Z) gacc += v;
       }
       const double gsum = wave_sum(gacc);
-      if (lane == 0) {
+      if (lane == 0 && !redo) {
         a.gsum[b] = gsum + (double)a.n_ring * t_now;
         a.nsw[b] = n_sweeps | (converged << 16);
       }
+      if (lane == 0 && redo) a.redo_list[atomicAdd(a.redo_ctr, 1)] = b;
       SB_STAMP(8);
       if (a.dbg && gw == 0 && iter == 10 && lane == 0) a.dbg[9] = n_sweeps;
     }
@@ -557,15 +635,32 @@ int sweep_roll_a_stride(int NR) { return a_stride(NR); }
 int sweep_roll_seam_doubles(int NR, int T) { (void)T; return tail_row(NR); } // the first tail row, by column
 int sweep_roll_waves() { return kWaves; }
 
+int sweep_roll_redo_workgroups() { return 8; } // the exact kernel's launch on the redo list (a handful of buildings per step at most)
+
 int prepare_sweep_roll(const Dev &d) {
   if (d.NR != 96) return (int)hipErrorInvalidValue;
-  return (int)hipFuncSetAttribute((const void *)k_sweep_roll<96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  const int e = (int)hipFuncSetAttribute((const void *)k_sweep_roll<96, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         d.lds_reg_bytes);
+  if (e != (int)hipSuccess) return e;
+  return (int)hipFuncSetAttribute((const void *)k_sweep_roll<96, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   d.lds_reg_bytes);
 }
 
+// The fast kernel, then the exact one on whatever the fast one could not decide (it returns at once when the
+// list is empty).  d.roll_exact (SBSIM_ROLL_EXACT=1): the exact kernel alone, on every building.
 int launch_sweep_roll(const Dev &d, hipStream_t stream) {
   if (d.NR != 96) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((k_sweep_roll<96>), dim3((d.sweep_wgs + kWaves - 1) / kWaves), dim3(64 * kWaves), (size_t)d.lds_reg_bytes, stream, d);
+  const dim3 grid((d.sweep_wgs + kWaves - 1) / kWaves), block(64 * kWaves);
+  if (d.roll_exact) {
+    hipLaunchKernelGGL((k_sweep_roll<96, true>), grid, block, (size_t)d.lds_reg_bytes, stream, d);
+    return (int)hipGetLastError();
+  }
+  hipLaunchKernelGGL((k_sweep_roll<96, false>), grid, block, (size_t)d.lds_reg_bytes, stream, d);
+  Dev r = d;
+  r.redo_mode = 1;
+  r.next_b = d.redo_ctr + 1;
+  r.sweep_wgs = sweep_roll_redo_workgroups() * kWaves;
+  hipLaunchKernelGGL((k_sweep_roll<96, true>), dim3(sweep_roll_redo_workgroups()), block, (size_t)d.lds_reg_bytes, stream, r);
   return (int)hipGetLastError();
 }
 

@@ -172,10 +172,18 @@ def test_thermostat_only_rollouts_on_reference_test_plans(name, golden):
     assert abs(float(g["blr_return_temp"][0]) - 301.895482) < 1e-5
 
 
-def test_divergent_buildings_against_oracle():
+@pytest.mark.parametrize("mode", ["library", "exact-only", "redo-every-third", "redo-all"])
+def test_divergent_buildings_against_oracle(mode, monkeypatch):
   """Config-2 style: per-building initial temperatures and per-building random actions;
-  every building is checked against its own CPU-oracle twin."""
+  every building is checked against its own CPU-oracle twin.  k_sweep_roll decides a sweep on the high
+  words of max |delta| and leaves the few buildings those 32 bits cannot decide to its float64
+  instantiation (the redo list, step_roll.hip): the library's pair of launches, the float64 kernel alone,
+  and the pair with every third / every building forced through the list."""
   _need_gpu()
+  if mode == "exact-only":
+    monkeypatch.setenv("SBSIM_ROLL_EXACT", "1")
+  if mode.startswith("redo"):
+    monkeypatch.setenv("SBSIM_DEBUG_FORCE_REDO", "3" if mode == "redo-every-third" else "1")
   g = load("h2_sb1_r9_random.npz")
   p = load("plan_r9_sb1.npz")
   B, T = 24, 40
