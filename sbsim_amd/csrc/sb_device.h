@@ -80,6 +80,11 @@ struct Dev {
   const uint8_t *tcset;    // mode 3: [T][NR] coefficient sets of the tail cells (set * 8)
   const double *csetab;    // mode 3: [ncset][4] distinct (bU, bD, bL, bR); the sweep's class bytes index this table
   int ncset;
+  int csetab_doubles;      // doubles of csetab (mode 4 with two_sym: [sets][2] for the wavefront's cells, then [sets][4] for the tail cells)
+  int two_sym, two_level;  // mode 4 (step_two.hip): two-coefficient cells (bV, bH); how much of A stays in LDS (0 / 1 / 2: two / three / four buildings per CU)
+  double *two_abuf;        // mode 4: [workgroups][NR - NL][64][2] the slots of A that do not fit in LDS (L2-resident)
+  const int *zs_off;       // mode 4: [Z + 2] the compact zone-sum scratch (slots of zone z: zs_off[z] .. zs_off[z + 1] - 1; zone Z: every other cell, a slot per lane)
+  int tail_set_base, tail_pad_set; // mode 4: LDS byte offset of the tail cells' (bU, bD, bL, bR) table, and of its pad set
   int RS;                  // rows of the trimmed grid = row stride of the HBM state [NR][RS]
   int AS;                  // row stride of A in LDS (odd when it fits: bank-conflict free)
   int ZRS;                 // row stride of the zone-sum scratch [Z+1][ZRS] that aliases A (RS | 1)
@@ -156,8 +161,9 @@ int launch_sweep_roll(const Dev &d, hipStream_t stream);
 int launch_sweep_two(const Dev &d, hipStream_t stream);
 int prepare_sweep_two(const Dev &d);
 bool sweep_two_supported(int NR);
-int sweep_two_lds_slots(int NR);
-int sweep_two_a_stride(int NR);
+int sweep_two_levels();                  // how many LDS budgets the kernel is built for (level 0: two buildings per CU, 1: three, 2: four)
+int sweep_two_lds_slots(int NR, int level);
+int sweep_two_a_stride(int NR, int level);
 int sweep_two_seam_doubles(int NR);
 int sweep_two_set_table();
 // step_band.hip: mode 5 (two wavefronts, one row per lane: 67..130 rows, <= 80 columns, sweeps overlapped in blocks)

@@ -86,7 +86,7 @@ struct sb_handle {
   DevBuf<uint8_t> cls, tcls, tcset;
   DevBuf<double> abuf; // step_stream.hip: A = ap*Tprev + g of the buildings in flight
   DevBuf<double> redo_scratch; // step_roll.hip: see Dev
-  DevBuf<int> redo_ctr, redo_list;
+  DevBuf<int> redo_ctr, redo_list, zs_off;
   DevBuf<double> ctab, csetab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum,
       hist_bins;
   DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone, cell_state, nsw, next_b, src_dest,

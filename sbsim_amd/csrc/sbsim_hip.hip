@@ -179,6 +179,9 @@ struct RegPlan {
   int r_cmap = 0, wave_doubles = 0, waves_per_wg = 1; // mode 3: four buildings per workgroup share the class words
   std::vector<unsigned long long> cmapS, amapS, zmapS;
   std::vector<int> cell_state;
+  // mode 4 (plan_two)
+  int two_sym = 0, two_level = 0, tail_set_base = 0, tail_pad_set = 0;
+  std::vector<int> zs_off; // [Z + 2] the compact zone-sum scratch: slots of zone z are zs_off[z] .. zs_off[z + 1] - 1
 };
 
 constexpr int kRegSeamPad = 8, kLdsCap = 160 * 1024;
@@ -196,6 +199,17 @@ bool env_flag(const char *name) {
 
 // Mode 4 (step_two.hip): one wavefront, two rows per lane, up to 128 + 2 rows and 80 columns
 // inside the exterior ring.  (x0, y0): the trim box's corner; zone_of: zone of every cell or -1.
+// Three variants (the kernel's template parameters SYM, DENSE):
+//   * general: four coefficients per cell, lane l owns rows 2l, 2l + 1, A's slots 72 / 74 in LDS: two
+//     buildings per CU;
+//   * sym: every cell of the wavefront rows is two coefficients (bV, bH) with T' = A + bV (U + D) + bH (L + R)
+//     -- true of interior control volumes (simulator.py:225-237) and of a rectangular building's edge / corner
+//     volumes (:130-142, :176-195) once a missing neighbour reads as zero: a pad column follows the last
+//     column in the circular slot order (NR > width), the rows are shifted by one so that lane 0's upper
+//     cell is a pad row above row 0 (lane l owns rows 2l - 1, 2l), pad rows follow the last row;
+//   * dense = sym with only 46 / 56 of A's slots in LDS (the rest in registers): three buildings per CU.
+// The zone-sum scratch that aliases A is compact: one slot per (zone, lane) pair that owns a cell of the
+// zone (SB1-synth: 1.1 K slots instead of 127 x 65).
 bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const std::vector<int> &zone_of, RegPlan &r) {
   const int W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = plan->H * plan->W;
   auto coef = [&](int c, int j) { return plan->class_coef[c * 8 + j]; };
@@ -203,41 +217,137 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
   for (int s : {76, 80})
     if (!NR && s >= Ws && sweep_two_supported(s)) NR = s;
   if (!NR || Hs > 128 + 2) return false;
-  const int T = std::max(0, Hs - 128), Hw = Hs - T, nl = (Hw + 1) / 2;
-  for (int x = x0 + Hw; x < x0 + Hs; ++x)
-    for (int y = y0; y < y0 + Ws; ++y)
-      if (zone_of[x * W + y] >= 0) return false; // the tail scan adds no zone sums
   int ts = 32;
   while (ts < ncls + 1) ts *= 2;
   if (ts > 256) return false;
   const int pad = ncls;
-  std::vector<int> set_of(ncls + 1, 0);
-  r.csetab.clear();
-  for (int c = 0; c < ncls; ++c) {
-    int found = -1;
-    for (size_t k = 0; k < r.csetab.size() / 4 && found < 0; ++k)
-      if (r.csetab[4 * k] == coef(c, 0) && r.csetab[4 * k + 1] == coef(c, 1) && r.csetab[4 * k + 2] == coef(c, 2) &&
-          r.csetab[4 * k + 3] == coef(c, 3)) found = (int)k;
-    if (found < 0) {
-      found = (int)r.csetab.size() / 4;
-      for (int j = 0; j < 4; ++j) r.csetab.push_back(coef(c, j));
+  auto cell_class = [&](int R, int col) { // trimmed coordinates
+    return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? (int)plan->cell_class[(x0 + R) * W + (y0 + col)] : pad;
+  };
+  // ---- can every wavefront cell do with two coefficients?  (rows shifted by one: 127 wavefront rows)
+  bool sym = NR > Ws && Hs <= 127 + 2 && !env_flag("SBSIM_TWO_GENERAL");
+  const int Hw_sym = std::min(Hs, 127);
+  for (int R = 0; sym && R < Hw_sym; ++R)
+    for (int col = 0; sym && col < Ws; ++col) {
+      const int c = cell_class(R, col);
+      const double bU = coef(c, 0), bD = coef(c, 1), bL = coef(c, 2), bR = coef(c, 3);
+      // a missing neighbour reads as zero only outside the grid (pad row / pad column); below the last
+      // wavefront row only when no tail row follows
+      const bool v_ok = bU == bD || (bU == 0.0 && R == 0) || (bD == 0.0 && R == Hs - 1);
+      const bool h_ok = bL == bR || (bL == 0.0 && col == 0) || (bR == 0.0 && col == Ws - 1);
+      sym = v_ok && h_ok;
     }
-    set_of[c] = found;
+  const int rowoff = sym ? 1 : 0;
+  const int Hw = std::min(Hs, 128 - rowoff), T = Hs - Hw, nl = (Hw + rowoff + 1) / 2; // wavefront rows, tail rows, lanes that own rows
+  for (int x = x0 + Hw; x < x0 + Hs; ++x)
+    for (int y = y0; y < y0 + Ws; ++y)
+      if (zone_of[x * W + y] >= 0) return false; // the tail scan adds no zone sums
+  // ---- coefficient sets.  general: (bU, bD, bL, bR) for every cell.  sym: (bV, bH) for the wavefront's
+  // cells [kSets][2], then (bU, bD, bL, bR) for the tail cells [kSets / 2][4]; the pad sets last.
+  const int kSets = sweep_two_set_table();
+  std::vector<int> set_of(ncls + 1, 0), tset_of(ncls + 1, 0);
+  std::vector<double> wtab, ttab; // the wavefront's table, the tail cells' table
+  auto intern = [](std::vector<double> &tab, int width, const double *v) {
+    for (size_t k = 0; k < tab.size() / width; ++k) {
+      bool same = true;
+      for (int j = 0; j < width; ++j) same = same && tab[width * k + j] == v[j];
+      if (same) return (int)k;
+    }
+    for (int j = 0; j < width; ++j) tab.push_back(v[j]);
+    return (int)(tab.size() / width) - 1;
+  };
+  std::vector<char> in_wave(ncls + 1, 0), in_tail(ncls + 1, 0);
+  for (int R = 0; R < Hs; ++R)
+    for (int col = 0; col < Ws; ++col) (R < Hw ? in_wave : in_tail)[cell_class(R, col)] = 1;
+  for (int c = 0; c < ncls; ++c) {
+    const double four[4] = {coef(c, 0), coef(c, 1), coef(c, 2), coef(c, 3)};
+    if (sym) {
+      if (in_wave[c]) {
+        const double two[2] = {four[0] != 0.0 ? four[0] : four[1], four[2] != 0.0 ? four[2] : four[3]};
+        set_of[c] = intern(wtab, 2, two);
+      }
+      if (in_tail[c]) tset_of[c] = intern(ttab, 4, four);
+    } else {
+      set_of[c] = tset_of[c] = intern(wtab, 4, four);
+    }
   }
-  set_of[pad] = (int)r.csetab.size() / 4; // the pad set: no neighbour counts
-  for (int j = 0; j < 4; ++j) r.csetab.push_back(0.0);
-  if ((int)r.csetab.size() / 4 > sweep_two_set_table()) { r.csetab.clear(); return false; }
+  const double zeros[4] = {0.0, 0.0, 0.0, 0.0};
+  const int wwidth = sym ? 2 : 4;
+  wtab.insert(wtab.end(), zeros, zeros + wwidth); // the pad set: no neighbour counts
+  set_of[pad] = (int)wtab.size() / wwidth - 1;
+  if (sym) {
+    ttab.insert(ttab.end(), zeros, zeros + 4);
+    tset_of[pad] = (int)ttab.size() / 4 - 1;
+    if ((int)wtab.size() / 2 > kSets || (int)ttab.size() / 4 > kSets / 2) return false;
+    wtab.resize((size_t)2 * kSets, 0.0);
+    r.csetab = wtab;
+    r.csetab.insert(r.csetab.end(), ttab.begin(), ttab.end());
+  } else {
+    tset_of[pad] = set_of[pad];
+    if ((int)wtab.size() / 4 > kSets) return false;
+    r.csetab = wtab;
+  }
+  r.two_sym = sym ? 1 : 0;
+  r.tail_set_base = sym ? 2 * kSets * 8 : 0;
+  r.tail_pad_set = r.tail_set_base + tset_of[pad] * 32;
 
-  const int AS = sweep_two_a_stride(NR), ZRS = 65, NE = 2 * NR;
-  if ((Z + 1) * ZRS > 64 * AS || (Z + 1) * ZRS > 65535) { r.csetab.clear(); return false; } // the zone-sum scratch aliases A
-  int off = 4 * sweep_two_set_table() + 2 * ts;
-  r.r_seam = off; off += sweep_two_seam_doubles(NR);
-  r.r_A = off; off += 64 * AS;
-  r.r_xchg = off; off += 8;
-  r.AS = AS;
-  r.lds_bytes = off * 8;
-  if (const char *padb = getenv("SBSIM_DEBUG_LDS_PAD")) r.lds_bytes += atoi(padb);
-  r.wg_per_cu = std::min(4, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule));
+  // ---- the lanes' cells: register J = 2 * slot + k of lane l is row 2l + k - rowoff, column (slot - l) mod NR
+  const int NE = 2 * NR;
+  auto row_of = [&](int lane, int k) { return 2 * lane + k - rowoff; };
+  auto reg_cell = [&](int lane, int J, int &R, int &col) {
+    const int j = J / 2;
+    col = ((j - lane) % NR + NR) % NR;
+    R = row_of(lane, J & 1);
+    return J < NE && R >= 0 && R < Hw && col < Ws;
+  };
+  // ---- the zone-sum scratch: one slot per (zone, lane) that owns a cell of the zone; zone Z (every cell
+  // outside a zone, the tail rows) has a slot for every lane
+  std::vector<std::vector<int>> zl(Z + 1);
+  {
+    std::vector<char> seen((size_t)(Z + 1) * 64, 0);
+    for (int lane = 0; lane < 64; ++lane) {
+      seen[(size_t)Z * 64 + lane] = 1;
+      for (int J = 0; J < NE; ++J) {
+        int R, col;
+        if (reg_cell(lane, J, R, col) && zone_of[(x0 + R) * W + (y0 + col)] >= 0) seen[(size_t)zone_of[(x0 + R) * W + (y0 + col)] * 64 + lane] = 1;
+      }
+    }
+    for (int z = 0; z <= Z; ++z)
+      for (int lane = 0; lane < 64; ++lane)
+        if (seen[(size_t)z * 64 + lane]) zl[z].push_back(lane);
+  }
+  r.zs_off.assign(Z + 2, 0);
+  for (int z = 0; z <= Z; ++z) r.zs_off[z + 1] = r.zs_off[z] + (int)zl[z].size();
+  const int zs_slots = r.zs_off[Z + 1];
+  if (zs_slots > 65535) return false;
+  auto zslot = [&](int z, int lane) {
+    const auto it = std::lower_bound(zl[z].begin(), zl[z].end(), lane);
+    return r.zs_off[z] + (int)(it - zl[z].begin());
+  };
+
+  // ---- LDS: [sets 4 kSets][ap g: 2 (ncls + 1), rounded to 8][first tail row][A rows: nl (+ 1 for the idle lanes)]
+  // As many buildings per CU as the kernel has a level for (A's other slots stream from L2: step_two.hip).
+  auto lds_bytes_for = [&](int level, int &AS, int &r_seam, int &r_A) {
+    AS = sweep_two_a_stride(NR, level);
+    int off = 4 * kSets + ((2 * (ncls + 1) + 7) & ~7);
+    r_seam = off; off += sweep_two_seam_doubles(NR);
+    r_A = off; off += std::max((nl < 64 ? nl + 1 : 64) * AS, zs_slots);
+    return off * 8;
+  };
+  auto per_cu = [&](int bytes) { return std::min(4, kLdsCap / ((bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule)); };
+  int AS = 0, r_seam = 0, r_A = 0, bytes = 0, level = 0;
+  int max_level = sym ? sweep_two_levels() - 1 : 0;
+  if (const char *e = getenv("SBSIM_TWO_MAX_LEVEL")) max_level = std::min(max_level, std::max(0, atoi(e)));
+  for (int lv = 0; lv <= max_level; ++lv) { // the lowest level that holds the most buildings
+    int as_, rs_, ra_;
+    const int b_ = lds_bytes_for(lv, as_, rs_, ra_);
+    if (lv == 0 || per_cu(b_) > per_cu(bytes)) { level = lv; bytes = b_; AS = as_; r_seam = rs_; r_A = ra_; }
+  }
+  if (const char *padb = getenv("SBSIM_DEBUG_LDS_PAD")) bytes += atoi(padb);
+  r.two_level = level;
+  r.r_seam = r_seam; r.r_A = r_A; r.r_xchg = 0; r.AS = AS;
+  r.lds_bytes = bytes;
+  r.wg_per_cu = per_cu(bytes);
   if (r.wg_per_cu < 1) { r.csetab.clear(); return false; }
 
   r.NR = NR; r.P = 4; r.RS = 64; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
@@ -246,24 +356,21 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
   r.lw[0] = nl; r.l0[0] = 0; r.rowbase[0] = 0; r.nch[0] = 0;
   r.lag = 0; r.nslots = 0;
   r.steps = NR + nl - 1 + 4 * T;
-  auto cell_class = [&](int R, int col) { // trimmed coordinates
-    return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? (int)plan->cell_class[(x0 + R) * W + (y0 + col)] : pad;
-  };
   const int NW = NR / 4, NWD = (NE + 3) / 4; // step_two.hip: class words of four steps, NR / 4 per lane
   r.cmapS.assign((size_t)NW * 64, 0);
   r.amapS.assign((size_t)NWD * 64, 0);
   r.zmapS.assign((size_t)NWD * 64, 0);
   r.tcls.assign((size_t)std::max(T, 1) * NR, (uint8_t)pad);
-  r.tcset.assign((size_t)std::max(T, 1) * NR, (uint8_t)(8 * set_of[pad]));
+  r.tcset.assign((size_t)std::max(T, 1) * NR, (uint8_t)(8 * tset_of[pad]));
   for (int t = 0; t < T; ++t)
     for (int c = 0; c < NR; ++c) {
       r.tcls[(size_t)t * NR + c] = (uint8_t)cell_class(Hw + t, c);
-      r.tcset[(size_t)t * NR + c] = (uint8_t)(8 * set_of[cell_class(Hw + t, c)]);
+      r.tcset[(size_t)t * NR + c] = (uint8_t)(8 * tset_of[cell_class(Hw + t, c)]);
     }
   for (int lane = 0; lane < 64; ++lane) {
-    auto row_class = [&](int k, int col) { // lower / upper cell of the lane at a column of the wavefront rows
-      const int R = 2 * lane + k;
-      return (R < Hw && col >= 0 && col < NR) ? cell_class(R, col) : pad;
+    auto row_class = [&](int k, int col) { // upper / lower cell of the lane at a column of the wavefront rows
+      const int R = row_of(lane, k);
+      return (R >= 0 && R < Hw && col >= 0 && col < NR) ? cell_class(R, col) : pad;
     };
     for (int wd = 0; wd < NW; ++wd) { // a byte per cell and step: the coefficient sets of the lane's (upper, lower) cell
       unsigned long long word = 0;
@@ -274,15 +381,16 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
       }
       r.cmapS[(size_t)wd * 64 + lane] = word;
     }
-    for (int g = 0; g < NWD; ++g) { // register J = 2 * slot + (row & 1)
+    for (int g = 0; g < NWD; ++g) { // register J = 2 * slot + k
       unsigned long long aword = 0, zword = 0;
       for (int k = 0; k < 4; ++k) {
-        const int J = 4 * g + k, j = J / 2, col = ((j - lane) % NR + NR) % NR, R = 2 * lane + (J & 1);
-        const bool cell = J < NE && R < Hw && col < Ws;
+        const int J = 4 * g + k;
+        int R, col;
+        const bool cell = reg_cell(lane, J, R, col);
         aword |= (unsigned long long)((cell ? cell_class(R, col) : pad) * 16) << (16 * k);
-        int z = Z; // dump row
+        int z = Z; // the dump zone
         if (cell && zone_of[(x0 + R) * W + (y0 + col)] >= 0) z = zone_of[(x0 + R) * W + (y0 + col)];
-        zword |= (unsigned long long)(z * ZRS + lane) << (16 * k);
+        zword |= (unsigned long long)zslot(z, lane) << (16 * k);
       }
       r.amapS[(size_t)g * 64 + lane] = aword;
       r.zmapS[(size_t)g * 64 + lane] = zword;
@@ -295,8 +403,8 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
       const int R = x - x0, col = y - y0;
       if (R < 0 || R >= Hs || col < 0 || col >= Ws) { r.cell_state[x * W + y] = -(++ring); continue; }
       if (R >= Hw) { r.cell_state[x * W + y] = NE * 64 + (R - Hw) * NR + col; continue; }
-      const int lane = R >> 1;
-      r.cell_state[x * W + y] = (2 * ((col + lane) % NR) + (R & 1)) * 64 + lane;
+      const int lane = (R + rowoff) >> 1;
+      r.cell_state[x * W + y] = (2 * ((col + lane) % NR) + ((R + rowoff) & 1)) * 64 + lane;
     }
   r.ok = true;
   return true;
@@ -980,8 +1088,21 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     SB_TRY(upload(h->tcset, r.tcset.data(), r.tcset.size()));
     SB_TRY(upload(h->csetab, r.csetab.data(), r.csetab.size()));
     d.tcset = h->tcset.p; d.csetab = h->csetab.p; d.ncset = (int)r.csetab.size() / 4;
+    d.csetab_doubles = (int)r.csetab.size();
+    d.two_sym = r.two_sym; d.two_level = r.two_level; d.tail_set_base = r.tail_set_base;
+    d.tail_pad_set = r.P == 4 ? r.tail_pad_set : (d.ncset - 1) * 32;
+    d.zs_off = nullptr;
+    if (!r.zs_off.empty()) {
+      SB_TRY(upload(h->zs_off, r.zs_off.data(), r.zs_off.size()));
+      d.zs_off = h->zs_off.p;
+    }
     SB_TRY(alloc_zero(h->temp, (size_t)d.B * d.state_doubles));
     if (d.P == 6) SB_TRY(alloc_zero(h->abuf, (size_t)h->info.workgroups * d.state_doubles)); // A = ap*Tprev + g, one grid per resident workgroup
+    d.two_abuf = nullptr;
+    if (d.P == 4) { // step_two.hip: the slots of A that stream from L2, one strip per resident workgroup
+      SB_TRY(alloc_zero(h->abuf, (size_t)h->info.workgroups * (size_t)std::max(1, d.NR - sweep_two_lds_slots(d.NR, d.two_level)) * 128));
+      d.two_abuf = h->abuf.p;
+    }
     d.tcls = h->tcls.p;
     d.cmapS = h->cmapS.p; d.amapS = h->amapS.p; d.zmapS = h->zmapS.p; d.cell_state = h->cell_state.p;
     d.ring = h->ring.p;

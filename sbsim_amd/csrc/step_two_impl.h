@@ -1,0 +1,744 @@
+#pragma once
+// step_two_impl.h -- (included by step_two_76.hip / step_two_80.hip: one translation unit per slot count, compiled in parallel)
+// the sweep kernel for floor plans of 67..130 rows and <= 80 columns inside their
+// exterior ring: one wavefront per building, the grid in registers, TWO rows per lane.
+// simulator.py:278-371.
+//
+// A 129 x 75 grid of doubles is 77 KB -- more than the LDS share of a building once A = ap*Tprev + g
+// (another 77 KB) sits there, but less than the 128 KB register file of one SIMD.  So the grid
+// lives in the registers of ONE wavefront: lane l owns rows 2l and 2l + 1, column c of both in
+// register slot (c + l) mod NR, and every lane works on slot s mod NR at step s of a sweep (the
+// anti-diagonal order of step_reg.hip / step_roll.hip, which reproduces the reference's row-major
+// in-place update).  Per step a lane updates two cells:
+//   row 2l   : U = lane l-1's row 2l-1 result of the previous step (DPP), D = own row 2l+1 (old)
+//   row 2l+1 : U = the value just computed, D = lane l+1's row 2l+2 (old, DPP)
+// -- two DPP exchanges per two cells where the one-row layout needs four.  Rows 128.. (at most two)
+// are finished by the affine scan of step_roll.hip (lanes = columns).  A lives in LDS as
+// [lane][slot][2 rows]: one ds_read_b128 per step; coefficient sets as in step_roll.hip (two
+// ds_read_b128 per cell, addressed by 16-bit LDS offsets that arrive in class words from L2).
+//
+// Sweeps are overlapped in BLOCKS (step_roll.hip overlaps all of them, undoing the started sweep from
+// copies -- another 252 registers here).  A block is a ramp-up (63 steps, lanes > s masked), rolling
+// periods of NR steps (lanes <= s - NR already in the next sweep) and a final period whose lanes
+// <= s - NR are masked: it stops after exactly m sweeps and costs 63 + m NR steps instead of
+// m (NR + 63).  Whether sweep k was the last one (simulator.py:360) is known only after its period,
+// so a period rolls only while the decay of max|delta| over the last two sweeps says that the NEXT
+// sweep cannot converge yet (may_roll); then the block ends with a final period, and if that sweep
+// did not converge either, the next block starts.  The grid is stored before a block; a rolling
+// period that finds max|delta| <= threshold has started the next sweep already -- the block is run
+// again from the stored grid with m = that sweep.  The iterates and the sweep count are always
+// those of the plain schedule; the prediction only decides the speed.  max|delta| of the two sweeps
+// in flight is separated by its sign as in step_roll.hip.  Two buildings fit in a CU's LDS, so two
+// of the four SIMDs run (LDS-grid kernel: one).
+#include <type_traits>
+
+#include "step_two_cfg.h"
+#include "sweep_common.h"
+
+namespace sb {
+namespace {
+
+using namespace sweep;
+using namespace two;
+
+constexpr int kWA = 3;     // class words (four steps each) are read this many words ahead
+constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in the hand-over
+
+// Slots of A kept in LDS (template parameter NL).  The others -- the last NR - NL slots of every period --
+// live in a per-workgroup strip of global memory that never leaves the XCD's L2 (3 buildings x 30 KB x 32 CUs
+// = 2.9 MB of 4 MB): written by the A pass, read kAD steps ahead of their use into a ring of kAR register
+// pairs, one global_load_dwordx4 per step.  So the LDS a building needs is a planner's choice (plan_two):
+//   level 0: 72 / 74 of 76 / 80 slots, < 80 KB: two buildings per CU
+//   level 1: 46 / 56,                  < 53 KB: three
+//   level 2: 34 / 42,                  < 40 KB: four -- every SIMD has a wavefront
+// (Homes in registers for those slots -- tried first: the grid's 304-320 registers, 112-176 for A and a sweep's
+// working set of ~140 do not fit 512; the compiler answered with 0.4-0.9 KB of scratch per lane.)
+// Row stride 2 * NL + 2 doubles: 2 mod 4, conflict-free ds_read_b128 across 16 lanes.
+constexpr int kAD = 6, kAR = 8; // global slots of A: read this many steps ahead, into a ring of this many register pairs
+
+template <bool SYM>
+struct StepBuf {         // LDS values of one step
+  d2 uda, lra, udb, lrb; // (bU, bD), (bL, bR) of the lane's upper / lower cell
+  d2 A;                  // A of the two cells
+  double sm;             // old value of the first tail row under lane 63's lower cell
+};
+// SYM: every cell's coefficients are two numbers, (bV, bH): T' = A + bV (U + D) + bH (L + R).  True of every
+// interior control volume (simulator.py:225-237: all four are 1 / (4 + t0)) and of the edge and corner volumes
+// of a rectangular building once their missing neighbours READ as zero (:130-142, :176-195: the weights of the
+// two present neighbours along the wall are equal) -- which the layout arranges: a pad column between the last
+// and the first column of the circular slot order (NR > width), a pad row above row 0 (lane 0's upper cell:
+// rows are shifted by one, plan_two) and pad rows below the last one.  plan_two checks every cell; plans that
+// do not qualify (courtyards, exterior space inside the trim box) run the four-coefficient instantiation.
+// One ds_read_b128 per cell instead of two, 4 adds + 4 FMAs instead of 8 FMAs, 12 registers fewer per buffer.
+template <>
+struct StepBuf<true> {
+  d2 ca, cb; // (bV, bH) of the lane's upper / lower cell
+  d2 A;
+  double sm;
+};
+
+struct Acc {
+  double cur;      // max |delta| of the sweep the lanes are finishing
+  double neg;      // -(max |delta|) of the sweep the lanes have started (rolling periods)
+  int sg;          // 0x80000000 in the lanes that have started the next sweep
+  double sre, sro; // the last wavefront row's new values on their way to the tail scan (even / odd columns)
+};
+
+struct Ctx {
+  unsigned arow;      // LDS byte address of the lane's row of A: the cell pair of slot j at [2 j]
+  const char *aglob;  // the workgroup's strip of A in global memory: the cell pair of slot NL + k at [k][lane] (uniform)
+  unsigned aoff;      // 16 * lane
+  unsigned ap;        // running byte offset of the slot being read ahead
+  unsigned seam;      // LDS byte address of the first tail row by step: the value under lane 63 at step s is [s]
+  const char *cmap;   // class words (uniform)
+  unsigned voff;      // byte offset of the lane's last-read class word: 8 * lane + 512 * word
+  unsigned long long w[kWA + 1]; // the word in use and the next kWA, in flight
+};
+
+// The lane's 2 NR grid registers: register J = 2 * slot + (row & 1).  The first 2 * kNV live in
+// VGPRs, the rest in AGPRs -- by hand: left to the register allocator, every register of the unrolled
+// sweep goes through an AGPR (and some through scratch).  VALU instructions cannot read AGPRs, so a
+// step reads the slot it needs next (v_accvgpr_read) and writes its results back once.
+template <int NR>
+struct Grid {
+#ifndef SB_TWO_NV
+#define SB_TWO_NV 24
+#endif
+  static constexpr int kNV = SB_TWO_NV; // slots homed in VGPRs
+  static constexpr int NE = 2 * NR, NVE = 2 * kNV;
+  double v[NVE];
+  int a[2 * (NE - NVE)];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < 2 * (NE - NVE); ++k) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(a[k]));
+#pragma unroll
+    for (int k = 0; k < NVE; ++k) v[k] = 0.0;
+  }
+  template <int J>
+  __device__ __forceinline__ double get() const {
+    static_assert(J >= 0 && J < NE, "grid register");
+    if constexpr (J < NVE) return v[J];
+    else {
+      int lo, hi;
+      asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(a[2 * (J - NVE)]));
+      asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(a[2 * (J - NVE) + 1]));
+      return __hiloint2double(hi, lo);
+    }
+  }
+  // Register J <- *(base + off) (bytes) without waiting for it: the AGPR homes are loaded directly
+  // (two global_load_dword the compiler does not track), so settle() must come before any get().
+  template <int J>
+  __device__ __forceinline__ void load_async(const double *base, unsigned off) {
+    off += (unsigned)J * 512u;
+    if constexpr (J < NVE) v[J] = *(const double *)((const char *)base + off);
+    else {
+      asm volatile("global_load_dword %0, %2, %3" : "=a"(a[2 * (J - NVE)]) : "0"(a[2 * (J - NVE)]), "v"(off), "s"(base) : "memory");
+      asm volatile("global_load_dword %0, %2, %3 offset:4"
+                   : "=a"(a[2 * (J - NVE) + 1])
+                   : "0"(a[2 * (J - NVE) + 1]), "v"(off), "s"(base)
+                   : "memory");
+    }
+  }
+  // uniform base + 32-bit byte offset (the lane's, made opaque by the caller inside its loop: the
+  // 2 NR addresses are not loop invariants the compiler could hoist -- and spill)
+  template <int J>
+  __device__ __forceinline__ void store(double *base, unsigned off) const {
+    *(double *)((char *)base + (off + (unsigned)J * 512u)) = get<J>();
+  }
+  __device__ __forceinline__ void settle() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 2 * (NE - NVE); ++k) asm volatile("" : "+a"(a[k])); // later reads depend on the wait
+  }
+  template <int J>
+  __device__ __forceinline__ void set(double x) {
+    static_assert(J >= 0 && J < NE, "grid register");
+    if constexpr (J < NVE) v[J] = x;
+    else {
+      // the old value as a tied input: every version of a register keeps the same AGPR (left free,
+      // the allocator fragments the 200+ long-lived values over the loop and spills them)
+      asm("v_accvgpr_write_b32 %0, %2" : "=a"(a[2 * (J - NVE)]) : "0"(a[2 * (J - NVE)]), "v"(__double2loint(x)));
+      asm("v_accvgpr_write_b32 %0, %2" : "=a"(a[2 * (J - NVE) + 1]) : "0"(a[2 * (J - NVE) + 1]), "v"(__double2hiint(x)));
+    }
+  }
+};
+
+// The three slots a step touches, in VGPRs: the previous slot's new values and the current slot's
+// old values (the next slot's are read by the step itself).
+struct Win {
+  double pa, pb, ca, cb;
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Class words: a byte per cell and step -- the coefficient set (its LDS byte offset is set * 32) of the
+// lane's upper (even bytes) and lower cell (odd bytes), four steps per 64-bit word.  The sets of a step
+// depend on (lane, step mod NR) only, so the table has NR / 4 words per lane (10 KB: L1 hits) and a
+// rolling period continues where the last one stopped; read kWA words = 12 steps ahead.  (One word per
+// step with the two LDS addresses ready-made cost no instruction to decode, but a load per step from a
+// 71 KB table: a quarter of the sweep's time, tools/exp_fixed_sweeps.py with PLAN=SB1-synth.)
+template <int NR>
+constexpr int class_words() { return NR / 4; }
+__device__ __forceinline__ unsigned long long class_word(const Ctx &x) {
+  return *(const unsigned long long *)(x.cmap + x.voff);
+}
+// Before load_step<S0>: the words of steps S0 .. (a word boundary at S0 rotates first).
+template <int NR, int S0>
+__device__ __forceinline__ void enter_words(Ctx &x, int lane) {
+  static_assert(NR % 4 == 0, "whole class words per sweep");
+  constexpr int j = S0 % NR, wi = j / 4, first = j % 4 == 0 ? 1 : 0, NW = class_words<NR>();
+#pragma unroll
+  for (int k = first; k <= kWA; ++k) {
+    x.voff = (unsigned)opaque(lane * 8 + 512 * ((wi + k - first) % NW));
+    x.w[k] = class_word(x);
+  }
+}
+template <int NR>
+__device__ __forceinline__ void first_words(Ctx &x, int lane) { enter_words<NR, 0>(x, lane); }
+
+template <int byte, int SH>
+__device__ __forceinline__ unsigned set_offset(unsigned h) { // (byte of h) << SH in one instruction: the set's LDS byte offset (32 or 16 bytes per set)
+  unsigned off;
+  if constexpr (byte == 0) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(h), "n"(SH));
+  else if constexpr (byte == 1) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(h), "n"(SH));
+  else if constexpr (byte == 2) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(h), "n"(SH));
+  else asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(h), "n"(SH));
+  return off;
+}
+
+// The global slots of A: the read for the step kAD steps ahead (slot index static).
+// The address is a running offset (bumped every fourth slot: the instruction's immediate reaches 4 KB) that
+// the compiler cannot see through: left to itself it keeps one loop-invariant offset register per slot alive
+// -- 30 to 42 of them, in scratch.
+template <int NR, int S, int NL>
+__device__ __forceinline__ void prefetch_a(d2 (&ring)[kAR], Ctx &x) {
+  constexpr int r = (S + kAD) % NR;
+  if constexpr (r >= NL) {
+    constexpr int k = r - NL;
+    if constexpr (k == 0) x.ap = x.aoff;
+    else if constexpr (k % 4 == 0) x.ap += 4096u;
+    if constexpr (k % 4 == 0) asm volatile("" : "+v"(x.ap));
+    ring[k % kAR] = *(const d2 *)(x.aglob + x.ap + (unsigned)(k % 4) * 1024u);
+  }
+}
+
+template <int NR, int S, bool TAIL, int NL, bool SYM>
+__device__ __forceinline__ void load_step(StepBuf<SYM> &p, Ctx &x, const d2 (&ring)[kAR]) {
+  constexpr int j = S % NR, wi = j / 4, pos = j % 4, NW = class_words<NR>();
+  if constexpr (pos == 0) { // a new word: the next ones move up, one more is asked for
+#pragma unroll
+    for (int k = 0; k < kWA; ++k) x.w[k] = x.w[k + 1];
+#ifndef SB_EXP_NOCW // timing experiment: no class-word loads inside the sweeps (wrong coefficients)
+    if constexpr ((wi + kWA) % NW == 0) x.voff -= 512u * (NW - 1);
+    else x.voff += 512u;
+    asm volatile("" : "+v"(x.voff)); // a running offset: nothing for the compiler to hoist
+    x.w[kWA] = class_word(x);
+#endif
+  }
+  const unsigned h = pos < 2 ? (unsigned)x.w[0] : (unsigned)(x.w[0] >> 32);
+  const lds_d2 sa = (lds_d2)set_offset<2 * (pos & 1), SYM ? 4 : 5>(h), sb = (lds_d2)set_offset<2 * (pos & 1) + 1, SYM ? 4 : 5>(h);
+  // A last: the step's first FMA needs it, so its one s_waitcnt covers every read of the step
+  if constexpr (TAIL && S >= 63) p.sm = *(const double __attribute__((address_space(3))) *)(x.seam + 8u * S);
+  else p.sm = 0.0;
+  if constexpr (SYM) {
+    p.ca = sa[0];
+    p.cb = sb[0];
+  } else {
+    p.uda = sa[0];
+    p.lra = sa[1];
+    p.udb = sb[0];
+    p.lrb = sb[1];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  constexpr int r = S % NR;
+  if constexpr (r < NL) p.A = *(lds_d2)(x.arow + 16u * r);
+  else p.A = ring[(r - NL) % kAR];
+}
+
+// One Gauss-Seidel update of every lane's two current cells at step S:
+//   S < 63             ramp-up of a block's first sweep: lanes > S have not started
+//   63 <= S < NR       all 64 lanes are in the same sweep
+//   NR <= S < NR + 63  ROLL: lanes <= S - NR are in the next sweep; else they have finished (masked)
+// Association order of the four products as in step_lds.hip / step_reg.hip / step_roll.hip.
+template <int NR, int S, bool TAIL, bool ROLL, bool SYM>
+__device__ __forceinline__ void step(Grid<NR> &g, Win &w, const StepBuf<SYM> &p, Acc &acc) {
+  constexpr int r = S % NR, rp = (S + 1) % NR;
+  const double na = g.template get<2 * rp>(), nb = g.template get<2 * rp + 1>(); // old values one column ahead
+  const double U = wave_shift1<0x13c, false>(w.pb, 0.0); // lane 0 sees the last row's latest value (times bU = 0; SYM: lane 0's upper cell is a pad row)
+  const double Dn = wave_shift1<0x130, true>(na, p.sm);
+  double t, t2, nva, nvb;
+  if constexpr (SYM) { // the horizontal pair first: it does not wait for the DPP moves
+    const double ha = w.pa + na, hb = w.pb + nb;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t) : "v"(p.ca.y), "v"(ha), "v"(p.A.x));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t2) : "v"(p.cb.y), "v"(hb), "v"(p.A.y));
+    nva = fma(p.ca.x, U + w.cb, t);
+    nvb = fma(p.cb.x, nva + Dn, t2);
+  } else {
+    asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t) : "v"(p.uda.y), "v"(w.cb), "v"(p.A.x));
+    t = fma(p.lra.y, na, t);
+    t = fma(p.lra.x, w.pa, t);
+    nva = fma(p.uda.x, U, t);
+    asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(t2) : "v"(p.udb.y), "v"(Dn), "v"(p.A.y));
+    t2 = fma(p.lrb.y, nb, t2);
+    t2 = fma(p.lrb.x, w.pb, t2);
+    nvb = fma(p.udb.x, nva, t2);
+  }
+  if constexpr (TAIL && S > 63) { // lane 0's U is column S - 64 of the last row: into the shift register of its parity
+    double &sr = (S - 64) % 2 == 0 ? acc.sre : acc.sro;
+    sr = wave_shift1<0x138, true>(sr, U);
+  }
+  double sa = nva, sb = nvb;
+  if constexpr (ROLL && S >= NR) {
+    constexpr int J = S - NR;
+    // the lane's two cells are in the same sweep: one |d| for both, + in the lanes still in sweep k,
+    // - in the lanes already in sweep k+1
+    const double dm = fmax(fabs(nva - w.ca), fabs(nvb - w.cb));
+    const double sd = __hiloint2double(__double2hiint(dm) | acc.sg, __double2loint(dm));
+    acc.cur = fmax(acc.cur, sd);
+    acc.neg = fmin(acc.neg, sd);
+    asm volatile("" : "+v"(acc.neg)); // here: sunk below the period's exit, the minima keep every sd of the period alive
+    if constexpr (J + 1 < 63) // lane J + 1 starts its next sweep at the next step (lane 0 keeps its bit)
+      acc.sg = __builtin_amdgcn_update_dpp(acc.sg, acc.sg, 0x138, 0xf, 0xf, false);
+  } else {
+    if constexpr (S < 63) {
+      const bool m = lanes_upto<S>();
+      sa = m ? nva : w.ca;
+      sb = m ? nvb : w.cb;
+    } else if constexpr (S >= NR) {
+      const bool m = lanes_upto<S - NR>();
+      sa = m ? w.ca : nva;
+      sb = m ? w.cb : nvb;
+    }
+    acc.cur = fmax(acc.cur, fabs(sa - w.ca));
+    acc.cur = fmax(acc.cur, fabs(sb - w.cb));
+  }
+  asm volatile("" : "+v"(acc.cur)); // here, not after the sweep (the maxima would keep every delta of the sweep alive)
+  g.template set<2 * r>(sa);
+  g.template set<2 * r + 1>(sb);
+  w.pa = sa;
+  w.pb = sb;
+  w.ca = na;
+  w.cb = nb;
+}
+
+// Steps S .. S1 - 1; the LDS reads of step S + 1 are issued before the arithmetic of step S (the
+// caller issues those of the first step; a period's last step reads nothing ahead).
+// last_step: the step at which the last lane that owns a row finishes (NR + lanes - 2).
+template <int NR, int S, int S1, bool TAIL, bool ROLL, int NL, bool SYM>
+__device__ __forceinline__ void run_steps(Grid<NR> &g, Win &w, d2 (&ring)[kAR], StepBuf<SYM> (&pb)[2], Ctx &x,
+                                          Acc &acc, int last_step) {
+  if constexpr (S < S1) {
+    if constexpr (!ROLL && S >= NR && (S - NR) % 4 == 0)
+      if (S > last_step) return; // uniform: only lanes without rows are left
+    prefetch_a<NR, S, NL>(ring, x);
+    if constexpr (S + 1 < NR + 63) load_step<NR, S + 1, TAIL, NL, SYM>(pb[(S + 1) & 1], x, ring);
+    __builtin_amdgcn_sched_barrier(0);
+    step<NR, S, TAIL, ROLL, SYM>(g, w, pb[S & 1], acc);
+    __builtin_amdgcn_sched_barrier(0);
+    run_steps<NR, S + 1, S1, TAIL, ROLL, NL, SYM>(g, w, ring, pb, x, acc, last_step);
+  }
+}
+
+// May the sweep after the last one run overlapped, i.e. is it safe to assume that it will NOT be the
+// step's last?  d1 -> d0: max|delta| of the last two sweeps.  Extrapolates the last decay (`haste` x
+// as fast, in the exponent) to the threshold: r sweeps to go; the next sweep may overlap if r > slack
+// (Dev::pred_haste, Dev::pred_slack: 1.0, 1.0 -- the decay slows down as the fast modes die out, so
+// the extrapolation errs on the short side).  Speed only: a wrong yes is found out and repaired.
+__device__ __forceinline__ bool may_roll(float d1, float d0, float thr, float haste, float slack) {
+  if (!(d0 > thr)) return false;
+  if (!(d0 < d1)) return true; // not decaying
+  return __log2f(thr / d0) < slack * haste * __log2f(d0 / d1); // r = log(thr/d0) / (haste log(d0/d1)) > slack; both logarithms are negative
+}
+
+// A = ap*Tprev + g for the lane's cells (e = Tprev before the first sweep): the pair of slot j to
+// [2 j] of the lane's A row or to the registers.  aw: class offsets into the (ap, g) table, four
+// cells per word.
+template <int NR, int NL>
+__device__ __forceinline__ void a_pass(const Grid<NR> &g, const Ctx &x, double *Aw, const char *tapg,
+                                       const unsigned long long *amap) {
+  constexpr int NWD = (2 * NR + 3) / 4;
+  static_assert(NR % 4 == 0, "a_pass: four slots per group");
+  amap += opaque(0);
+  constexpr int kAA = 8; // words (four registers each) read ahead
+  unsigned long long aw[kAA + 2];
+  unsigned gofs = x.aoff;
+#pragma unroll
+  for (int k = 0; k < kAA; ++k) aw[k] = amap[k * 64];
+  static_for<0, NR / 4>([&](auto gc) {
+    constexpr int j0 = 4 * decltype(gc)::value, W0 = j0 / 2;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (W0 + kAA + k < NWD) aw[(W0 + kAA + k) % (kAA + 2)] = amap[(W0 + kAA + k) * 64];
+    const unsigned long long w0 = aw[W0 % (kAA + 2)], w1 = aw[(W0 + 1) % (kAA + 2)]; // eight registers' class offsets
+    d2 pg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pg[k] = *(const d2 *)(tapg + (unsigned)(((k < 4 ? w0 : w1) >> (16 * (k & 3))) & 0xffffull));
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 4>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, j = j0 + k;
+      const double av0 = fma(pg[2 * k].x, g.template get<2 * j>(), pg[2 * k].y);
+      const double av1 = fma(pg[2 * k + 1].x, g.template get<2 * j + 1>(), pg[2 * k + 1].y);
+      if constexpr (j < NL) *(d2 *)(Aw + 2 * j) = d2{av0, av1};
+      else { // a global slot; the running offset as in prefetch_a (one invariant address per slot would live in scratch)
+        constexpr int kg = j - NL;
+        if constexpr (kg % 4 == 0) {
+          if constexpr (kg > 0) gofs += 4096u;
+          asm volatile("" : "+v"(gofs));
+        }
+        *(d2 *)(const_cast<char *>(x.aglob) + gofs + (unsigned)(kg % 4) * 1024u) = d2{av0, av1};
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// The end of a building's step, register by register: store it, add it to its zone sum (LDS),
+// load the same register of the next building.  zw: zone-sum offsets (in doubles), four registers
+// per word, read kZA words ahead (memory operations return in order: waiting for a young word
+// would drain the queue of row loads in front of it).
+template <int NR, int J>
+__device__ __forceinline__ void hand_over(Grid<NR> &g, unsigned long long (&zw)[kZA + 1], const unsigned long long *zmap,
+                                          double *tp, const double *np_, int lane_off, double *zs) {
+  constexpr int NE = 2 * NR;
+  if constexpr (J < NE) {
+    if constexpr (J % 4 == 0 && J / 4 + kZA < (NE + 3) / 4) zw[(J / 4 + kZA) % (kZA + 1)] = zmap[(J / 4 + kZA) * 64];
+    const unsigned idx = (unsigned)((zw[(J / 4) % (kZA + 1)] >> (16 * (J & 3))) & 0xffffull);
+    const double v = g.template get<J>();
+    *(double *)((char *)tp + ((unsigned)lane_off + (unsigned)J * 512u)) = v;
+    __hip_atomic_fetch_add(zs + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    g.template load_async<J>(np_, (unsigned)lane_off);
+    if constexpr ((J & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    hand_over<NR, J + 1>(g, zw, zmap, tp, np_, lane_off, zs);
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) double lds[];
+
+template <int NR, bool TAIL, int LEVEL, bool SYM>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_two(Dev a) {
+  const int lane = threadIdx.x & 63;
+  constexpr int kNL = lds_slots(NR, LEVEL), kAS = a_stride_of(kNL), NE = 2 * NR;
+  static_assert(kNL >= kAD && NR - kNL >= 0, "the global slots are read kAD steps ahead, from a step of the same period");
+  constexpr int kZW = (NE + 3) / 4;
+
+  double *tabc = lds;                        // [kSets][4]: bU bD bL bR per coefficient set; SYM: [kSets][2] (bV, bH), then [kSets / 2][4] for the tail cells
+  double *tapg = lds + 4 * kSets;            // [ts][2]: (ap, g) per class; g of this building
+  double *tE0 = lds + a.r_seam + 2;          // the first tail row by column ([2 guards | NR | 2 guards])
+  double *A = lds + a.r_A;                   // [64][kAS]; after the sweeps: zone sums [Z + 1][ZRS]
+  for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0; // every byte starts finite
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < 4 * kSets; i += 64) tabc[i] = i < a.csetab_doubles ? a.csetab[i] : 0.0;
+  for (int c = lane; c <= a.ncls; c += 64) tapg[2 * c] = a.ctab[c * 8 + 4]; // row `ncls`: the pad class
+  __builtin_amdgcn_wave_barrier();
+
+  const sb_params &p = a.p;
+  if ((unsigned)(size_t)(__attribute__((address_space(3))) double *)tabc != 0u) __builtin_trap(); // class words hold LDS addresses
+  Ctx x;
+  // the lanes without rows (all their cells are pad cells: A = 0) share one row behind the others'
+  const int arow_i = lane < a.lw[0] ? lane : a.lw[0];
+  x.arow = (unsigned)((a.r_A + arow_i * kAS) * 8);
+  x.seam = (unsigned)((a.r_seam + 2 - 63) * 8); // lane 63 works on column s - 63 at step s
+  x.cmap = (const char *)a.cmapS;
+  x.aglob = (const char *)(a.two_abuf + (size_t)blockIdx.x * (size_t)(NR - kNL) * 128);
+  x.aoff = (unsigned)lane * 16u;
+  x.ap = x.aoff;
+  x.voff = 0;
+  const int last_step = NR + a.lw[0] - 2; // a.lw[0]: lanes that own rows
+  // the lane's tail cells (static per floor plan): LDS offsets of their coefficient sets (two
+  // 16-bit halves)
+  const bool tactive = TAIL && tail_col<NR>(lane, 0) >= 0;
+  const int tc0 = tactive ? tail_col<NR>(lane, 0) : 0;
+  int tset[kTailMax];
+#pragma unroll
+  for (int t = 0; t < kTailMax; ++t) {
+    tset[t] = a.tail_pad_set * 0x10001; // the pad set of the tail cells' table (byte offset)
+    if (TAIL && t < a.T && tactive)
+      tset[t] = (a.tail_set_base + ((int)a.tcset[t * NR + tc0] << 2)) | ((a.tail_set_base + ((int)a.tcset[t * NR + tc0 + 1] << 2)) << 16); // set * 8 -> set * 32
+  }
+  const unsigned long long *amap = a.amapS + lane;
+  const unsigned long long *zmap = a.zmapS + lane;
+
+#define SB_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+
+  // The lane's registers of the NEXT building are loaded while this building's are stored; so are
+  // the building's small inputs.
+  Grid<NR> g;
+  g.init();
+  Win w;
+  double nx_tnow = 0.0, nx_lo = 0.0, nx_hi = 0.0;
+  double tv[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // the lane's tail cells
+  // a building's small inputs: its g per class goes straight into the (ap, g) table (free once the
+  // previous building's A pass is done), its tail rows into tv
+#define SB_LOAD_AUX(bb)                                                                         \
+  do {                                                                                          \
+    nx_tnow = a.bld[(bb)].t_now;                                                                \
+    nx_lo = a.scal[(size_t)(bb) * kNScal + 16];                                                 \
+    nx_hi = a.scal[(size_t)(bb) * kNScal + 17];                                                 \
+    for (int c = lane; c <= a.ncls; c += 64) tapg[2 * c + 1] = a.gtabg[(size_t)(bb) * a.ts + c]; \
+    const double *tt_ = a.temp + (size_t)(bb) * a.state_doubles + NE * 64;                      \
+    _Pragma("unroll") for (int t = 0; t < kTailMax; ++t)                                        \
+      _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
+        if (TAIL && t < a.T) tv[t][k] = tt_[t * NR + tc0 + k];                                  \
+  } while (0)
+  if ((int)blockIdx.x < a.B) {
+    const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles;
+    const unsigned lo8 = (unsigned)opaque(lane * 8);
+    static_for<0, NE>([&](auto Jc) { g.template load_async<decltype(Jc)::value>(tp_, lo8); });
+    g.settle();
+    SB_LOAD_AUX(blockIdx.x);
+  }
+  int iter = 0;
+  for (int b = blockIdx.x, bn = 0; b < a.B; b = bn, ++iter) {
+    {
+      int nb = 0;
+      if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1);
+      bn = __builtin_amdgcn_readfirstlane(nb);
+    }
+    SB_STAMP(0);
+    first_words<NR>(x, lane);
+    double *Ttail = a.temp + (size_t)b * a.state_doubles + NE * 64; // [T][NR]
+    const double t_now = nx_tnow;
+    // exterior-space cells outside the trim box all become t_now in the first sweep
+    // (simulator.py:256-258); their largest |delta| follows from their extreme values
+    const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0;
+    if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(1);
+    double At[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // A of the lane's tail cells
+#pragma unroll
+    for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (TAIL && t < a.T && tactive) {
+          const d2 pg = *(const d2 *)((const char *)tapg + 16 * (int)a.tcls[t * NR + tc0 + k]); // (ap, g) of the cell's class
+          At[t][k] = fma(pg.x, tv[t][k], pg.y);
+        }
+    a_pass<NR, kNL>(g, x, A + (size_t)arow_i * kAS, (const char *)tapg, amap);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(2);
+
+    int n_sweeps = 0, converged = 0;
+    {
+      StepBuf<SYM> pb[2];
+      d2 ring[kAR]; // A's global slots on their way in (dead outside the sweeps: the A pass needs the registers)
+#pragma unroll
+      for (int k = 0; k < kAR; ++k) ring[k] = d2{0.0, 0.0};
+      Acc acc;
+      acc.sre = acc.sro = 0.0;
+      double *tp = a.temp + (size_t)b * a.state_doubles;
+      // the end of a sweep: the tail rows, then max |delta| over the wavefront (uniform)
+      auto sweep_end = [&]() -> double {
+        double dm = acc.cur;
+        if constexpr (TAIL) {
+          // the last row's last column enters its shift register; then both are reversed: lane l
+          // holds columns 2 (l - L0), 2 (l - L0) + 1, the tail scan's layout
+          constexpr int last = (NR + 62) % NR;
+          const double ul = wave_shift1<0x13c, false>(w.pb, 0.0); // slot `last`'s new value: the window's previous slot
+          (void)last;
+          double &sr = (NR - 1) % 2 == 0 ? acc.sre : acc.sro;
+          sr = wave_shift1<0x138, true>(sr, ul);
+          const int rev = (63 - lane) * 4;
+          const double U0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(rev, __double2hiint(acc.sre)),
+                                             __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sre)));
+          const double U1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(rev, __double2hiint(acc.sro)),
+                                             __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sro)));
+          dm = fmax(dm, tail_pass<NR>(a.T, tactive, tE0 + tc0, U0, U1, tv, tset, At));
+        }
+        double md = wave_max(dm);
+        if (n_sweeps == 0) md = fmax(md, ring_d);
+        ++n_sweeps;
+        return md;
+      };
+      const float thr = (float)p.conv_threshold;
+      const int prev_sweeps = __builtin_amdgcn_readfirstlane(a.nsw[b] & 0xffff); // of this building's previous step
+      float d1 = 0.0f, d0 = 0.0f; // max |delta| of the last two sweeps
+#pragma nounroll
+      for (;;) { // simulator.py:348-368
+        // a block: ramp-up, rolling periods while the next sweep cannot be the last one, final period.
+        // The step's first block has no decay to go by: it rolls (pred_first - 1 periods, then by the
+        // decay) if the building's previous step took six sweeps or more -- a hint; a step that
+        // converges sooner is found out and run again from Tprev.
+        const int n0 = n_sweeps;
+        int roll0 = n0 >= 2 ? (int)may_roll(d1, d0, thr, a.pred_haste, a.pred_slack) : (int)(n0 == 0 && prev_sweeps >= 6 && a.pred_first > 1);
+        roll0 = __builtin_amdgcn_readfirstlane(roll0) && n0 + 2 <= p.iter_limit;
+        if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + (roll0 ? 13 : 14), 1ull); // developer aid: blocks / single sweeps
+        if (roll0 && n0 > 0) { // the grid as of n0 sweeps, should the block overrun (before any sweep: Tprev is still there)
+          const unsigned lo8 = (unsigned)opaque(lane * 8);
+          static_for<0, NE>([&](auto Jc) { g.template store<decltype(Jc)::value>(tp, lo8); });
+#pragma unroll
+          for (int t = 0; t < kTailMax; ++t)
+            if (TAIL && t < a.T && tactive) *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
+        }
+        double md = 0.0;
+        int m = 0; // > 0: the block is being run again and ends with its m-th sweep
+#pragma nounroll
+        for (;;) { // at most twice
+          __builtin_amdgcn_sched_barrier(0);
+#define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && n_sweeps == 4 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+          SB_STAMP2(10);
+          acc.cur = 0.0;
+          acc.neg = 0.0;
+          acc.sg = lane == 0 ? (int)0x80000000 : 0;
+          load_step<NR, 0, TAIL, kNL, SYM>(pb[0], x, ring);
+          w.pa = g.template get<NE - 2>();
+          w.pb = g.template get<NE - 1>();
+          w.ca = g.template get<0>();
+          w.cb = g.template get<1>();
+          run_steps<NR, 0, 63, TAIL, false, kNL, SYM>(g, w, ring, pb, x, acc, last_step); // ramp-up; reads ahead for step 63
+          bool overrun = false;
+#pragma nounroll
+          for (int q = 1;; ++q) {
+            int go;
+            if (m > 0) go = q < m;
+            else if (!roll0 || n_sweeps + 2 > p.iter_limit) go = 0; // the final period must fit under the limit
+            else if (q == 1) go = 1;
+            else go = n_sweeps >= 2 ? (int)may_roll(d1, d0, thr, a.pred_haste, a.pred_slack) : (int)(q < a.pred_first);
+            if (!__builtin_amdgcn_readfirstlane(go)) break;
+            // A does not change during the sweeps: unless its address does (as far as the compiler can
+            // tell), every ds_read of the period is hoisted out of this loop -- into scratch
+            asm volatile("" : "+v"(x.arow), "+v"(x.seam));
+            __builtin_amdgcn_sched_barrier(0);
+            run_steps<NR, 63, NR + 63, TAIL, true, kNL, SYM>(g, w, ring, pb, x, acc, last_step);
+            __builtin_amdgcn_sched_barrier(0);
+            md = sweep_end();
+            d1 = d0;
+            d0 = (float)md;
+            if (md <= p.conv_threshold) { // sweep n0 + q was the last one, and the next has been started
+              overrun = true;
+              m = q;
+              break;
+            }
+            acc.cur = -acc.neg;
+            acc.neg = 0.0;
+            acc.sg = lane == 0 ? (int)0x80000000 : 0;
+            load_step<NR, 63, TAIL, kNL, SYM>(pb[1], x, ring); // after the tail scan: lane 63's lower neighbour is new
+          }
+          if (!overrun) break;
+          // back to the stored grid; this time the block ends with sweep n0 + m
+          if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + 15, 1ull);
+          n_sweeps = n0;
+          {
+            const unsigned lo8 = (unsigned)opaque(lane * 8);
+            static_for<0, NE>([&](auto Jc) { g.template load_async<decltype(Jc)::value>(tp, lo8); });
+            g.settle();
+          }
+#pragma unroll
+          for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (TAIL && t < a.T) tv[t][k] = Ttail[t * NR + tc0 + k];
+          if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
+          first_words<NR>(x, lane);
+          __builtin_amdgcn_wave_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        run_steps<NR, 63, NR + 63, TAIL, false, kNL, SYM>(g, w, ring, pb, x, acc, last_step); // the block's last sweep
+        __builtin_amdgcn_sched_barrier(0);
+        first_words<NR>(x, lane); // the next block's first class words
+        SB_STAMP2(11);
+        md = sweep_end();
+        SB_STAMP2(12);
+        d1 = d0;
+        d0 = (float)md;
+        converged = md <= p.conv_threshold;
+        if (converged || n_sweeps >= p.iter_limit) break;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(3);
+
+    // grid back to HBM.  Zone sums (A is dead now): every lane adds its cells into its own slot of the zone
+    // (a.zs_off: the slots of zone z; only the lanes that own a cell of the zone have one); zone Z collects
+    // every cell outside a zone, so that the sum of all slots is the grid sum.
+    double *zs = A;
+    const int zs_n = a.zs_off[a.Z + 1], zs_dump = a.zs_off[a.Z];
+    {
+      unsigned long long zw[kZA + 1];
+      const unsigned long long *zm = zmap + opaque(0);
+#pragma unroll
+      for (int g = 0; g < kZA; ++g) zw[g] = zm[g * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      double *tp = a.temp + (size_t)b * a.state_doubles;
+      for (int i = lane; i < zs_n; i += 64) zs[i] = 0.0;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < kTailMax; ++t) // the tail rows hold no zone cells (sb_create checks): all into row Z
+        if (TAIL && t < a.T && tactive) {
+          *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
+          zs[zs_dump + lane] += tv[t][0] + tv[t][1]; // the lane's own slot of zone Z
+        }
+      const double *np_ = a.temp + (size_t)(bn < a.B ? bn : b) * a.state_doubles;
+      hand_over<NR, 0>(g, zw, zm, tp, np_, opaque(lane * 8), zs);
+      g.settle();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SB_STAMP(4);
+    if (bn < a.B) SB_LOAD_AUX(bn);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_wave_barrier();
+
+    { // hand the zone sums, the grid sum and the sweep count to k_post: a lane per zone adds the zone's slots
+      // in slot order (deterministic), four at a time
+      double gacc = 0.0;
+      for (int zb = 0; zb <= a.Z; zb += 64) {
+        const int zz = zb + lane;
+        double v = 0.0;
+        if (zz <= a.Z) {
+          const int s0 = a.zs_off[zz], s1 = a.zs_off[zz + 1];
+          double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+          int i = s0;
+          for (; i + 4 <= s1; i += 4) { v += zs[i]; v1 += zs[i + 1]; v2 += zs[i + 2]; v3 += zs[i + 3]; }
+          for (; i < s1; ++i) v += zs[i];
+          v = (v + v1) + (v2 + v3);
+          if (zz < a.Z) a.zsum[(size_t)b * a.Z + zz] = v;
+          gacc += v;
+        }
+      }
+      const double gsum = wave_sum(gacc);
+      if (lane == 0) {
+        a.gsum[b] = gsum + (double)a.n_ring * t_now;
+        a.nsw[b] = n_sweeps | (converged << 16);
+      }
+      SB_STAMP(5);
+      if (a.dbg && blockIdx.x == 0 && iter == 3 && lane == 0) a.dbg[9] = n_sweeps;
+    }
+    __builtin_amdgcn_wave_barrier(); // the zone sums are read: A may be written again
+  }
+#undef SB_STAMP
+#undef SB_STAMP2
+#undef SB_LOAD_AUX
+}
+
+template <int NR, bool TAIL, int LEVEL, bool SYM>
+int launch(const Dev &d, hipStream_t stream, bool prepare) {
+  if (prepare)
+    return (int)hipFuncSetAttribute((const void *)k_sweep_two<NR, TAIL, LEVEL, SYM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    d.lds_reg_bytes);
+  hipLaunchKernelGGL((k_sweep_two<NR, TAIL, LEVEL, SYM>), dim3(d.sweep_wgs), dim3(64), (size_t)d.lds_reg_bytes, stream, d);
+  return (int)hipGetLastError();
+}
+
+// The planner's choice (plan_two): four coefficients per cell (level 0 only) or two (d.two_sym); d.two_level:
+// how much of A stays in LDS, i.e. two, three or four buildings per CU.
+template <int NR, bool TAIL>
+int launch_v(const Dev &d, hipStream_t stream, bool prepare) {
+#ifdef SB_TWO_ONLY // developer builds: one instantiation
+  return launch<NR, TAIL, SB_TWO_ONLY_LEVEL, true>(d, stream, prepare);
+#else
+  if (!d.two_sym) return d.two_level == 0 ? launch<NR, TAIL, 0, false>(d, stream, prepare) : (int)hipErrorInvalidValue;
+  if (d.two_level == 2) return launch<NR, TAIL, 2, true>(d, stream, prepare);
+  if (d.two_level == 1) return launch<NR, TAIL, 1, true>(d, stream, prepare);
+  return launch<NR, TAIL, 0, true>(d, stream, prepare);
+#endif
+}
+
+} // namespace
+} // namespace sb

@@ -11,7 +11,7 @@ base=$(basename $src .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fPIC "$@" \
   -I $root/include -I $root/sbsim_amd/csrc -c $root/sbsim_amd/csrc/$src -o $obj/${base}_$name.o
 objs=""
-for o in sbsim_hip step_reg step_roll step_two step_band step_stream step_lds generators floorplan episode; do
+for o in sbsim_hip step_reg step_roll step_two step_two_76 step_two_80 step_band step_stream step_lds generators floorplan episode; do
   [ $o = $base ] && objs="$objs $obj/${base}_$name.o" || objs="$objs $obj/$o.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $root/tools/libexp_$name.so
