@@ -99,12 +99,13 @@ struct Ctx {
 // VGPRs, the rest in AGPRs -- by hand: left to the register allocator, every register of the unrolled
 // sweep goes through an AGPR (and some through scratch).  VALU instructions cannot read AGPRs, so a
 // step reads the slot it needs next (v_accvgpr_read) and writes its results back once.
-template <int NR>
+// NV: slots homed in VGPRs -- 24, or fewer in the instantiations with tail rows (their per-lane tail state is alive
+// through the sweeps: with 24 the compiler parked 24-100 bytes of building-lifetime values in scratch; a slot
+// moved to AGPRs costs eight v_accvgpr moves per period, 0.3 %)
+constexpr int grid_vgpr_slots(int NR, bool tail) { return !tail ? 24 : NR <= 76 ? 20 : 16; }
+template <int NR, int NV>
 struct Grid {
-#ifndef SB_TWO_NV
-#define SB_TWO_NV 24
-#endif
-  static constexpr int kNV = SB_TWO_NV; // slots homed in VGPRs
+  static constexpr int kNV = NV; // slots homed in VGPRs
   static constexpr int NE = 2 * NR, NVE = 2 * kNV;
   double v[NVE];
   int a[2 * (NE - NVE)];
@@ -266,8 +267,8 @@ __device__ __forceinline__ void load_step(StepBuf<SYM> &p, Ctx &x, const d2 (&ri
 //   63 <= S < NR       all 64 lanes are in the same sweep
 //   NR <= S < NR + 63  ROLL: lanes <= S - NR are in the next sweep; else they have finished (masked)
 // Association order of the four products as in step_lds.hip / step_reg.hip / step_roll.hip.
-template <int NR, int S, bool TAIL, bool ROLL, bool SYM>
-__device__ __forceinline__ void step(Grid<NR> &g, Win &w, const StepBuf<SYM> &p, Acc &acc) {
+template <int NR, int S, bool TAIL, bool ROLL, bool SYM, int NV>
+__device__ __forceinline__ void step(Grid<NR, NV> &g, Win &w, const StepBuf<SYM> &p, Acc &acc) {
   constexpr int r = S % NR, rp = (S + 1) % NR;
   const double na = g.template get<2 * rp>(), nb = g.template get<2 * rp + 1>(); // old values one column ahead
   const double U = wave_shift1<0x13c, false>(w.pb, 0.0); // lane 0 sees the last row's latest value (times bU = 0; SYM: lane 0's upper cell is a pad row)
@@ -330,8 +331,8 @@ __device__ __forceinline__ void step(Grid<NR> &g, Win &w, const StepBuf<SYM> &p,
 // Steps S .. S1 - 1; the LDS reads of step S + 1 are issued before the arithmetic of step S (the
 // caller issues those of the first step; a period's last step reads nothing ahead).
 // last_step: the step at which the last lane that owns a row finishes (NR + lanes - 2).
-template <int NR, int S, int S1, bool TAIL, bool ROLL, int NL, bool SYM>
-__device__ __forceinline__ void run_steps(Grid<NR> &g, Win &w, d2 (&ring)[kAR], StepBuf<SYM> (&pb)[2], Ctx &x,
+template <int NR, int S, int S1, bool TAIL, bool ROLL, int NL, bool SYM, int NV>
+__device__ __forceinline__ void run_steps(Grid<NR, NV> &g, Win &w, d2 (&ring)[kAR], StepBuf<SYM> (&pb)[2], Ctx &x,
                                           Acc &acc, int last_step) {
   if constexpr (S < S1) {
     if constexpr (!ROLL && S >= NR && (S - NR) % 4 == 0)
@@ -359,13 +360,13 @@ __device__ __forceinline__ bool may_roll(float d1, float d0, float thr, float ha
 // A = ap*Tprev + g for the lane's cells (e = Tprev before the first sweep): the pair of slot j to
 // [2 j] of the lane's A row or to the registers.  aw: class offsets into the (ap, g) table, four
 // cells per word.
-template <int NR, int NL>
-__device__ __forceinline__ void a_pass(const Grid<NR> &g, const Ctx &x, double *Aw, const char *tapg,
+template <int NR, int NL, int NV>
+__device__ __forceinline__ void a_pass(const Grid<NR, NV> &g, const Ctx &x, double *Aw, const char *tapg,
                                        const unsigned long long *amap) {
   constexpr int NWD = (2 * NR + 3) / 4;
   static_assert(NR % 4 == 0, "a_pass: four slots per group");
   amap += opaque(0);
-  constexpr int kAA = 8; // words (four registers each) read ahead
+  constexpr int kAA = 4; // words (four registers each) read ahead (8 were no faster and cost eight registers that the tail rows then spilled)
   unsigned long long aw[kAA + 2];
   unsigned gofs = x.aoff;
 #pragma unroll
@@ -402,8 +403,8 @@ __device__ __forceinline__ void a_pass(const Grid<NR> &g, const Ctx &x, double *
 // load the same register of the next building.  zw: zone-sum offsets (in doubles), four registers
 // per word, read kZA words ahead (memory operations return in order: waiting for a young word
 // would drain the queue of row loads in front of it).
-template <int NR, int J>
-__device__ __forceinline__ void hand_over(Grid<NR> &g, unsigned long long (&zw)[kZA + 1], const unsigned long long *zmap,
+template <int NR, int J, int NV>
+__device__ __forceinline__ void hand_over(Grid<NR, NV> &g, unsigned long long (&zw)[kZA + 1], const unsigned long long *zmap,
                                           double *tp, const double *np_, int lane_off, double *zs) {
   constexpr int NE = 2 * NR;
   if constexpr (J < NE) {
@@ -423,7 +424,7 @@ extern __shared__ __attribute__((aligned(16))) double lds[];
 template <int NR, bool TAIL, int LEVEL, bool SYM>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_two(Dev a) {
   const int lane = threadIdx.x & 63;
-  constexpr int kNL = lds_slots(NR, LEVEL), kAS = a_stride_of(kNL), NE = 2 * NR;
+  constexpr int kNL = lds_slots(NR, LEVEL), kAS = a_stride_of(kNL), NE = 2 * NR, NV = grid_vgpr_slots(NR, TAIL);
   static_assert(kNL >= kAD && NR - kNL >= 0, "the global slots are read kAD steps ahead, from a step of the same period");
   constexpr int kZW = (NE + 3) / 4;
 
@@ -454,37 +455,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   // 16-bit halves)
   const bool tactive = TAIL && tail_col<NR>(lane, 0) >= 0;
   const int tc0 = tactive ? tail_col<NR>(lane, 0) : 0;
-  int tset[kTailMax];
+  int tset[kTailMax], tcl[kTailMax]; // and the (ap, g) table offsets of their classes (two 16-bit halves)
 #pragma unroll
   for (int t = 0; t < kTailMax; ++t) {
+    tcl[t] = 0;
+    if (TAIL && t < a.T && tactive) tcl[t] = (16 * (int)a.tcls[t * NR + tc0]) | ((16 * (int)a.tcls[t * NR + tc0 + 1]) << 16);
     tset[t] = a.tail_pad_set * 0x10001; // the pad set of the tail cells' table (byte offset)
     if (TAIL && t < a.T && tactive)
       tset[t] = (a.tail_set_base + ((int)a.tcset[t * NR + tc0] << 2)) | ((a.tail_set_base + ((int)a.tcset[t * NR + tc0 + 1] << 2)) << 16); // set * 8 -> set * 32
   }
-  const unsigned long long *amap = a.amapS + lane;
-  const unsigned long long *zmap = a.zmapS + lane;
+  // (a.amapS + lane, a.zmapS + lane: formed where they are used, from an opaque lane number -- as kernel-lifetime
+  // 64-bit values they lived in scratch)
 
 #define SB_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
   // The lane's registers of the NEXT building are loaded while this building's are stored; so are
   // the building's small inputs.
-  Grid<NR> g;
+  Grid<NR, NV> g;
   g.init();
   Win w;
   double nx_tnow = 0.0, nx_lo = 0.0, nx_hi = 0.0;
   double tv[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // the lane's tail cells
   // a building's small inputs: its g per class goes straight into the (ap, g) table (free once the
-  // previous building's A pass is done), its tail rows into tv
+  // previous building's A pass is done).  (Its tail rows are read after the A pass: read here, eight more
+  // registers are alive during it -- in scratch; the exposed load is 1 us of a 0.1-0.6 ms building-step.)
 #define SB_LOAD_AUX(bb)                                                                         \
   do {                                                                                          \
     nx_tnow = a.bld[(bb)].t_now;                                                                \
     nx_lo = a.scal[(size_t)(bb) * kNScal + 16];                                                 \
     nx_hi = a.scal[(size_t)(bb) * kNScal + 17];                                                 \
     for (int c = lane; c <= a.ncls; c += 64) tapg[2 * c + 1] = a.gtabg[(size_t)(bb) * a.ts + c]; \
-    const double *tt_ = a.temp + (size_t)(bb) * a.state_doubles + NE * 64;                      \
-    _Pragma("unroll") for (int t = 0; t < kTailMax; ++t)                                        \
-      _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
-        if (TAIL && t < a.T) tv[t][k] = tt_[t * NR + tc0 + k];                                  \
   } while (0)
   if ((int)blockIdx.x < a.B) {
     const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles;
@@ -502,25 +502,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     }
     SB_STAMP(0);
     first_words<NR>(x, lane);
-    double *Ttail = a.temp + (size_t)b * a.state_doubles + NE * 64; // [T][NR]
-    const double t_now = nx_tnow;
+    char *Ttail = (char *)(a.temp + (size_t)b * a.state_doubles + NE * 64); // [T][NR], uniform; the lane's part: tc0 * 8, made opaque where it is used
+    // wave-uniform: into scalar registers (as vector registers they stayed alive through the sweeps)
+    auto uni = [](double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); };
+    const double t_now = uni(nx_tnow);
     // exterior-space cells outside the trim box all become t_now in the first sweep
     // (simulator.py:256-258); their largest |delta| follows from their extreme values
-    const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0;
-    if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
-    __builtin_amdgcn_wave_barrier();
+    const double ring_d = uni(a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0);
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(1);
+    a_pass<NR, kNL>(g, x, A + (size_t)arow_i * kAS, (const char *)tapg, a.amapS + opaque(lane));
+    __builtin_amdgcn_sched_barrier(0);
     double At[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // A of the lane's tail cells
+    if constexpr (TAIL) {
+      const unsigned to_ = (unsigned)opaque(tc0 * 8); // uniform base + the lane's offset (a 64-bit pointer per tail cell would be a kernel-lifetime value)
 #pragma unroll
-    for (int t = 0; t < kTailMax; ++t)
+      for (int t = 0; t < kTailMax; ++t)
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if (TAIL && t < a.T && tactive) {
-          const d2 pg = *(const d2 *)((const char *)tapg + 16 * (int)a.tcls[t * NR + tc0 + k]); // (ap, g) of the cell's class
-          At[t][k] = fma(pg.x, tv[t][k], pg.y);
-        }
-    a_pass<NR, kNL>(g, x, A + (size_t)arow_i * kAS, (const char *)tapg, amap);
+        for (int k = 0; k < 2; ++k)
+          if (t < a.T) tv[t][k] = *(const double *)(Ttail + to_ + (unsigned)(t * NR + k) * 8u);
+      if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
+#pragma unroll
+      for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (t < a.T && tactive) {
+            const d2 pg = *(const d2 *)((const char *)tapg + ((tcl[t] >> (16 * k)) & 0xffff)); // (ap, g) of the cell's class
+            At[t][k] = fma(pg.x, tv[t][k], pg.y);
+          }
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(2);
@@ -575,7 +585,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           static_for<0, NE>([&](auto Jc) { g.template store<decltype(Jc)::value>(tp, lo8); });
 #pragma unroll
           for (int t = 0; t < kTailMax; ++t)
-            if (TAIL && t < a.T && tactive) *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
+            if (TAIL && t < a.T && tactive) *(d2 *)(Ttail + (unsigned)opaque(tc0 * 8) + (unsigned)(t * NR) * 8u) = d2{tv[t][0], tv[t][1]};
         }
         double md = 0.0;
         int m = 0; // > 0: the block is being run again and ends with its m-th sweep
@@ -634,7 +644,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           for (int t = 0; t < kTailMax; ++t)
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-              if (TAIL && t < a.T) tv[t][k] = Ttail[t * NR + tc0 + k];
+              if (TAIL && t < a.T) tv[t][k] = *(const double *)(Ttail + (unsigned)opaque(tc0 * 8) + (unsigned)(t * NR + k) * 8u);
           if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
           first_words<NR>(x, lane);
           __builtin_amdgcn_wave_barrier();
@@ -662,7 +672,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     const int zs_n = a.zs_off[a.Z + 1], zs_dump = a.zs_off[a.Z];
     {
       unsigned long long zw[kZA + 1];
-      const unsigned long long *zm = zmap + opaque(0);
+      const unsigned long long *zm = a.zmapS + opaque(lane);
 #pragma unroll
       for (int g = 0; g < kZA; ++g) zw[g] = zm[g * 64];
       __builtin_amdgcn_sched_barrier(0);
@@ -672,7 +682,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
       for (int t = 0; t < kTailMax; ++t) // the tail rows hold no zone cells (sb_create checks): all into row Z
         if (TAIL && t < a.T && tactive) {
-          *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
+          *(d2 *)(Ttail + (unsigned)opaque(tc0 * 8) + (unsigned)(t * NR) * 8u) = d2{tv[t][0], tv[t][1]};
           zs[zs_dump + lane] += tv[t][0] + tv[t][1]; // the lane's own slot of zone Z
         }
       const double *np_ = a.temp + (size_t)(bn < a.B ? bn : b) * a.state_doubles;
