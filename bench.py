@@ -153,20 +153,21 @@ def stub_rank(args) -> None:
   if distributed:
     assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
   dev = torch.device("cpu")
+  pf = sd.preflight(dev, args.gpus)       # before any work: world size, a 256 KiB all_gather, all_reduce(MAX)
   B, K, W = args.buildings, args.steps, args.warmup
   lo, hi = sd.shard_range(world * B, rank, world)
   returns = torch.zeros((B,), dtype=torch.float32)
   for _ in range(W):
     time.sleep(1e-3)
-  if distributed:
-    dist.barrier()
+  sd.barrier(dev)
   t0 = time.perf_counter()
   for t in range(K):
     time.sleep(1e-3)
     returns += torch.arange(lo, hi, dtype=torch.float32)
-  if distributed:
-    dist.barrier()
-  elapsed = sd.max_over_ranks(time.perf_counter() - t0, dev)
+  sd.barrier(dev)
+  mine = time.perf_counter() - t0
+  per_rank = sd.all_ranks(mine / K * 1e3, dev)
+  elapsed = sd.max_over_ranks(mine, dev)
   g0 = time.perf_counter()
   all_returns = sd.gather_returns(returns, world * B)
   gather_ms = (time.perf_counter() - g0) * 1e3
@@ -176,7 +177,9 @@ def stub_rank(args) -> None:
                       "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stub",
                       "return_gather_ms": gather_ms, "gathered_returns": int(all_returns.numel()),
-                      "gather_in_global_order": ok, "config": {"workload": "launcher plumbing test (stub step, gloo)"}}))
+                      "gather_in_global_order": ok, "rccl_ranks": pf["ranks"], "preflight": pf,
+                      "per_rank_ms_per_step": per_rank,
+                      "config": {"workload": "launcher plumbing test (stub step, gloo)"}}))
   if distributed:
     dist.destroy_process_group()
 
@@ -353,6 +356,24 @@ def mixed_config(args) -> None:
     c["env"].close()
 
 
+def start_rank(args):
+  """One process per GPU: binds the rank to its device, joins the process group ("nccl" = RCCL on ROCm) and
+  runs the preflight check (sbsim_amd.distributed.preflight: world size, one rank per device, a 256 KiB
+  all_gather and an all_reduce(MAX)) BEFORE any environment is built.  -> (rank, device, distributed?, preflight)."""
+  rank, local_rank, world = sd.env_rank_world()
+  local_rank = sd.device_index(local_rank)      # (SBSIM_BENCH_SHARE_GPU=1: ranks share the visible devices)
+  if local_rank >= torch.cuda.device_count():
+    raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but {torch.cuda.device_count()} are visible "
+                     f"(--gpus {args.gpus}: one process per GPU of this node)")
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+  distributed = sd.init_process_group(sd.backend_for_gpu())
+  if not distributed and args.gpus != 1:
+    raise SystemExit(f"bench.py: --gpus {args.gpus} but only one rank is running")
+  pf = sd.preflight(dev, args.gpus)
+  return rank, dev, distributed, pf
+
+
 def policy_config(args) -> None:
   """BASELINE.json configs[4] (SURVEY.md 8d "Config 5"): the configs[1] batch per GPU driven through
   `BatchedEnvironment.step()` by a SAC-shaped actor (2 x 128 MLP, tanh-squashed Gaussian, the policy
@@ -360,17 +381,10 @@ def policy_config(args) -> None:
   never leave HBM, data-parallel actors, no per-step collective.  env-steps/s INCLUDE policy inference
   and the host-side step inputs.  tf-agents is not installable here: the loop makes the same env API
   calls (`reset()`, `step(action)` -> TimeStep) a tf-agents driver would."""
-  rank, local_rank, world = sd.env_rank_world()
-  local_rank = sd.device_index(local_rank)
-  torch.cuda.set_device(local_rank)
-  distributed = sd.init_process_group(sd.backend_for_gpu())
+  rank, dev, distributed, pf = start_rank(args)
+  local_rank, world = dev.index, pf["ranks"]
   if distributed:
     import torch.distributed as dist
-    if dist.get_world_size() != args.gpus:
-      raise SystemExit(f"bench.py: --gpus {args.gpus} but {dist.get_world_size()} ranks are running")
-  elif args.gpus != 1:
-    raise SystemExit(f"bench.py: --gpus {args.gpus} but only one rank is running")
-  dev = torch.device("cuda", local_rank)
   B, K, W = args.buildings, args.steps, args.warmup
   plan = r9_plan()
   env = BatchedEnvironment(plan, B, device=local_rank, holiday_calendar="us", num_days_in_episode=3,
@@ -395,8 +409,7 @@ def policy_config(args) -> None:
     return torch.tanh(mean + log_std.exp() * torch.randn(mean.shape, device=dev, generator=gen)).contiguous()
 
   def barrier():
-    if distributed:
-      dist.barrier()
+    sd.barrier(dev)
     torch.cuda.synchronize(dev)
 
   obs = ts.observation
@@ -423,7 +436,9 @@ def policy_config(args) -> None:
     obs = ts.observation
     returns += ts.reward
   barrier()
-  elapsed = sd.max_over_ranks(time.perf_counter() - t0, dev)
+  mine = time.perf_counter() - t0
+  per_rank = sd.all_ranks(mine / K * 1e3, dev)
+  elapsed = sd.max_over_ranks(mine, dev)
   gather_ms, n_gathered = 0.0, B
   if distributed:
     g0 = time.perf_counter()
@@ -440,6 +455,7 @@ def policy_config(args) -> None:
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "env_steps_per_s": env_steps_per_s,
         "return_gather_ms": gather_ms, "gathered_returns": n_gathered,
+        "rccl_ranks": pf["ranks"], "preflight": pf, "per_rank_ms_per_step": per_rank,
         "config": {"workload": "BASELINE.json configs[4]: configs[1]'s batch per GPU driven through BatchedEnvironment.step() "
                                "by a SAC-shaped actor (2 x 128 MLP, tanh-squashed Gaussian) on the environment's GPU",
                    "buildings_per_gpu": B, "grid": [H, Wd], "zones": Z, "policy": "MLP %d-128-128-4, fp32" % O,
@@ -485,17 +501,10 @@ def main() -> None:
   if args.config == "policy":
     return policy_config(args)
 
-  rank, local_rank, world = sd.env_rank_world()
-  local_rank = sd.device_index(local_rank)      # (SBSIM_BENCH_SHARE_GPU=1: ranks share the visible devices)
-  torch.cuda.set_device(local_rank)
-  distributed = sd.init_process_group(sd.backend_for_gpu())   # "nccl" is RCCL on ROCm
+  rank, dev, distributed, pf = start_rank(args)
+  local_rank, world = dev.index, pf["ranks"]
   if distributed:
     import torch.distributed as dist
-    if dist.get_world_size() != args.gpus:
-      raise SystemExit(f"bench.py: --gpus {args.gpus} but {dist.get_world_size()} ranks are running")
-  elif args.gpus != 1:
-    raise SystemExit(f"bench.py: --gpus {args.gpus} but only one rank is running")
-  dev = torch.device("cuda", local_rank)
 
   B, K, W = args.buildings, args.steps, args.warmup
   plan = r9_plan()
@@ -515,8 +524,7 @@ def main() -> None:
   returns = torch.zeros((B,), dtype=torch.float32, device=dev)
 
   def barrier():
-    if distributed:
-      dist.barrier()
+    sd.barrier(dev)
     torch.cuda.synchronize(dev)
 
   def new_events(n, per_step):
@@ -560,6 +568,8 @@ def main() -> None:
   pre_ms = float(np.mean([e[2].elapsed_time(e[0]) for e in wev])) if W else None
   post_ms = float(np.mean([e[1].elapsed_time(e[3]) for e in wev])) if W else None
 
+  per_rank = sd.all_ranks(elapsed / K * 1e3, dev)   # every rank's own ms per step (the line's value uses the slowest)
+  per_rank_kernel = sd.all_ranks(float(np.mean(kernel_ms)), dev)
   elapsed = sd.max_over_ranks(elapsed, dev)
   gather_ms, n_gathered = 0.0, B
   if distributed:
@@ -584,6 +594,8 @@ def main() -> None:
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "env_steps_per_s": env_steps_per_s,
         "return_gather_ms": gather_ms, "gathered_returns": n_gathered,   # end-of-rollout all_gather, outside the timed region
+        "rccl_ranks": pf["ranks"], "preflight": pf,                      # what sbsim_amd.distributed.preflight saw before the run
+        "per_rank_ms_per_step": per_rank, "per_rank_sweep_kernel_ms": per_rank_kernel,
         "config": {"workload": "BASELINE.json configs[1]: 64k replicated SB1-physics buildings on floor plan R9 "
                                "(68x98 CVs, 9 zones), random setpoint actions, sinusoid weather",
                    "buildings_per_gpu": B, "grid": [H, Wd], "zones": Z,

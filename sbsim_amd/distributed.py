@@ -91,6 +91,78 @@ def gather_returns(local_returns: torch.Tensor, n_buildings_total: int) -> torch
   return out.to(local_returns.device) if staged else out
 
 
+def barrier(device: torch.device | None = None) -> None:
+  """dist.barrier() that names the rank's device under RCCL (without device_ids the first barrier of a
+  process binds NCCL/RCCL to "the current device" with a warning, and to the wrong one if set_device was
+  forgotten); a plain barrier on gloo; nothing when single-process."""
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    return
+  if dist.get_backend() == "nccl" and device is not None and device.type == "cuda":
+    dist.barrier(device_ids=[device.index])
+  else:
+    dist.barrier()
+
+
+def all_ranks(value: float, device: torch.device) -> List[float]:
+  """One float per rank, in rank order, on every rank (per-rank step times in the bench line)."""
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    return [float(value)]
+  on_host = dist.get_backend() == "gloo"
+  t = torch.tensor([value], dtype=torch.float64, device="cpu" if on_host else device)
+  parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+  dist.all_gather(parts, t)
+  return [float(p.item()) for p in parts]
+
+
+def preflight(device: torch.device, n_expected: int, payload_bytes: int = 256 * 1024) -> dict:
+  """Checks the multi-process set-up before any environment is built, so that the first RCCL run fails
+  early and legibly instead of hanging in a collective: the world size is what the caller expects, every
+  rank sits on its own device (unless SBSIM_BENCH_SHARE_GPU=1), a 256 KiB all_gather returns every rank's
+  pattern in rank order and an all_reduce(MAX) returns the largest rank.  Returns what it saw (rank 0 prints
+  it in the bench line); raises SystemExit with the reason otherwise.  Backend-agnostic: "nccl" (= RCCL) on
+  GPUs, "gloo" in the CPU tests."""
+  if not (dist.is_available() and dist.is_initialized()):
+    if n_expected != 1:
+      raise SystemExit(f"preflight: {n_expected} ranks expected but torch.distributed is not initialised "
+                       "(start under torch.distributed.run, or let bench.py --gpus N launch the ranks)")
+    return {"ranks": 1, "backend": None, "devices": [str(device)], "ok": True}
+  world, rank, backend = dist.get_world_size(), dist.get_rank(), dist.get_backend()
+  if world != n_expected:
+    raise SystemExit(f"preflight: {n_expected} ranks expected, the process group has {world}")
+  on_host = backend == "gloo" or device.type != "cuda"
+  cdev = torch.device("cpu") if on_host else device
+  if device.type == "cuda":
+    n_dev = torch.cuda.device_count()
+    if not share_gpu() and n_dev < world:
+      raise SystemExit(f"preflight: {world} ranks on this node but only {n_dev} visible GPU(s) "
+                       "(one process per GPU; SBSIM_BENCH_SHARE_GPU=1 shares devices over gloo for tests)")
+  # every rank's device, in rank order
+  mine = torch.tensor([device.index if device.type == "cuda" else -1], dtype=torch.int64, device=cdev)
+  seen = [torch.empty_like(mine) for _ in range(world)]
+  dist.all_gather(seen, mine)
+  devices = [int(t.item()) for t in seen]
+  if device.type == "cuda" and not share_gpu() and len(set(devices)) != world:
+    raise SystemExit(f"preflight: two ranks share a device (rank -> device: {devices}); "
+                     "each rank must call torch.cuda.set_device(LOCAL_RANK)")
+  # a payload-sized all_gather: rank r sends r + 1 everywhere
+  n = max(1, payload_bytes // 4)
+  src = torch.full((n,), float(rank + 1), dtype=torch.float32, device=cdev)
+  parts = [torch.empty_like(src) for _ in range(world)]
+  dist.all_gather(parts, src)
+  for r, p in enumerate(parts):
+    if not bool((p == float(r + 1)).all()):
+      raise SystemExit(f"preflight: all_gather returned wrong data for rank {r} on rank {rank} ({backend})")
+  top = torch.tensor([float(rank)], dtype=torch.float64, device=cdev)
+  dist.all_reduce(top, op=dist.ReduceOp.MAX)
+  if int(top.item()) != world - 1:
+    raise SystemExit(f"preflight: all_reduce(MAX) over ranks gave {top.item()}, expected {world - 1} ({backend})")
+  if device.type == "cuda":
+    torch.cuda.synchronize(device)
+  names = devices if device.type != "cuda" else [f"cuda:{d}" for d in devices]
+  return {"ranks": world, "backend": "rccl (torch 'nccl')" if backend == "nccl" else backend, "devices": names,
+          "all_gather_bytes_per_rank": n * 4, "ok": True}
+
+
 def max_over_ranks(seconds: float, device: torch.device) -> float:
   """Wall time of the slowest rank (bench.py contract)."""
   if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

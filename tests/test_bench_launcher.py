@@ -32,6 +32,11 @@ def test_gpus_2_spawns_two_ranks_and_gathers_in_global_order():
   assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
   assert d["gathered_returns"] == 74 and d["gather_in_global_order"] is True
   assert d["return_gather_ms"] >= 0.0 and d["scaling"] == "weak"
+  # the preflight check ran before the steps (world size, a 256 KiB all_gather, all_reduce(MAX)) and every
+  # rank's own step time is in the line, so that a scaling line can be verified
+  assert d["rccl_ranks"] == 2 and d["preflight"]["ok"] is True and d["preflight"]["backend"] == "gloo"
+  assert d["preflight"]["all_gather_bytes_per_rank"] == 256 * 1024
+  assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.001 + 1e-9
 
 
 def test_gpus_1_runs_in_process():
@@ -39,8 +44,33 @@ def test_gpus_1_runs_in_process():
   assert r.returncode == 0, r.stderr[-2000:]
   d = _json_line(r.stdout)
   assert d["n_gpus"] == 1 and d["gathered_returns"] == 5
+  assert d["rccl_ranks"] == 1 and d["per_rank_ms_per_step"] == [d["ms_per_step"]]
 
 
 def test_world_size_mismatch_is_an_error():
   r = _run(["--gpus", "4", "--stub-step"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
   assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_preflight_tool_on_gloo():
+  """tools/preflight_multi_gpu.py --cpu under torch.distributed.run: both ranks pass and say so."""
+  import socket
+  with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+  env = dict(os.environ)
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                      "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "preflight_multi_gpu.py"), "--cpu"],
+                     capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+  assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+  assert r.stdout.count(": ok") == 2 and "preflight rank 0/2" in r.stdout and "preflight rank 1/2" in r.stdout
+
+
+def test_preflight_refuses_a_world_size_it_was_not_told():
+  from sbsim_amd import distributed as sd
+  import torch
+  assert sd.preflight(torch.device("cpu"), 1)["ranks"] == 1
+  with pytest.raises(SystemExit, match="2 ranks expected"):
+    sd.preflight(torch.device("cpu"), 2)

@@ -915,6 +915,9 @@ def test_bench_two_ranks_sharing_one_gpu(monkeypatch):
   d = _run_bench(["--gpus", "2", "--buildings", "8192", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"])
   assert d["n_gpus"] == 2 and d["gathered_returns"] == 16384 and d["scaling"] == "weak"
   assert d["config"]["buildings_per_gpu"] == 8192 and d["value"] > 1e6 and "share a device" in d["config"]["parallelism"]
+  # the preflight check (world size, device per rank, 256 KiB all_gather, all_reduce(MAX)) ran first; per-rank times
+  assert d["rccl_ranks"] == 2 and d["preflight"]["ok"] is True and d["preflight"]["devices"] == ["cuda:0", "cuda:0"]
+  assert len(d["per_rank_ms_per_step"]) == 2 and len(d["per_rank_sweep_kernel_ms"]) == 2
   p = _run_bench(["--config", "policy", "--gpus", "2", "--buildings", "4096", "--steps", "2", "--warmup", "1"])
   assert p["n_gpus"] == 2 and p["gathered_returns"] == 8192
 
@@ -928,4 +931,6 @@ def test_bench_two_gpus_when_the_box_has_them():
   one = _run_bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
   two = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
   assert two["n_gpus"] == 2 and two["gathered_returns"] == 131072
+  assert two["rccl_ranks"] == 2 and two["preflight"]["backend"].startswith("rccl") and two["preflight"]["devices"] == ["cuda:0", "cuda:1"]
+  assert len(two["per_rank_ms_per_step"]) == 2 and max(two["per_rank_ms_per_step"]) <= two["ms_per_step"] * 1.01
   assert two["value"] / 2 > 0.9 * one["value"]
