@@ -488,6 +488,9 @@ def main() -> None:
                   help="replicated: BASELINE.json configs[1] (the metric's configuration, default); "
                        "mixed: configs[2], three floor-plan classes on one GPU; policy: configs[4], the "
                        "replicated batch driven by a SAC-shaped actor on the same GPU(s)")
+  ap.add_argument("--through-env-api", action="store_true",
+                  help="time BatchedEnvironment.step() itself (the public API) instead of the three phase launches; "
+                       "roofline.avg_kernel_ms is then the whole step's GPU time")
   ap.add_argument("--stub-step", action="store_true",
                   help="developer / CPU test: launcher, barrier and return-gather plumbing with a stub step (gloo)")
   args = ap.parse_args()
@@ -548,6 +551,16 @@ def main() -> None:
     env._prev_thermostat_ts = env._now
     env._now = env._now + env._step_interval
 
+  if args.through_env_api:   # the public API itself: BatchedEnvironment.step() (host inputs, sb_step, TimeStep); the events bracket the whole step
+    def one_step(t, e):  # noqa: F811
+      if len(e) == 4:
+        e[2].record()
+      e[0].record()
+      env.step(actions[t])
+      e[1].record()
+      if len(e) == 4:
+        e[3].record()
+
   wev, ev = new_events(W, 4), new_events(K, 2)
   for t in range(W):
     one_step(t, wev[t])
@@ -596,6 +609,7 @@ def main() -> None:
         "return_gather_ms": gather_ms, "gathered_returns": n_gathered,   # end-of-rollout all_gather, outside the timed region
         "rccl_ranks": pf["ranks"], "preflight": pf,                      # what sbsim_amd.distributed.preflight saw before the run
         "per_rank_ms_per_step": per_rank, "per_rank_sweep_kernel_ms": per_rank_kernel,
+        "timed_through": "BatchedEnvironment.step()" if args.through_env_api else "BatchedSimulator.step(phases=PRE | SWEEP | POST) with HIP events around the sweep kernel",
         "config": {"workload": "BASELINE.json configs[1]: 64k replicated SB1-physics buildings on floor plan R9 "
                                "(68x98 CVs, 9 zones), random setpoint actions, sinusoid weather",
                    "buildings_per_gpu": B, "grid": [H, Wd], "zones": Z,
@@ -631,7 +645,12 @@ def main() -> None:
       if same_kernel and t.get("state_bytes_per_building") == state_bytes and B == 65536:
         result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
         result["roofline"]["traffic_source"] = t.get("source")
+        # replayed from the committed PMC profile of this command (a run cannot read its own TCC counters);
+        # the guards above tie it to this kernel, state layout and batch
+        result["roofline"]["traffic_measured_in_run"] = False
+        result["roofline"]["traffic_profile_commit"] = t.get("commit")
       else:
+        result["roofline"]["traffic_measured_in_run"] = False
         result["roofline"]["traffic_source"] = (f"profiles/traffic_latest.json is for kernel {t.get('kernel')!r}, "
                                                 f"{t.get('state_bytes_per_building')} state bytes per building, 65,536 buildings: not this run")
     if world == 1 and not args.no_cpu_baseline:

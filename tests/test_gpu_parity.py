@@ -922,6 +922,19 @@ def test_bench_two_ranks_sharing_one_gpu(monkeypatch):
   assert p["n_gpus"] == 2 and p["gathered_returns"] == 8192
 
 
+def test_bench_through_the_public_env_api_costs_the_same():
+  """The headline line steps through BatchedSimulator.step(phases=...) so that HIP events can bracket the
+  sweep kernel; `--through-env-api` times BatchedEnvironment.step() itself (host-side step inputs, sb_step,
+  TimeStep): within 3 % of the phases path."""
+  _need_gpu()
+  common = ["--gpus", "1", "--steps", "20", "--warmup", "30", "--no-cpu-baseline"]
+  a = _run_bench(common)
+  b = _run_bench(common + ["--through-env-api"])
+  assert b["timed_through"] == "BatchedEnvironment.step()" and a["timed_through"].startswith("BatchedSimulator.step")
+  assert abs(b["config"]["mean_sweeps_per_env_step"] - a["config"]["mean_sweeps_per_env_step"]) < 1e-9
+  assert b["ms_per_step"] < 1.03 * a["ms_per_step"], (a["ms_per_step"], b["ms_per_step"])
+
+
 def test_bench_two_gpus_when_the_box_has_them():
   """`bench.py --gpus 2` on a box with two devices: two ranks over RCCL, 131,072 gathered returns, a
   per-GPU rate within 5 % ... of the one-GPU line's (weak scaling: independent shards, one gather)."""
