@@ -128,9 +128,15 @@ def tf_agents_environment(env):
   return TFAgentsBatchedEnv()
 
 
-def gymnasium_vector_env(env):
+def gymnasium_vector_env(env, time_limit_is_truncation: bool = True):
   """-> gymnasium.vector.VectorEnv around ``env`` (next-step autoreset: the step after a terminal one ignores
-  its actions and returns the next episode's first observation).  ImportError without gymnasium."""
+  its actions and returns the next episode's first observation).  ImportError without gymnasium.
+
+  An episode here ends only because its time is up (`num_timesteps_in_episode`, environment.py:1286-1292) --
+  in gymnasium's vocabulary a TRUNCATION: `truncated` is set at the last step and `terminated` stays False, so
+  that a learner keeps bootstrapping from the last observation.  (The reference's own TF-Agents environment
+  ends the episode with discount 0, i.e. as a termination; `time_limit_is_truncation=False` reports it that
+  way: `terminated` set, `truncated` False -- round 3's behaviour.)"""
   import gymnasium as gym
 
   a_spec, o_spec = env.action_spec(), env.observation_spec()
@@ -153,8 +159,9 @@ def gymnasium_vector_env(env):
       a = torch.as_tensor(np.asarray(actions, dtype=np.float32)).to(_device_of(self._env))
       t = self._env.step(a)
       st = t.step_type.cpu().numpy()
-      terminated = st == STEP_LAST
-      return (t.observation.cpu().numpy(), t.reward.cpu().numpy().astype(np.float32), terminated, np.zeros_like(terminated),
+      last = st == STEP_LAST
+      terminated, truncated = (np.zeros_like(last), last) if time_limit_is_truncation else (last, np.zeros_like(last))
+      return (t.observation.cpu().numpy(), t.reward.cpu().numpy().astype(np.float32), terminated, truncated,
               {"step_type": st, "discount": t.discount.cpu().numpy()})
 
     def close(self, **kwargs):

@@ -293,6 +293,9 @@ class HipSimulatorBuilding:
         if dev.device_type == DeviceType.VAV and (v < 0.0 or v > 1.0):
           r.response_type = ActionResponseType.REJECTED_NOT_ENABLED_OR_AVAILABLE
           r.additional_info = "damper_setting must be in [0 ,1]"
+          # a FINITE out-of-range value: anything <= SB_ACTION_KEEP (-inf, -3.4e38) would read as "field not
+          # mentioned" on the device, which would then not reject the step
+          v = -1.0 if v < 0.0 else 2.0
         row[self._action_col[(single.device_id, single.setpoint_name)]] = v
       resp.single_action_responses.append(r)
     self._actions[:] = torch.tensor(row, dtype=torch.float32, device=self._actions.device)

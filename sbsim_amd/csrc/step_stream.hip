@@ -126,7 +126,10 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
         if (has_prev) {
           const int need = min(t0 + kPF, NS) + 63; // column c is published at step c + 63: c + 64 steps completed
           while (__builtin_amdgcn_readfirstlane(*prog_prev) < need) __builtin_amdgcn_s_sleep(1);
-          asm volatile("" ::: "memory");
+          // acquire: the seam reads below must not be hoisted above the spin (the hardware keeps a wavefront's LDS
+          // operations in order; this fence is for the compiler -- the seam values are plain doubles, the
+          // progress word a volatile int, and type-based alias analysis would let one pass the other)
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
 #pragma unroll
         for (int k = 0; k < kPF; ++k) {
@@ -164,7 +167,10 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
           nv = act ? res : nv;
           old = eR;
         }
-        if (lane == 0) *prog_mine = min(t0 + kPF, NW); // steps completed (LDS operations of a wavefront stay in order)
+        // release: every seam value of these steps is written before the progress word says so (for the compiler;
+        // the hardware keeps a wavefront's LDS operations in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) *prog_mine = min(t0 + kPF, NW); // steps completed
       }
       // max |delta| over the building
       double m = wave_max(acc);
