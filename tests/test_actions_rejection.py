@@ -205,4 +205,12 @@ def test_hip_simulator_building_rejections_and_damper_commands():
     zt = b.env.sim.zone_temps()[0].cpu().numpy()
     assert np.abs(zt - g["zone_temp_post"][t]).max() < T_TOL, t
     assert abs(b.last_reward - float(g["reward"][t])) < 1e-6, t
+  # a damper command of -inf: the host says REJECTED and the device must reject the step too (reward -inf,
+  # environment.py:1301-1302) -- the raw value would read as "field not mentioned" there (<= SB_ACTION_KEEP)
+  resp = b.request_action(ba.ActionRequest(timestamp=b.current_timestamp, single_action_requests=[
+      ba.SingleActionRequest("boiler_id", "supply_water_setpoint", 340.0),
+      ba.SingleActionRequest(vav, "supply_air_damper_percentage_command", float("-inf"))]))
+  assert resp.single_action_responses[1].response_type == ba.ActionResponseType.REJECTED_NOT_ENABLED_OR_AVAILABLE
+  b.wait_time()
+  assert float(b.env._reward[0]) == float("-inf")
   b.close()
