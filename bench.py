@@ -33,7 +33,7 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 from sbsim_amd import _ffi, distributed as sd  # noqa: E402
-from sbsim_amd.environment import BatchedEnvironment, SimConfig  # noqa: E402
+from sbsim_amd.environment import BatchedEnvironment, MixedBatchedEnvironment, SimConfig  # noqa: E402
 from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
@@ -241,60 +241,49 @@ MIXED_CLASSES = [("R9", (3, 3), (20, 30)), ("SB2-synth", (8, 5), (12, 14)), ("SB
 def mixed_config(args) -> None:
   """BASELINE.json configs[2] (SURVEY.md 8d "Config 3"): the batch split evenly over three floor-plan
   classes -- R9 (9 zones), "SB2-synth" (8x5 rooms, 40 zones), "SB1-synth" (14x9 rooms, 126 zones, the
-  real SB1's VAV count; SB2 / SB3 do not exist in the reference) -- one handle per class, each on its
-  own HIP stream so that the classes' launches overlap, random setpoint actions.  One JSON line;
-  `roofline` sums the algorithmic bytes of the three sweep kernels over their summed durations."""
+  real SB1's VAV count; SB2 / SB3 do not exist in the reference) -- behind ONE environment
+  (`MixedBatchedEnvironment`: one library handle and one HIP stream per class inside, so that the classes'
+  launches overlap), stepped through its public `step()` with random setpoint actions.  One JSON line;
+  `roofline` sums the algorithmic bytes of the three sweep kernels over their summed durations, each measured
+  with the chip to itself in three rounds after the timed ones."""
   dev = torch.device("cuda", 0)
   torch.cuda.set_device(0)
   B_each, K, W = args.buildings // len(MIXED_CLASSES), args.steps, args.warmup
   N_ALONE = 3
-  classes = []
-  for name, rooms, shape in MIXED_CLASSES:
-    plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-      env = BatchedEnvironment(plan, B_each, device=0, holiday_calendar="us", collect_info=True, num_days_in_episode=3)
-      rs = np.random.RandomState(7)
-      H, Wd = plan.shape
-      t_init = torch.tensor(np.clip(294.0 + rs.randn(B_each), 285.0, 305.0), dtype=torch.float64, device=dev)
-      env.reset()
-      env.sim.reset(temps=t_init[:, None].expand(B_each, H * Wd).contiguous())
-      gen = torch.Generator(device=dev)
-      gen.manual_seed(1234)
-      acts = torch.rand((W + K + N_ALONE, B_each, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
-    check = TwinCheck(env, plan, t_init[:args.check_buildings].cpu().numpy(),
-                      args.check_buildings) if args.check_buildings else None
-    classes.append(dict(name=name, env=env, acts=acts, stream=stream, ev=[], sweeps=0.0, check=check))
+  plans = [FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
+           for _, rooms, shape in MIXED_CLASSES]
+  menv = MixedBatchedEnvironment([(p, B_each) for p in plans], device=0, holiday_calendar="us", collect_info=True,
+                                 num_days_in_episode=3)
+  menv.reset()
+  rs = np.random.RandomState(7)
+  t_init = torch.tensor(np.clip(294.0 + rs.randn(B_each), 285.0, 305.0), dtype=torch.float64, device=dev)
+  checks = []
+  for env, plan in zip(menv.envs, plans):   # every class starts from the same per-building temperatures
+    H, Wd = plan.shape
+    env.sim.reset(temps=t_init[:, None].expand(B_each, H * Wd).contiguous())
+    checks.append(TwinCheck(env, plan, t_init[:args.check_buildings].cpu().numpy(), args.check_buildings)
+                  if args.check_buildings else None)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(1234)
+  acts = torch.rand((W + K + N_ALONE, menv.batch_size, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
   torch.cuda.synchronize(dev)
 
-  def round_(t, timed):
-    for c in classes:
-      with torch.cuda.stream(c["stream"]):
-        env = c["env"]
-        si = env.make_step_in(env.current_simulation_timestamp)
-        a = (c["acts"][t], si, env._obs, env._reward, env._info)
-        env.sim.step(*a, phases=1)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        env.sim.step(*a, phases=2)
-        e1.record()
-        env.sim.step(*a, phases=4)
-        env._prev_thermostat_ts = env._now
-        env._now = env._now + env._step_interval
-        if timed:
-          c["ev"].append((e0, e1))
-        if c["check"]:
-          c["check"].record(si, c["acts"][t])
+  def round_(t):
+    sis = [env.make_step_in(env.current_simulation_timestamp) if c else None for env, c in zip(menv.envs, checks)]
+    menv.step(acts[t])
+    for (lo, hi), c, si in zip(menv.slices, checks, sis):
+      if c:
+        c.record(si, acts[t, lo:hi])
+
+  alone_ms = [[] for _ in menv.envs]
 
   def alone(t):
     """One untimed round with the classes one after the other: a class's sweep kernel with the chip to itself."""
-    for c in classes:
+    for k, (env, stream, (lo, hi)) in enumerate(zip(menv.envs, menv.streams, menv.slices)):
       torch.cuda.synchronize(dev)
-    for c in classes:
-      with torch.cuda.stream(c["stream"]):
-        env = c["env"]
+      with torch.cuda.stream(stream):
         si = env.make_step_in(env.current_simulation_timestamp)
-        a = (c["acts"][t], si, env._obs, env._reward, env._info)
+        a = (acts[t, lo:hi], si, env._obs, env._reward, env._info)
         env.sim.step(*a, phases=1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -303,57 +292,62 @@ def mixed_config(args) -> None:
         env.sim.step(*a, phases=4)
         env._prev_thermostat_ts = env._now
         env._now = env._now + env._step_interval
-        if c["check"]:
-          c["check"].record(si, c["acts"][t])
+        env._step_count += 1
+        if checks[k]:
+          checks[k].record(si, acts[t, lo:hi])
       torch.cuda.synchronize(dev)
-      c.setdefault("alone_ms", []).append(e0.elapsed_time(e1))
+      alone_ms[k].append(e0.elapsed_time(e1))
 
   for t in range(W):
-    round_(t, False)
+    round_(t)
   torch.cuda.synchronize(dev)
+  menv.profile = True
   t0 = time.perf_counter()
   for t in range(W, W + K):
-    round_(t, True)
+    round_(t)
   torch.cuda.synchronize(dev)
   elapsed = time.perf_counter() - t0
-  for t in range(W + K, W + K + N_ALONE):   # after the timed rounds, in the same regime: each class with the chip to itself
+  menv.profile = False
+  for t in range(W + K, W + K + N_ALONE):   # after the timed rounds, in the same regime
     alone(t)
   per_class, alg_bytes, kern_s = {}, 0.0, 0.0
-  for c in classes:
-    env, li = c["env"], c["env"].sim.launch_info
-    ms = float(np.mean([a.elapsed_time(b) for a, b in c["ev"]]))
+  for k, ((name, _, _), env) in enumerate(zip(MIXED_CLASSES, menv.envs)):
+    li = env.sim.launch_info
+    ms_alone = float(np.mean(alone_ms[k]))
     alg = li["algorithmic_bytes_per_env_step"] * env.sim.B
     alg_bytes += alg
-    kern_s += ms * 1e-3
-    per_class[c["name"]] = {
+    kern_s += ms_alone * 1e-3
+    per_class[name] = {
         "grid": list(env.sim.plan.shape), "zones": env.sim.Z, "buildings": env.sim.B,
         "kernel": _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?"),
-        # in the timed rounds the classes' kernels overlap on their streams (a class also waits for CUs);
-        # `alone`: the same kernel with the chip to itself (three rounds after the timed ones, one class after the other)
-        "sweep_kernel_ms": ms, "sweep_kernel_ms_alone": float(np.mean(c["alone_ms"])) if c.get("alone_ms") else None,
+        # in the timed rounds the classes overlap on their streams (a class also waits for CUs): the GPU time of a
+        # class's whole step on its stream; `alone`: its sweep kernel with the chip to itself
+        "step_ms_in_round": float(np.mean([a.elapsed_time(b) for a, b in menv.class_events[k]])),
+        "sweep_kernel_ms_alone": ms_alone,
         "mean_sweeps_per_env_step": float(env.info[:, 4].mean()),
-        "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-        "roofline_frac_alone": (alg / (float(np.mean(c["alone_ms"])) * 1e-3) / 1e9 / HBM_PEAK_GBPS) if c.get("alone_ms") else None,
+        "roofline_frac_alone": alg / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "launch": li}
-    if c["check"]:
-      per_class[c["name"]]["parity_vs_oracle"] = c["check"].verify()
-  zone_updates = sum(c["env"].sim.B * c["env"].sim.Z for c in classes) * K
-  env_steps = sum(c["env"].sim.B for c in classes) * K
+    if checks[k]:
+      per_class[name]["parity_vs_oracle"] = checks[k].verify()
+  zone_updates = sum(env.sim.B * env.sim.Z for env in menv.envs) * K
+  env_steps = menv.batch_size * K
   achieved = alg_bytes / kern_s / 1e9
   print(json.dumps({
       "metric": "zone-updates/sec over three floor-plan classes (mixed zone counts), 1 MI355X",
       "value": zone_updates / elapsed, "unit": "zone-updates/s", "n_gpus": 1, "steps": K, "warmup": W,
       "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
       "dtype": "f64", "data": "synthetic", "env_steps_per_s": env_steps / elapsed,
+      "timed_through": "MixedBatchedEnvironment.step()",
       "config": {"workload": "BASELINE.json configs[2]: %d buildings x 3 floor-plan classes (R9, SB2-synth 40 zones, "
-                             "SB1-synth 126 zones), random setpoint actions, one handle and one HIP stream per class" % B_each,
-                 "classes": per_class},
+                             "SB1-synth 126 zones) behind one MixedBatchedEnvironment (one handle and one HIP stream per "
+                             "class inside), random setpoint actions" % B_each,
+                 "observation_width": menv.observation_spec().shape[0], "classes": per_class},
       "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                   "note": "sum of the three sweep kernels' algorithmic bytes over the sum of their durations "
-                           "(the kernels overlap: wall time per round is ms_per_step)"}}))
-  for c in classes:
-    c["env"].close()
+                   "note": "sum of the three sweep kernels' algorithmic bytes over the sum of their durations, each "
+                           "measured with the chip to itself (in the timed rounds the kernels overlap: wall time per "
+                           "round is ms_per_step)"}}))
+  menv.close()
 
 
 def start_rank(args):

@@ -27,7 +27,7 @@ import ctypes as C
 import dataclasses
 import datetime as dt
 import math
-from typing import Dict, Mapping, Optional, Sequence, Tuple
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -667,19 +667,137 @@ class BatchedEnvironment:
     self.sim.close()
 
 
+class MixedBatchedEnvironment:
+  """One vectorised environment over SEVERAL floor-plan classes (BASELINE.json configs[2]: a batch mixed over
+  floor plans with different zone counts): the same ``reset()`` / ``step(action)`` -> TimeStep contract as
+  ``BatchedEnvironment`` over the concatenated batch.
+
+      env = MixedBatchedEnvironment([(plan_a, 21845), (plan_b, 21845), (plan_c, 21845)], holiday_calendar="us")
+      ts = env.reset()
+      ts = env.step(actions)            # actions [B_total, n_actions] in HBM, buildings in class order
+
+  Inside: one ``BatchedEnvironment`` (one library handle, the sweep kernel the planner picks for that plan)
+  per class, each on its own HIP stream, so that the classes' launches overlap on the chip; ``step`` makes
+  every class stream wait for the caller's stream (the actions) and the caller's stream wait for every class.
+  The classes share the simulator clock and the episode length, so they step and end together.
+
+  Observations: a class's observation row has ``3 * zones + 19`` fields, so rows differ in width.  The
+  mixed observation is ``[B_total, max width]``; a building's row holds its class's fields first (the layout
+  of ``BatchedEnvironment.field_names`` of its class, ``self.envs[k].field_names``) and zeros after
+  ``self.observation_widths[k]``; ``self.class_of_building`` ([B_total] int32 in HBM) and ``self.slices``
+  say which class a building belongs to.  Every keyword argument goes to each class's ``BatchedEnvironment``."""
+
+  def __init__(self, classes: Sequence[Tuple[FloorPlan, int]], device: int = 0, **env_kwargs):
+    if not classes:
+      raise ValueError("MixedBatchedEnvironment needs at least one (floor plan, number of buildings) class")
+    self.device = int(device)
+    self.tdev = torch.device("cuda", self.device)
+    self.envs: List[BatchedEnvironment] = []
+    self.streams: List[torch.cuda.Stream] = []
+    self.slices: List[Tuple[int, int]] = []
+    lo = 0
+    for plan, n in classes:
+      stream = torch.cuda.Stream(device=self.tdev)
+      with torch.cuda.stream(stream):
+        env = BatchedEnvironment(plan, int(n), device=self.device, **env_kwargs)
+      self.envs.append(env)
+      self.streams.append(stream)
+      self.slices.append((lo, lo + env.batch_size))
+      lo += env.batch_size
+    torch.cuda.synchronize(self.tdev)
+    self.batch_size = lo
+    specs = {tuple(e.action_spec().shape) for e in self.envs}
+    if len(specs) != 1 or len({e.steps_per_episode for e in self.envs}) != 1:
+      raise ValueError("the classes of a MixedBatchedEnvironment share the action set and the episode length")
+    self.observation_widths = [e.sim.O for e in self.envs]
+    O = max(self.observation_widths)
+    self._action_spec = self.envs[0].action_spec()
+    self._observation_spec = ArraySpec((O,), np.dtype(np.float32), "observation")
+    self._obs = torch.zeros((self.batch_size, O), dtype=torch.float32, device=self.tdev)
+    self._reward = torch.zeros((self.batch_size,), dtype=torch.float32, device=self.tdev)
+    self._discount = torch.zeros((self.batch_size,), dtype=torch.float32, device=self.tdev)
+    self._step_type = torch.zeros((self.batch_size,), dtype=torch.int32, device=self.tdev)
+    cls = torch.zeros((self.batch_size,), dtype=torch.int32, device=self.tdev)
+    for k, (a, b) in enumerate(self.slices):
+      cls[a:b] = k
+    self.class_of_building = cls
+    self.profile = False          # True: every step records (start, end) HIP events per class on its stream
+    self.class_events: List[List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = [[] for _ in self.envs]
+
+  def action_spec(self) -> ArraySpec:
+    return self._action_spec
+
+  def observation_spec(self) -> ArraySpec:
+    return self._observation_spec
+
+  @property
+  def batched(self) -> bool:
+    return True
+
+  @property
+  def steps_per_episode(self) -> int:
+    return self.envs[0].steps_per_episode
+
+  @property
+  def current_simulation_timestamp(self) -> dt.datetime:
+    return self.envs[0].current_simulation_timestamp
+
+  def _each(self, fn) -> TimeStep:
+    """Runs fn(class index, env) -> TimeStep on every class's stream between two joins with the caller's stream."""
+    cur = torch.cuda.current_stream(self.tdev)
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    for k, (env, stream, (a, b)) in enumerate(zip(self.envs, self.streams, self.slices)):
+      stream.wait_event(ready)
+      with torch.cuda.stream(stream):
+        if self.profile:
+          e0 = torch.cuda.Event(enable_timing=True)
+          e0.record(stream)
+        ts = fn(k, env)
+        if self.profile:
+          e1 = torch.cuda.Event(enable_timing=True)
+          e1.record(stream)
+          self.class_events[k].append((e0, e1))
+        self._obs[a:b, : self.observation_widths[k]].copy_(ts.observation)
+        self._reward[a:b].copy_(ts.reward)
+        self._discount[a:b].copy_(ts.discount)
+        self._step_type[a:b].copy_(ts.step_type)
+        done = torch.cuda.Event()
+        done.record(stream)
+      cur.wait_event(done)
+    return TimeStep(self._step_type, self._reward, self._discount, self._obs)
+
+  def reset(self) -> TimeStep:
+    return self._each(lambda k, env: env.reset())
+
+  def step(self, action: torch.Tensor, rejected: Optional[torch.Tensor] = None) -> TimeStep:
+    """``BatchedEnvironment.step`` for every class (actions / rejected flags of its slice of the batch).  The
+    TimeStep's tensors are this environment's own buffers: the next ``step`` / ``reset`` overwrites them."""
+    if tuple(action.shape) != (self.batch_size,) + tuple(self._action_spec.shape):
+      raise ValueError(f"action must be [{self.batch_size}, {self._action_spec.shape[0]}]")
+    action = action.contiguous()
+    return self._each(lambda k, env: env.step(action[self.slices[k][0]:self.slices[k][1]],
+                                              None if rejected is None else rejected[self.slices[k][0]:self.slices[k][1]]))
+
+  def close(self) -> None:
+    for env in self.envs:
+      env.close()
+
+
 class GymVectorEnv:
   """gymnasium.vector-style view of a ``BatchedEnvironment`` (no gymnasium import needed):
 
       obs, info = venv.reset()
       obs, reward, terminated, truncated, info = venv.step(actions)      # all [B, ...] tensors in HBM
 
-  Every sub-environment shares the simulator clock, so they terminate together: the terminal
-  step of an episode (``environment.py:1366-1368``) returns ``terminated = True`` for all of
-  them, and -- gymnasium's "next-step" autoreset mode -- the following ``step`` ignores its
+  Every sub-environment shares the simulator clock, so they end together: the last step of an
+  episode (``environment.py:1366-1368``: its time is up) returns ``truncated = True`` for all of
+  them (``terminated`` with ``time_limit_is_truncation=False``), and -- gymnasium's "next-step" autoreset mode -- the following ``step`` ignores its
   actions and returns the first observation of the next episode with zero reward."""
 
-  def __init__(self, env: BatchedEnvironment):
+  def __init__(self, env: BatchedEnvironment, time_limit_is_truncation: bool = True):
     self.env = env
+    self.time_limit_is_truncation = bool(time_limit_is_truncation)
     self.num_envs = env.batch_size
     self.single_action_shape = tuple(env.action_spec().shape)
     self.single_observation_shape = tuple(env.observation_spec().shape)
@@ -692,8 +810,10 @@ class GymVectorEnv:
 
   def step(self, actions: torch.Tensor):
     ts = self.env.step(actions)
-    terminated = ts.step_type == STEP_LAST
-    truncated = torch.zeros_like(terminated)
+    # an episode ends only because its time is up: gymnasium's TRUNCATION (a learner keeps bootstrapping);
+    # time_limit_is_truncation=False reports it as a termination, like the reference's discount 0
+    last = ts.step_type == STEP_LAST
+    terminated, truncated = (torch.zeros_like(last), last) if self.time_limit_is_truncation else (last, torch.zeros_like(last))
     return ts.observation, ts.reward, terminated, truncated, {"step_type": ts.step_type, "discount": ts.discount}
 
   def close(self) -> None:

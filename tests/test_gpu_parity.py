@@ -605,13 +605,13 @@ def test_gym_vector_view_autoresets_like_gymnasium():
     obs, rew, term, trunc, info = venv.step(a)
     ts = ref.step(a)
     assert torch.equal(obs, ts.observation) and torch.equal(rew, ts.reward)
-    assert not bool(trunc.any())
-    assert bool(term.all()) == bool((ts.step_type == 2).all()) and bool(term.all()) == bool(term.any())
-    if bool(term.all()):
+    assert not bool(term.any())                     # the episode's time is up: a truncation, never a termination
+    assert bool(trunc.all()) == bool((ts.step_type == 2).all()) and bool(trunc.all()) == bool(trunc.any())
+    if bool(trunc.all()):
       seen_terminal += 1
-      obs2, rew2, term2, _, info2 = venv.step(a)    # next-step autoreset: first observation, zero reward
+      obs2, rew2, term2, trunc2, info2 = venv.step(a)    # next-step autoreset: first observation, zero reward
       ts2 = ref.step(a)
-      assert bool((info2["step_type"] == 0).all()) and float(rew2.abs().max()) == 0.0 and not bool(term2.any())
+      assert bool((info2["step_type"] == 0).all()) and float(rew2.abs().max()) == 0.0 and not bool(term2.any() or trunc2.any())
       assert torch.equal(obs2, ts2.observation)
   assert seen_terminal == 2
   venv.close(); ref.close()
@@ -879,6 +879,43 @@ def _run_bench(args, timeout=600):
   return json.loads(lines[0])
 
 
+def test_mixed_environment_equals_its_classes_stepped_alone():
+  """MixedBatchedEnvironment (one env over several floor-plan classes, BASELINE.json configs[2]): every class's
+  slice of the TimeStep equals what a BatchedEnvironment of that class alone returns for the same actions --
+  observations in the first `observation_widths[k]` columns, zeros after -- over an episode end and the reset
+  that follows; the classes share the clock."""
+  _need_gpu()
+  from sbsim_amd.environment import BatchedEnvironment, MixedBatchedEnvironment
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  plans = [FloorPlan.from_file_input(rectangular_floor_plan(r, sh), Materials.sb1(), 10.0, 300.0)
+           for r, sh in (((3, 3), (20, 30)), ((2, 2), (5, 9)), ((8, 5), (12, 14)))]
+  counts, steps = [5, 7, 3], 4
+  kw = dict(num_days_in_episode=steps * 300.0 / 86400.0, holiday_calendar=None)
+  menv = MixedBatchedEnvironment(list(zip(plans, counts)), **kw)
+  refs = [BatchedEnvironment(p, n, **kw) for p, n in zip(plans, counts)]
+  assert menv.batch_size == 15 and menv.slices == [(0, 5), (5, 12), (12, 15)]
+  assert menv.observation_widths == [r.sim.O for r in refs] and menv.observation_spec().shape == (max(menv.observation_widths),)
+  assert menv.class_of_building.cpu().tolist() == [0] * 5 + [1] * 7 + [2] * 3
+  rs = np.random.RandomState(3)
+
+  def compare(ts, rts):
+    for k, ((lo, hi), r) in enumerate(zip(menv.slices, rts)):
+      w = menv.observation_widths[k]
+      assert torch.equal(ts.observation[lo:hi, :w], r.observation) and not bool(ts.observation[lo:hi, w:].any())
+      assert torch.equal(ts.reward[lo:hi], r.reward) and torch.equal(ts.discount[lo:hi], r.discount)
+      assert torch.equal(ts.step_type[lo:hi], r.step_type)
+
+  compare(menv.reset(), [r.reset() for r in refs])
+  for t in range(2 * steps + 3):                    # two episode ends and the resets that follow
+    a = torch.tensor(rs.uniform(-1, 1, size=(15, 2)).astype(np.float32), device="cuda")
+    compare(menv.step(a), [r.step(a[lo:hi].contiguous()) for (lo, hi), r in zip(menv.slices, refs)])
+  with pytest.raises(ValueError, match="action must be"):
+    menv.step(torch.zeros((14, 2), device="cuda"))
+  menv.close()
+  for r in refs:
+    r.close()
+
+
 def test_bench_mixed_config_line_and_its_twins():
   """`bench.py --config mixed` (BASELINE.json configs[2]) at the full batch, two timed rounds: the JSON line
   parses, names the three classes' kernels, and 64 buildings per class agree with their CPU-oracle twins
@@ -886,10 +923,11 @@ def test_bench_mixed_config_line_and_its_twins():
   _need_gpu()
   d = _run_bench(["--config", "mixed", "--buildings", "65535", "--steps", "2", "--warmup", "1", "--check-buildings", "64"])
   assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "zone-updates/s" and d["value"] > 1e7
+  assert d["timed_through"] == "MixedBatchedEnvironment.step()" and d["config"]["observation_width"] == 3 * 126 + 19
   cl = d["config"]["classes"]
   assert set(cl) == {"R9", "SB2-synth", "SB1-synth"}
   for name, c in cl.items():
-    assert c["buildings"] == 21845 and c["sweep_kernel_ms_alone"] > 0
+    assert c["buildings"] == 21845 and c["sweep_kernel_ms_alone"] > 0 and c["step_ms_in_round"] > 0
     par = c["parity_vs_oracle"]
     assert par["buildings"] == 64 and par["steps"] == 6            # 1 warm-up + 2 timed + 3 one-class-at-a-time rounds
     assert par["sweep_count_mismatches"] == 0 and par["max_abs_dT_zone_K"] < T_TOL, (name, par)
