@@ -1,18 +1,20 @@
 """CPU restatement of the device convection shuffle (TEST INFRASTRUCTURE: only tests/ may import
 this).
 
-Checker for `k_convect` (sbsim_amd/csrc/sbsim_hip.hip).  The random PROCESS is
+Checker for `k_convect` (sbsim_amd/csrc/generators.hip).  The random PROCESS is
 `StochasticConvectionSimulator._shuffle_max_dist` of the reference
 (simulator/stochastic_convection_simulator.py:101-145): every cell of a room starts a swap with
 probability p, its partner is uniform over the room's cells inside the offset window
 (:125-131: dx, dy in [-distance, distance), dx^2 + dy^2 <= distance), the swaps run one after
 the other in uniformly random order (:137-145).  Here the swaps are really applied one after
 the other (the device follows every value through the sequence instead); the draws are the
-device's: Philox4x32-10, key = seed, counter = (global building lo, hi, call number, grid cell),
-word 0 -> inclusion (u = (x >> 8) / 2**24, included unless u > p), word 1 -> partner
-((x * count) >> 32 among the valid offsets in (dx, dy) raster order), word 2 -> order (swaps by
-increasing (x, cell's index in the room)).  The reference draws from Python's global `random`,
-which no counter-based generator reproduces: what is pinned against the reference is the
+device's: a counter-based mixer -- MurmurHash3's 32-bit finaliser -- over (stream, cell, word number):
+stream = conv_stream(seed, global building, call number), word k of the cell with grid index g0 =
+fmix32((stream ^ g0 * 0x9E3779B1) + k * 0x6C8E9CF5); word 0 -> inclusion (u = (x >> 8) / 2**24, included
+unless u > p), word 1 -> order (swaps by increasing ((x >> 12) << 11 | the cell's rank in the room)),
+word 2 -> the partner ((x * count) >> 32 among the valid offsets in (dx, dy) raster order); wide windows:
+words 2, 3, .. -> candidates until one is accepted.  The reference draws from Python's
+global `random`, which no counter-based generator reproduces: what is pinned against the reference is the
 displacement statistics (tests/golden/convection_stats.npz)."""
 from __future__ import annotations
 
@@ -20,16 +22,39 @@ import numpy as np
 
 from oracle.occupancy_oracle import philox4x32_10
 
+M32 = 0xFFFFFFFF
+
+
+def fmix32(h: int) -> int:
+  """MurmurHash3's 32-bit finaliser."""
+  h &= M32
+  h ^= h >> 16; h = (h * 0x85EBCA6B) & M32
+  h ^= h >> 13; h = (h * 0xC2B2AE35) & M32
+  h ^= h >> 16
+  return h
+
+
+def conv_stream(seed: int, gb: int, call: int) -> int:
+  h = fmix32((seed & M32) ^ 0x9E3779B9)
+  h = fmix32(h ^ ((seed >> 32) & M32))
+  h = fmix32(h ^ (gb & M32))
+  h = fmix32(h ^ ((gb >> 32) & M32))
+  return fmix32(h ^ (call & M32))
+
+
+def conv_word(stream: int, g0: int, k: int) -> int:
+  return fmix32(((stream ^ ((g0 * 0x9E3779B1) & M32)) + k * 0x6C8E9CF5) & M32)
+
 
 def offsets(distance: int):
   return [(dx, dy) for dx in range(-distance, distance) for dy in range(-distance, distance)
           if dx * dx + dy * dy <= distance]
 
 
-WIDE_MAX_BLOCKS = 4095   # Philox blocks (four candidates each) a wide-window draw may use: the counter word has 12 bits for it
+CONV_MAX_TRIES = 1 << 14   # partner candidates of a wide-window draw (words 2 .. CONV_MAX_TRIES - 1)
 
 
-def wide_partner(gb: int, call: int, g0: int, seed: int, distance: int, accept, ranked=None, W: int = 0):
+def wide_partner(stream: int, g0: int, distance: int, accept, ranked=None, W: int = 0):
   """The device's partner choice for windows of more than 64 offsets (distance >= 20; distance = -1
   with p < 1 is the reference's 1000: stochastic_convection_simulator.py:108-109): rejection sampling,
   uniform over the reference's candidate list (:122-131; the window [-d, d) does not cut the disc:
@@ -37,30 +62,25 @@ def wide_partner(gb: int, call: int, g0: int, seed: int, distance: int, accept, 
   a cell of the room, uniform by its rank in raster order (`ranked`: the room's grid indices, sorted), kept
   when dx^2 + dy^2 <= distance -> its grid index.  Otherwise: (dx, dy) uniform in [-R, R]^2, kept when inside
   the disc and in the room (`accept(dx, dy)` -> the partner's index in the room, or -1).  The cell itself is a
-  candidate, so a draw is accepted sooner or later (after WIDE_MAX_BLOCKS blocks the cell stays: None).
-  Draws: Philox blocks with counter word 3 = g0 | (block + 1) << 20, each word one candidate."""
-  M = 0xFFFFFFFF
+  candidate, so a draw is accepted sooner or later (after CONV_MAX_TRIES words the cell stays: None)."""
   R = int(np.floor(np.sqrt(distance)))
-  one = lambda v: np.array([v], dtype=np.uint64)
   by_rank = ranked is not None and len(ranked) < (2 * R + 1) ** 2
   x0, y0 = divmod(g0, W) if by_rank else (0, 0)
-  for blk in range(WIDE_MAX_BLOCKS):
-    w = philox4x32_10(one(gb & M), one(gb >> 32), one(call), one(g0 | ((blk + 1) << 20)), seed & M, (seed >> 32) & M)
-    for k in range(4):
-      x = int(w[k][0])
-      if by_rank:
-        g = int(ranked[(x * len(ranked)) >> 32])
-        xx, yy = divmod(g, W)
-        if (xx - x0) ** 2 + (yy - y0) ** 2 <= distance:
-          return ("cell", g)
-        continue
-      dx = (((x & 0xFFFF) * (2 * R + 1)) >> 16) - R
-      dy = (((x >> 16) * (2 * R + 1)) >> 16) - R
-      if dx * dx + dy * dy > distance:
-        continue
-      j = accept(dx, dy)
-      if j >= 0:
-        return ("index", j)
+  for k in range(2, CONV_MAX_TRIES):
+    x = conv_word(stream, g0, k)
+    if by_rank:
+      g = int(ranked[(x * len(ranked)) >> 32])
+      xx, yy = divmod(g, W)
+      if (xx - x0) ** 2 + (yy - y0) ** 2 <= distance:
+        return ("cell", g)
+      continue
+    dx = (((x & 0xFFFF) * (2 * R + 1)) >> 16) - R
+    dy = (((x >> 16) * (2 * R + 1)) >> 16) - R
+    if dx * dx + dy * dy > distance:
+      continue
+    j = accept(dx, dy)
+    if j >= 0:
+      return ("index", j)
   return None
 
 
@@ -114,31 +134,30 @@ class ConvectionOracle:
     cells = self.zones[z]
     gb = self.first + b
     n = len(cells)
-    w = philox4x32_10(np.full(n, gb & 0xFFFFFFFF), np.full(n, gb >> 32), np.full(n, call), cells,
-                      self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
-    u = (w[0] >> np.uint64(8)).astype(np.float64) / 16777216.0
+    stream = conv_stream(self.seed, gb, call)
+    rank = np.empty(n, dtype=np.int64)
+    rank[np.argsort(cells, kind="stable")] = np.arange(n)     # the cell's rank in raster order
     seq = []
     for i in range(n):
-      if u[i] > self.p:
+      g0 = int(cells[i])
+      u = (conv_word(stream, g0, 0) >> 8) / 16777216.0
+      if u > self.p:
         continue
-      x, y = divmod(int(cells[i]), self.W)
+      x, y = divmod(g0, self.W)
+
+      def accept(dx, dy, x=x, y=y):
+        xx, yy = x + dx, y + dy
+        if 0 <= xx < self.H and 0 <= yy < self.W and self.room[xx * self.W + yy] == z:
+          return int(self.local[xx * self.W + yy])
+        return -1
       if self.off is None:   # more than 64 offsets: rejection sampling (the device's wide path)
-        def accept(dx, dy, x=x, y=y):
-          xx, yy = x + dx, y + dy
-          if 0 <= xx < self.H and 0 <= yy < self.W and self.room[xx * self.W + yy] == z:
-            return int(self.local[xx * self.W + yy])
-          return -1
-        hit = wide_partner(gb, call, int(cells[i]), self.seed, self.distance, accept, ranked=self.ranked[z], W=self.W)
+        hit = wide_partner(stream, g0, self.distance, accept, ranked=self.ranked[z], W=self.W)
         other = i if hit is None else (int(self.local[hit[1]]) if hit[0] == "cell" else hit[1])
-      else:
-        cand = []
-        for dx, dy in self.off:
-          xx, yy = x + dx, y + dy
-          if 0 <= xx < self.H and 0 <= yy < self.W and self.room[xx * self.W + yy] == z:
-            cand.append(int(self.local[xx * self.W + yy]))
-        other = cand[(int(w[1][i]) * len(cand)) >> 32]
+      else:                  # uniform over the valid offsets, in (dx, dy) raster order ((0, 0) always is one)
+        cand = [j for j in (accept(dx, dy) for dx, dy in self.off) if j >= 0]
+        other = cand[(conv_word(stream, g0, 2) * len(cand)) >> 32]
       if other != i:
-        seq.append((int(w[2][i]), i, other))
+        seq.append(((((conv_word(stream, g0, 1) >> 12) << 11) | int(rank[i])) + 1, i, other))
     seq.sort()
     return [(i, o) for _, i, o in seq]
 

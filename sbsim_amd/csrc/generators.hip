@@ -24,23 +24,6 @@ __device__ inline void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
   }
 }
 
-// Position of the k-th (0-based) set bit of m (k < popcount(m)): halving by population counts, no
-// lane-divergent loop.
-__device__ inline int kth_set_bit(unsigned long long m, int k) {
-  int pos = 0;
-  uint32_t w = (uint32_t)m;
-  int c = __popc(w);
-  if (k >= c) { k -= c; pos = 32; w = (uint32_t)(m >> 32); }
-#pragma unroll
-  for (int half = 16; half >= 1; half >>= 1) {
-    const uint32_t lo = w & ((1u << half) - 1u);
-    c = __popc(lo);
-    if (k >= c) { k -= c; pos += half; w >>= half; }
-    else w = lo;
-  }
-  return pos;
-}
-
 struct OccArgs {
   uint32_t *state; // [B][Z]: bit i = occupant i of the zone is at WORK
   int B, Z, n_occ, hour, workday, e_arr, l_arr, e_dep;
@@ -108,6 +91,8 @@ struct ConvArgs {
   // the partner by rejection sampling inside the disc (oracle/convection_oracle.py wide_partner)
   int wide, wide_r, wide_d, H, transposed;
   const short *room; // [N] the cell's room in the handle's grid (-1: none)
+  const unsigned short *partner; // [cells][pw]: a cell's valid offsets, in table order, as indices of the target cells in the room's list
+  int pw;
   const int *by_rank; // by_rank[zone_off[z] + r]: index (in the zone's cell list) of the room's r-th cell in the CALLER's raster order
   double p;
   uint64_t seed;
@@ -116,7 +101,6 @@ struct ConvArgs {
 };
 
 constexpr int kConvMaxThreads = 512, kConvMaxPerLane = 8;
-constexpr int kWideMaxBlocks = 4095; // Philox blocks of four candidates a wide-window draw may use (the counter word has 12 bits for it)
 
 // The whole-room shuffle (distance = -1, p = 1: stochastic_convection_simulator.py:78-99,
 // _shuffle_no_max_dist): the values of a room's cells are permuted uniformly at random
@@ -138,12 +122,32 @@ __host__ __device__ inline uint32_t perm_apply(const PermKeys &K, uint32_t x, ui
 }
 constexpr int kConvMaxRoom = 2047; // a cell's index in its room fits 11 bits next to the 20-bit grid index
 
-// A cell's own swap in LDS, one 16-byte read per visit: the random key of its time stamp; the
-// cell's grid index (ties, low 20 bits) and the other cell of the swap (bits 20..30; itself: no
-// swap); the next swap that chose the same cell as this one (list link, 0xffff: end).
-struct __attribute__((aligned(16))) ConvRec {
-  uint32_t key, tie_other, nxt, pad;
-};
+// The shuffle's random numbers: a counter-based mixer -- MurmurHash3's 32-bit finaliser over (stream, cell,
+// word number) -- an eighth of Philox4x32-10's instructions (which was a quarter of this kernel's).  stream:
+// (seed, global building, call number) folded once per building; word k of the cell with index g0 in the
+// CALLER's grid: fmix32((stream ^ g0 * 0x9E3779B1) + k * 0x6C8E9CF5).  Word 0 -> inclusion (u = (x >> 8) / 2^24,
+// included unless u > p), word 1 -> the swap's time stamp (its top 20 bits; ties by the cell's rank in the
+// room), words 2.. -> partner candidates until one is accepted.  Known answers: tests/test_convection.py;
+// restated in oracle/convection_oracle.py.  (Occupancy and the whole-room permutation keep Philox.)
+__host__ __device__ inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__host__ __device__ inline uint32_t conv_stream(uint64_t seed, uint64_t gb, uint32_t call) {
+  uint32_t h = fmix32((uint32_t)seed ^ 0x9E3779B9u);
+  h = fmix32(h ^ (uint32_t)(seed >> 32));
+  h = fmix32(h ^ (uint32_t)gb);
+  h = fmix32(h ^ (uint32_t)(gb >> 32));
+  return fmix32(h ^ call);
+}
+__host__ __device__ inline uint32_t conv_word(uint32_t cell_key, uint32_t k) { return fmix32(cell_key + k * 0x6C8E9CF5u); }
+
+// A cell's own swap in LDS, 8 bytes: its time stamp ((top 20 bits of word 1) << 11 | the cell's rank in the
+// room) + 1 -- 0: the cell starts no swap; unique within a room, so the order of the swaps is total and does not
+// depend on the state layout -- and the swap's other cell (low 16 bits) with the next swap that chose the same
+// cell as this one (high 16 bits: a list link, 0xffff: end).  head[c]: the first swap that chose cell c.
+constexpr uint32_t kConvEnd = 0xffffu;
+constexpr int kConvMaxTries = 1 << 14; // partner candidates of a wide-window draw (the cell itself is one: accepted sooner or later)
 
 // Q: cells per lane; the workgroup has ceil(largest room / Q) lanes rounded up to a wavefront.
 // Room-major: the lane keeps its cells' table entries in registers while the workgroup walks
@@ -152,83 +156,86 @@ template <int Q>
 __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
   const int kConvThreads = blockDim.x;
   extern __shared__ __attribute__((aligned(16))) unsigned long long conv_lds[];
-  ConvRec *rec = (ConvRec *)conv_lds;            // [max_room]
+  uint2 *rec = (uint2 *)conv_lds;                // [max_room] {stamp, other | next << 16}
   double *vout = (double *)(rec + o.max_room);   // [max_room] the value that ends in this cell
-  int *head = (int *)(vout + o.max_room);        // [max_room] first swap that chose this cell (-1: none)
+  uint32_t *head = (uint32_t *)(vout + o.max_room); // [max_room] first swap that chose this cell (kConvEnd: none)
   __shared__ int soff[64];                       // the offset table as steps in the handle's grid
   const int tid = threadIdx.x;
   if (tid < 64) soff[tid] = tid < o.n_off ? o.off[tid] : 0;
   __syncthreads();
   for (int z = 0; z < o.Z; ++z) {
     const int c0 = o.zone_off[z], n = o.zone_off[z + 1] - c0;
-    ConvCell cc[Q];
+    // the lane's cells: what every building needs of them, in registers (the rest of a ConvCell -- its index in the
+    // handle's grid -- only the wide-window path reads, from memory: eight waves per SIMD need <= 64 registers)
+    int c_g0[Q], c_sidx[Q], c_rank[Q], c_cnt[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const int i = tid + q * kConvThreads;
-      cc[q] = o.cells[c0 + (i < n ? i : 0)];
+      const ConvCell c = o.cells[c0 + (i < n ? i : 0)];
+      c_g0[q] = c.g0; c_sidx[q] = c.sidx; c_rank[q] = c.pad; c_cnt[q] = __popcll(c.mask);
     }
+    for (int i = tid; i < n; i += kConvThreads) head[i] = kConvEnd; // (re-armed with every building's store phase)
+    __syncthreads();
     for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
       double *st = o.temp + (size_t)b * o.stride;
-      const unsigned long long gb = (unsigned long long)(o.first_building + b);
-      for (int i = tid; i < n; i += kConvThreads) head[i] = -1;
-      __syncthreads();
+      const uint32_t stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call);
       double val[Q];
+      int oth[Q];
+      uint32_t stamp[Q];
+      // the draws first -- the partner is a table read (L1 / L2): the Q reads of a lane are in flight together
+      // -- then the records and the list links (LDS atomics)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int i = tid + q * kConvThreads;
+        oth[q] = i;
+        stamp[q] = 0;
+        if (i < n) {
+          val[q] = st[c_sidx[q]];
+          const uint32_t key = stream ^ ((uint32_t)c_g0[q] * 0x9E3779B1u);
+          const double u = (double)(conv_word(key, 0) >> 8) * (1.0 / 16777216.0);
+          int other = i;
+          if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table: the partner by rejection --
+            // uniform over the reference's candidate list (:122-131; the cell itself is a candidate)
+            const int span = 2 * o.wide_r + 1, W0 = o.transposed ? o.H : o.W; // W0: row length of the caller's grid
+            if (n < span * span) { // the room has fewer cells than the window's box: a cell of the room (by rank), kept when inside the disc
+              const int x0 = c_g0[q] / W0, y0 = c_g0[q] - x0 * W0;
+              for (int k = 2; k < kConvMaxTries; ++k) {
+                const int j = o.by_rank[c0 + (int)(((unsigned long long)conv_word(key, (uint32_t)k) * (unsigned long long)n) >> 32)];
+                const int gj = o.cells[c0 + j].g0, dx = gj / W0 - x0, dy = gj - (gj / W0) * W0 - y0;
+                if (dx * dx + dy * dy <= o.wide_d) { other = j; break; }
+              }
+            } else { // a square of the box, kept when inside the disc and in the room
+              const int gh = o.cells[c0 + i].gh, xh = gh / o.W, yh = gh - xh * o.W;
+              for (int k = 2; k < kConvMaxTries; ++k) {
+                const uint32_t w = conv_word(key, (uint32_t)k);
+                const int dx = (int)(((w & 0xffffu) * (uint32_t)span) >> 16) - o.wide_r;
+                const int dy = (int)(((w >> 16) * (uint32_t)span) >> 16) - o.wide_r;
+                const int hx = xh + (o.transposed ? dy : dx), hy = yh + (o.transposed ? dx : dy);
+                if (dx * dx + dy * dy <= o.wide_d && hx >= 0 && hx < o.H && hy >= 0 && hy < o.W && (int)o.room[hx * o.W + hy] == z) {
+                  other = o.local[hx * o.W + hy];
+                  break;
+                }
+              }
+            }
+          } else if (!(u > o.p)) { // :119: uniform over the room's cells inside the offset window -- the cell's own
+            // partner list (the valid offsets in (dx, dy) raster order, as list indices; built by sb_convection_attach)
+            const int cnt = c_cnt[q];
+            const int pick = (int)(((unsigned long long)conv_word(key, 2) * (unsigned long long)cnt) >> 32);
+            other = (int)o.partner[(size_t)(c0 + i) * (size_t)o.pw + (size_t)pick];
+          }
+          oth[q] = other;
+          stamp[q] = (((conv_word(key, 1) >> 12) << 11) | (uint32_t)c_rank[q]) + 1u; // pad: the cell's rank
+        }
+      }
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
         if (i < n) {
-          val[q] = st[cc[q].sidx];
-          uint32_t c[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc[q].g0};
-          philox4x32_10(c, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
-          const double u = (double)(c[0] >> 8) * (1.0 / 16777216.0);
-          int other = i;
-          if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table: the partner by rejection --
-            // uniform over the reference's candidate list (:122-131; the cell itself is a candidate, so a draw is
-            // accepted sooner or later; after kWideMaxBlocks Philox blocks -- never, for a room that is not a
-            // single cell of a 2047-cell comb -- the cell stays)
-            const int span = 2 * o.wide_r + 1, W0 = o.transposed ? o.H : o.W; // W0: row length of the caller's grid
-            bool found = false;
-            if (n < span * span) { // the room has fewer cells than the window's box: a cell of the room (by rank), kept when inside the disc
-              const int x0 = cc[q].g0 / W0, y0 = cc[q].g0 - x0 * W0;
-              for (int blk = 0; blk < kWideMaxBlocks && !found; ++blk) {
-                uint32_t t[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc[q].g0 | ((uint32_t)(blk + 1) << 20)};
-                philox4x32_10(t, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const int j = o.by_rank[c0 + (int)(((unsigned long long)t[k] * (unsigned long long)n) >> 32)];
-                  const int gj = o.cells[c0 + j].g0, dx = gj / W0 - x0, dy = gj - (gj / W0) * W0 - y0;
-                  if (!found && dx * dx + dy * dy <= o.wide_d) { other = j; found = true; }
-                }
-              }
-            } else { // a square of the box, kept when inside the disc and in the room
-              const int xh = cc[q].gh / o.W, yh = cc[q].gh - xh * o.W;
-              for (int blk = 0; blk < kWideMaxBlocks && !found; ++blk) {
-                uint32_t t[4] = {(uint32_t)gb, (uint32_t)(gb >> 32), o.call, (uint32_t)cc[q].g0 | ((uint32_t)(blk + 1) << 20)};
-                philox4x32_10(t, (uint32_t)o.seed, (uint32_t)(o.seed >> 32));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const int dx = (int)(((t[k] & 0xffffu) * (uint32_t)span) >> 16) - o.wide_r;
-                  const int dy = (int)(((t[k] >> 16) * (uint32_t)span) >> 16) - o.wide_r;
-                  const int hx = xh + (o.transposed ? dy : dx), hy = yh + (o.transposed ? dx : dy);
-                  if (!found && dx * dx + dy * dy <= o.wide_d && hx >= 0 && hx < o.H && hy >= 0 && hy < o.W &&
-                      (int)o.room[hx * o.W + hy] == z) {
-                    other = o.local[hx * o.W + hy];
-                    found = true;
-                  }
-                }
-              }
-            }
-          } else if (!(u > o.p)) { // :119
-            const int cnt = __popcll(cc[q].mask);
-            int pick = (int)(((unsigned long long)c[1] * (unsigned long long)cnt) >> 32); // uniform in [0, cnt)
-            const int k = kth_set_bit(cc[q].mask, pick);
-            other = o.local[cc[q].gh + soff[k]]; // offset k as a step in the handle's grid
-          }
-          ConvRec r;
-          r.key = c[2];
-          r.tie_other = (uint32_t)cc[q].g0 | ((uint32_t)other << 20);
-          r.nxt = other != i ? (uint32_t)atomicExch(&head[other], i) & 0xffffu : 0xffffu;
-          r.pad = 0;
+          const int other = oth[q];
+          uint2 r;
+          r.x = other != i ? stamp[q] : 0u;
+          const uint32_t nxt = other != i ? atomicExch(&head[other], (uint32_t)i) : kConvEnd;
+          r.y = (uint32_t)other | (nxt << 16);
           rec[i] = r;
         }
       }
@@ -236,26 +243,25 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
-        if (i < n) {
-          int pos = i;
-          unsigned long long t = 0; // time stamps: (key << 20 | grid index) + 1, ties in raster order of the caller's grid
-          for (;;) {
-            const ConvRec own = rec[pos];
-            int j = head[pos];
-            unsigned long long best = ~0ull;
-            int to = -1;
-            const int own_other = (int)(own.tie_other >> 20);
-            const unsigned long long own_t = (((unsigned long long)own.key << 20) | (own.tie_other & 0xfffffu)) + 1ull;
-            if (own_other != pos && own_t > t) { best = own_t; to = own_other; }
-            while (j >= 0) { // the swaps that chose this cell
-              const ConvRec rj = rec[j];
-              const unsigned long long tj = (((unsigned long long)rj.key << 20) | (rj.tie_other & 0xfffffu)) + 1ull;
-              if (tj > t && tj < best) { best = tj; to = j; }
-              j = rj.nxt == 0xffffu ? -1 : (int)rj.nxt;
+        if (i < n) { // follow the value through the swaps that touch the cell it sits in
+          int pos = i, to = -1;
+          uint32_t t = 0, best = 0xffffffffu;
+          uint2 R = rec[pos];
+          uint32_t j = head[pos];
+          if (R.x > t) { best = R.x; to = (int)(R.y & 0xffffu); }
+          for (;;) { // (one loop over hops and list nodes alike, and a rejection loop over the offsets instead of the
+            // partner list, were both slower: scalar branch overhead, lanes waiting for the longest loop)
+            while (j != kConvEnd) { // the swaps that chose this cell
+              const uint2 N = rec[j];
+              if (N.x > t && N.x < best) { best = N.x; to = (int)j; }
+              j = N.y >> 16;
             }
             if (to < 0) break;
-            t = best;
-            pos = to;
+            t = best; pos = to;    // the earliest later swap moves the value
+            R = rec[pos];
+            j = head[pos];
+            best = 0xffffffffu; to = -1;
+            if (R.x > t) { best = R.x; to = (int)(R.y & 0xffffu); }
           }
           vout[pos] = val[q];
         }
@@ -264,7 +270,10 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
-        if (i < n) st[cc[q].sidx] = vout[i];
+        if (i < n) {
+          st[c_sidx[q]] = vout[i];
+          head[i] = kConvEnd; // for the next building (the follow phase is over: every lane is past the barrier above)
+        }
       }
       __syncthreads();
     }
@@ -407,6 +416,8 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   for (int z = 0; z < d.Z; ++z)
     for (int i = h->h_zone_off[z]; i < h->h_zone_off[z + 1]; ++i) room[h->h_zone_cells[i]] = z;
   std::vector<ConvCell> cells(h->h_zone_cells.size());
+  const int pw = wide ? 1 : (int)((offd.size() + 1) & ~(size_t)1);
+  std::vector<unsigned short> partner(h->h_zone_cells.size() * (size_t)pw, 0);
   std::vector<int> by_rank(h->h_zone_cells.size(), 0);
   int max_room = 1;
   for (int z = 0; z < d.Z; ++z) {
@@ -436,6 +447,16 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   }
   if (max_room > kConvMaxRoom)
     return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: a room has more than 2047 cells");
+  if (!wide) // every cell's partner list: the targets of its valid offsets, in table order, as list indices
+    for (int z = 0; z < d.Z; ++z) {
+      const int c0 = h->h_zone_off[z], n = h->h_zone_off[z + 1] - c0;
+      for (int i = 0; i < n; ++i) {
+        const ConvCell &c = cells[(size_t)c0 + i];
+        int cnt = 0;
+        for (size_t k = 0; k < offd.size(); ++k)
+          if ((c.mask >> k) & 1ull) partner[((size_t)c0 + i) * pw + cnt++] = (unsigned short)local[c.gh + offd[k]];
+      }
+    }
   {
     std::vector<short> room16(room.size());
     for (size_t i = 0; i < room.size(); ++i) room16[i] = (short)room[i];
@@ -454,6 +475,9 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   if ((rc = upload(h->conv_off, offd.data(), offd.size())) != SB_OK) return rc;
   if ((rc = upload(h->conv_cells, cells.data(), cells.size())) != SB_OK) return rc;
   if ((rc = upload(h->conv_by_rank, by_rank.data(), by_rank.size())) != SB_OK) return rc;
+  if (h->conv_partner.p) { (void)hipFree(h->conv_partner.p); h->conv_partner.p = nullptr; }
+  if ((rc = upload(h->conv_partner, partner.data(), partner.size())) != SB_OK) return rc;
+  h->conv_pw = pw;
   h->conv_whole_room = whole_room;
   h->conv_p = p; h->conv_n_off = (int)offd.size(); h->conv_max_room = max_room;
   h->conv_seed = seed; h->conv_first = first_building; h->conv_calls = 0;
@@ -481,11 +505,13 @@ int sb_launch_convection(sb_handle *h, hipStream_t stream) {
   o.p = h->conv_p; o.seed = h->conv_seed; o.first_building = h->conv_first; o.call = h->conv_calls++;
   o.wide = h->conv_wide ? 1 : 0; o.wide_d = h->conv_wide_d; o.wide_r = (int)std::floor(std::sqrt((double)h->conv_wide_d));
   o.H = d.H; o.transposed = h->conv_transposed ? 1 : 0; o.room = h->conv_room.p; o.by_rank = h->conv_by_rank.p;
-  const size_t lds = (size_t)o.max_room * (16 + 8 + 4);
+  o.partner = h->conv_partner.p; o.pw = h->conv_pw;
+  const size_t lds = (size_t)o.max_room * (8 + 8 + 4);
   // cells per lane: workgroups of about 256 lanes; the grid is exactly what is resident at once
   // (the runtime's occupancy for this instantiation), so that every workgroup gets the same number
   // of buildings and there is no second round
   int q = std::max(1, (o.max_room + 255) / 256);
+  if (const char *e = getenv("SBSIM_DEBUG_CONV_Q")) q = std::max(1, atoi(e)); // developer knob: cells per lane (too few for the largest room: the launch fails below)
   if (q > kConvMaxPerLane) q = kConvMaxPerLane;
   const int threads = ((o.max_room + q - 1) / q + 63) / 64 * 64;
   if (threads > kConvMaxThreads) return fail(SB_ERR_UNSUPPORTED, "convection: room too large for one workgroup");

@@ -106,6 +106,8 @@ struct sb_handle {
   int conv_wide_d = 0;
   DevBuf<short> conv_room;          // per grid cell: its room (-1: none)
   DevBuf<ConvCell> conv_cells;
+  DevBuf<unsigned short> conv_partner; // per room cell: its valid offsets' target cells (list indices), conv_pw entries per cell
+  int conv_pw = 1;
   double conv_p = 0.0;
   int conv_n_off = 0, conv_max_room = 0;
   uint64_t conv_seed = 0;

@@ -25,6 +25,24 @@ def _stats(grids, H, W):
   return hist / inner.sum(), fixed, msd
 
 
+KAT_WORDS = [3190747415, 3427320923, 4229512302]   # conv_word(conv_stream(4242, 1000, 0), 777, 0..2)
+
+
+def test_mixer_known_answers():
+  """The shuffle's generator (generators.hip fmix32 / conv_stream / conv_word): MurmurHash3's finaliser --
+  its published test values -- and the composition the kernel uses, pinned here so that the device, which is
+  compared with this restatement cell for cell, cannot drift with it."""
+  from oracle.convection_oracle import conv_stream, conv_word, fmix32
+  assert fmix32(0) == 0 and fmix32(1) == 0x514E28B7 and fmix32(0xFFFFFFFF) == 0x81F16F39   # MurmurHash3 fmix32
+  s = conv_stream(4242, 1000, 0)
+  assert s == conv_stream(4242, 1000, 0) and s != conv_stream(4242, 1001, 0) and s != conv_stream(4242, 1000, 1)
+  assert conv_stream(0x1_0000_0000 + 4242, 1000, 0) != s                                # the seed's high word counts
+  assert [conv_word(s, 777, k) for k in range(3)] == KAT_WORDS
+  # uniformity of the top bits over cells and words (a smoke test, not a battery): 4,096 draws into 16 bins
+  draws = np.array([conv_word(s, g, k) >> 28 for g in range(1024) for k in range(4)])
+  assert np.abs(np.bincount(draws, minlength=16) - 256).max() < 70
+
+
 def test_offset_window_is_the_reference_one():
   """stochastic_convection_simulator.py:125-131 with distance = 5: squared distance <= 5."""
   off = offsets(5)
