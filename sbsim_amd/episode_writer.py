@@ -115,11 +115,22 @@ class EpisodeWriter:
   def write_reward_response(self, reward_response: bytes, timestamp) -> None:
     self._append(REWARD_RESPONSE_PREFIX, timestamp, reward_response)
 
+  def write_building_image(self, base64_img: bytes, timestamp) -> None:
+    """utils/controller_writer.py:65-71: one CSV row [timestamp.timestamp(), the image] appended to
+    building_images.csv (utils/constants.py:54) with the csv module's default dialect, as the reference does."""
+    import csv
+    import os
+    ts = host_inputs.as_datetime(timestamp)
+    seconds = ts.timestamp() if ts.tzinfo else ts.replace(tzinfo=dt.timezone.utc).timestamp()  # pd.Timestamp.timestamp(): naive = UTC
+    with open(os.path.join(self._dir, BUILDING_IMAGE_CSV_FILE), "a") as fh:
+      csv.writer(fh).writerow([seconds, base64_img])
+
 
 # DeviceInfo.DeviceType / ValueType, ZoneInfo.ZoneType (proto/smart_control_building.proto)
 DEVICE_TYPES = dict(UNDEFINED=0, FAN=1, PMP=2, FCU=3, VAV=4, DH=5, AHU=6, BLR=7, OTHER=23)
 VALUE_CONTINUOUS, ZONE_TYPE_ROOM = 1, 1
 DEVICE_INFO_PREFIX, ZONE_INFO_PREFIX = "device_info", "zone_info"   # utils/constants.py:57-58
+BUILDING_IMAGE_CSV_FILE = "building_images.csv"                       # utils/constants.py:54
 
 
 def _ints(a):

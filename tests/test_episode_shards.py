@@ -192,3 +192,14 @@ def test_normalization_info_records(tmp_path):
   path = str(tmp_path / ew.NORMALIZATION_FILENAME)
   ew.write_records(path, [v0, v1])
   assert open(path, "rb").read() == g["shard_normalization_info"].tobytes()
+
+
+def test_building_image_rows_are_the_reference_writers(tmp_path):
+  """utils/controller_writer.py:65-71 `write_building_image`: rows of building_images.csv.  The expected text is
+  what the reference's own ProtoWriter wrote for these two calls (a naive timestamp counts as UTC, the image's
+  bytes go through csv as their repr), run in the build container through oracle/refshim."""
+  w = EpisodeWriter(str(tmp_path))
+  w.write_building_image(b"aGVsbG8=", dt.datetime(2023, 7, 6, 7, 5, 0))
+  w.write_building_image(b"d29ybGQ=", dt.datetime(2023, 7, 6, 8, 5, 0, tzinfo=UTC))
+  with open(os.path.join(str(tmp_path), "building_images.csv")) as fh:
+    assert fh.read() == "1688627100.0,b'aGVsbG8='\n1688630700.0,b'd29ybGQ='\n"
