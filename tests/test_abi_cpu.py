@@ -72,14 +72,16 @@ def test_plan_info_picks_the_step_kernel_without_a_gpu():
   assert rows["waves_per_workgroup"] == 4 and rows["workgroups"] == 256 and rows["lds_bytes_per_workgroup"] <= 160 * 1024
   rc, cols = _plan_info(r9.transposed())
   assert rc == 0 and cols["path"] == 1 and cols["waves_per_building"] == 1 and cols["kernel"] == 4   # k_sweep_two
-  assert cols["sweep_steps"] == 76 + 48 - 1            # step_two.hip: 66 columns -> 76 slots, 96 rows -> 48 lanes
-  assert 2 * ((cols["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024   # two buildings per CU
+  # step_two.hip: 66 columns -> 76 slots; a rectangular plan's cells are two-coefficient cells, so the rows are
+  # shifted by one (a pad row above row 0): 96 rows -> 49 lanes; most of A streams from L2: four buildings per CU
+  assert cols["sweep_steps"] == 76 + 49 - 1
+  assert 4 * ((cols["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
   assert cols["algorithmic_bytes_per_env_step"] == 53764
   sb1 = FloorPlan.from_file_input(rectangular_floor_plan((14, 9), (8, 7)), Materials.sb1(), 10.0, 300.0)
   rc, big = _plan_info(sb1)
   assert rc == 0 and big["path"] == 1 and big["waves_per_building"] == 1 and big["kernel"] == 4
-  assert big["sweep_steps"] == 76 + 64 - 1 + 4         # 129 x 75 inside the ring: 64 lanes + one tail row
-  assert 2 * ((big["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
+  assert big["sweep_steps"] == 76 + 64 - 1 + 8         # 129 x 75 inside the ring: rows -1 .. 126 on 64 lanes + two tail rows
+  assert 4 * ((big["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
   small = FloorPlan.from_file_input(rectangular_floor_plan((1, 2), (6, 8)), Materials.sb1(), 10.0, 300.0)
   rc, one = _plan_info(small)
   assert rc == 0 and one["path"] == 1 and one["waves_per_building"] == 1 and one["kernel"] == 1

@@ -151,9 +151,15 @@ def test_gymnasium_adapter_autoresets_at_the_next_step(monkeypatch):
   obs, rew, term, trunc, info = venv.step(np.zeros((2, 2), np.float32))
   assert not term.any() and not trunc.any() and rew.dtype == np.float32
   obs, rew, term, trunc, info = venv.step(np.zeros((2, 2), np.float32))
-  assert term.all()
+  assert trunc.all() and not term.any()          # the episode's time is up: gymnasium's truncation
   obs, rew, term, trunc, info = venv.step(np.zeros((2, 2), np.float32))   # next-step autoreset
-  assert not term.any() and (info["step_type"] == STEP_FIRST).all() and (rew == 0).all()
+  assert not term.any() and not trunc.any() and (info["step_type"] == STEP_FIRST).all() and (rew == 0).all()
+  # the reference's own reading (discount 0 = a termination), on request
+  venv = adapters.gymnasium_vector_env(_ToyEnv(B=2, O=3, n=1), time_limit_is_truncation=False)
+  venv.reset()
+  venv.step(np.zeros((2, 2), np.float32))
+  _, _, term, trunc, _ = venv.step(np.zeros((2, 2), np.float32))
+  assert term.all() and not trunc.any()
 
 
 @pytest.mark.gpu
