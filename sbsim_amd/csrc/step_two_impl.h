@@ -54,6 +54,10 @@ constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in 
 // (Homes in registers for those slots -- tried first: the grid's 304-320 registers, 112-176 for A and a sweep's
 // working set of ~140 do not fit 512; the compiler answered with 0.4-0.9 KB of scratch per lane.)
 // Row stride 2 * NL + 2 doubles: 2 mod 4, conflict-free ds_read_b128 across 16 lanes.
+#ifndef SB_TWO_PD
+#define SB_TWO_PD 1
+#endif
+constexpr int kPD = SB_TWO_PD, kPB = kPD == 1 ? 2 : 4; // a step's LDS reads are issued this many steps ahead, into a ring of kPB buffers (NR % kPB == 0)
 constexpr int kAD = 6, kAR = 8; // global slots of A: read this many steps ahead, into a ring of this many register pairs
 
 template <bool SYM>
@@ -272,7 +276,8 @@ __device__ __forceinline__ void step(Grid<NR, NV> &g, Win &w, const StepBuf<SYM>
   constexpr int r = S % NR, rp = (S + 1) % NR;
   const double na = g.template get<2 * rp>(), nb = g.template get<2 * rp + 1>(); // old values one column ahead
   const double U = wave_shift1<0x13c, false>(w.pb, 0.0); // lane 0 sees the last row's latest value (times bU = 0; SYM: lane 0's upper cell is a pad row)
-  const double Dn = wave_shift1<0x130, true>(na, p.sm);
+  // the lane below's upper cell; under the last lane: the first tail row (TAIL), else nothing (zero fill: no `old` operand to set up)
+  const double Dn = TAIL ? wave_shift1<0x130, true>(na, p.sm) : wave_shift1<0x130, false>(na, 0.0);
   double t, t2, nva, nvb;
   if constexpr (SYM) { // the horizontal pair first: it does not wait for the DPP moves
     const double ha = w.pa + na, hb = w.pb + nb;
@@ -332,15 +337,15 @@ __device__ __forceinline__ void step(Grid<NR, NV> &g, Win &w, const StepBuf<SYM>
 // caller issues those of the first step; a period's last step reads nothing ahead).
 // last_step: the step at which the last lane that owns a row finishes (NR + lanes - 2).
 template <int NR, int S, int S1, bool TAIL, bool ROLL, int NL, bool SYM, int NV>
-__device__ __forceinline__ void run_steps(Grid<NR, NV> &g, Win &w, d2 (&ring)[kAR], StepBuf<SYM> (&pb)[2], Ctx &x,
+__device__ __forceinline__ void run_steps(Grid<NR, NV> &g, Win &w, d2 (&ring)[kAR], StepBuf<SYM> (&pb)[kPB], Ctx &x,
                                           Acc &acc, int last_step) {
   if constexpr (S < S1) {
     if constexpr (!ROLL && S >= NR && (S - NR) % 4 == 0)
       if (S > last_step) return; // uniform: only lanes without rows are left
     prefetch_a<NR, S, NL>(ring, x);
-    if constexpr (S + 1 < NR + 63) load_step<NR, S + 1, TAIL, NL, SYM>(pb[(S + 1) & 1], x, ring);
+    if constexpr (S + kPD < NR + 63) load_step<NR, S + kPD, TAIL, NL, SYM>(pb[(S + kPD) % kPB], x, ring);
     __builtin_amdgcn_sched_barrier(0);
-    step<NR, S, TAIL, ROLL, SYM>(g, w, pb[S & 1], acc);
+    step<NR, S, TAIL, ROLL, SYM>(g, w, pb[S % kPB], acc);
     __builtin_amdgcn_sched_barrier(0);
     run_steps<NR, S + 1, S1, TAIL, ROLL, NL, SYM>(g, w, ring, pb, x, acc, last_step);
   }
@@ -537,7 +542,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
     int n_sweeps = 0, converged = 0;
     {
-      StepBuf<SYM> pb[2];
+      StepBuf<SYM> pb[kPB];
       d2 ring[kAR]; // A's global slots on their way in (dead outside the sweeps: the A pass needs the registers)
 #pragma unroll
       for (int k = 0; k < kAR; ++k) ring[k] = d2{0.0, 0.0};
@@ -597,7 +602,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           acc.cur = 0.0;
           acc.neg = 0.0;
           acc.sg = lane == 0 ? (int)0x80000000 : 0;
-          load_step<NR, 0, TAIL, kNL, SYM>(pb[0], x, ring);
+          static_for<0, kPD>([&](auto kc) { load_step<NR, decltype(kc)::value, TAIL, kNL, SYM>(pb[decltype(kc)::value % kPB], x, ring); });
           w.pa = g.template get<NE - 2>();
           w.pb = g.template get<NE - 1>();
           w.ca = g.template get<0>();
@@ -629,7 +634,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             acc.cur = -acc.neg;
             acc.neg = 0.0;
             acc.sg = lane == 0 ? (int)0x80000000 : 0;
-            load_step<NR, 63, TAIL, kNL, SYM>(pb[1], x, ring); // after the tail scan: lane 63's lower neighbour is new
+            // after the tail scan: lane 63's lower neighbour is new
+            static_for<0, kPD>([&](auto kc) { load_step<NR, 63 + decltype(kc)::value, TAIL, kNL, SYM>(pb[(63 + decltype(kc)::value) % kPB], x, ring); });
           }
           if (!overrun) break;
           // back to the stored grid; this time the block ends with sweep n0 + m

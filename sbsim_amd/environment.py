@@ -27,6 +27,7 @@ import ctypes as C
 import dataclasses
 import datetime as dt
 import math
+import os
 from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -303,6 +304,8 @@ class BatchedSimulator:
     # device-side orientation (internal to the library; reset()/temps() convert, so callers
     # always see the reference's [H, W] layout): the library reports, per orientation, which
     # step kernel it would use, how many wavefront steps one sweep takes and on how many wavefronts
+    if orientation == "auto" and os.environ.get("SBSIM_ORIENTATION") in ("rows", "columns"):   # developer knob
+      orientation = os.environ["SBSIM_ORIENTATION"]
     cands = {"rows": [False], "columns": [True], "auto": [False, True]}[orientation]
     best = None
     for tr in cands:
