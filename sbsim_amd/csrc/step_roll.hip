@@ -360,7 +360,13 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
   const unsigned long long *zmap = a.zmapS + lane;
 
 // developer aid: cycle stamps of workgroup 0's 11th building (steady state, not the cold start)
+// (compiled in with -DSB_PHASE_STAMPS only -- tools/prof_sweeps.py on a tools/build_variant.sh build: the tests'
+// uniform branches were 1 % of the product kernel's instructions)
+#ifdef SB_PHASE_STAMPS
 #define SB_STAMP(i) do { if (a.dbg && gw == 0 && iter == 10 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define SB_STAMP(i) do { } while (0)
+#endif
 
   // The lane's row of the NEXT building is loaded while this building's row is stored, slot by
   // slot, so the loop never waits on HBM latency; so are the building's small inputs.
@@ -506,7 +512,11 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
 #pragma nounroll
       for (;;) { // simulator.py:348-368
         __builtin_amdgcn_sched_barrier(0);
+#ifdef SB_PHASE_STAMPS
 #define SB_STAMP2(i) do { if (a.dbg && gw == 0 && iter == 10 && n_sweeps == 1 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define SB_STAMP2(i) do { } while (0)
+#endif
         SB_STAMP2(10);
         roll_pairs<NR, kWin, NR + kWin, true, EXACT>(e, bk, Areg, pb, x, acc);
         SB_STAMP2(11);
@@ -620,7 +630,9 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
       }
       if (lane == 0 && redo) a.redo_list[atomicAdd(a.redo_ctr, 1)] = b;
       SB_STAMP(8);
+#ifdef SB_PHASE_STAMPS
       if (a.dbg && gw == 0 && iter == 10 && lane == 0) a.dbg[9] = n_sweeps;
+#endif
     }
   }
 #undef SB_STAMP

@@ -472,7 +472,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   // (a.amapS + lane, a.zmapS + lane: formed where they are used, from an opaque lane number -- as kernel-lifetime
   // 64-bit values they lived in scratch)
 
+// (cycle stamps and block counters: compiled in with -DSB_PHASE_STAMPS only -- tools/bench_two_rows.py on a
+// tools/build_variant.sh build)
+#ifdef SB_PHASE_STAMPS
 #define SB_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define SB_COUNT(i) do { if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + (i), 1ull); } while (0)
+#else
+#define SB_STAMP(i) do { } while (0)
+#define SB_COUNT(i) do { } while (0)
+#endif
 
   // The lane's registers of the NEXT building are loaded while this building's are stored; so are
   // the building's small inputs.
@@ -584,7 +592,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         const int n0 = n_sweeps;
         int roll0 = n0 >= 2 ? (int)may_roll(d1, d0, thr, a.pred_haste, a.pred_slack) : (int)(n0 == 0 && prev_sweeps >= 6 && a.pred_first > 1);
         roll0 = __builtin_amdgcn_readfirstlane(roll0) && n0 + 2 <= p.iter_limit;
-        if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + (roll0 ? 13 : 14), 1ull); // developer aid: blocks / single sweeps
+        SB_COUNT(roll0 ? 13 : 14); // developer aid: blocks / single sweeps
         if (roll0 && n0 > 0) { // the grid as of n0 sweeps, should the block overrun (before any sweep: Tprev is still there)
           const unsigned lo8 = (unsigned)opaque(lane * 8);
           static_for<0, NE>([&](auto Jc) { g.template store<decltype(Jc)::value>(tp, lo8); });
@@ -597,7 +605,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma nounroll
         for (;;) { // at most twice
           __builtin_amdgcn_sched_barrier(0);
+#ifdef SB_PHASE_STAMPS
 #define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && n_sweeps == 4 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define SB_STAMP2(i) do { } while (0)
+#endif
           SB_STAMP2(10);
           acc.cur = 0.0;
           acc.neg = 0.0;
@@ -639,7 +651,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           }
           if (!overrun) break;
           // back to the stored grid; this time the block ends with sweep n0 + m
-          if (a.dbg && lane == 0) atomicAdd((unsigned long long *)a.dbg + 15, 1ull);
+          SB_COUNT(15);
           n_sweeps = n0;
           {
             const unsigned lo8 = (unsigned)opaque(lane * 8);
@@ -724,11 +736,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         a.nsw[b] = n_sweeps | (converged << 16);
       }
       SB_STAMP(5);
+#ifdef SB_PHASE_STAMPS
       if (a.dbg && blockIdx.x == 0 && iter == 3 && lane == 0) a.dbg[9] = n_sweeps;
+#endif
     }
     __builtin_amdgcn_wave_barrier(); // the zone sums are read: A may be written again
   }
 #undef SB_STAMP
+#undef SB_COUNT
 #undef SB_STAMP2
 #undef SB_LOAD_AUX
 }
