@@ -11,7 +11,9 @@ echo "$cmd" > $out/command.txt
 timeout 600 $cmd 2>/dev/null | tail -1 > $out/bench_mixed.json
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mixed_$tag -o bench -- $cmd > $out/bench_mixed_under_rocprof.json 2> /tmp/prof_mixed_$tag.err)
 find /tmp/prof_mixed_$tag -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_mixed.csv \;
+[ -f $PWD/tools/libexp_stamps.so ] && export SBSIM_LIB=$PWD/tools/libexp_stamps.so   # the stamps and block counters need a -DSB_PHASE_STAMPS build
 SBSIM_PHASE_TIMING=1 timeout 600 python tools/bench_two_rows.py 2>/dev/null | tail -2 > $out/two_rows_classes.txt
+unset SBSIM_LIB
 head -6 $out/kernel_stats_mixed.csv | cut -c1-220
 cat $out/two_rows_classes.txt | cut -c1-300
 python - $out/bench_mixed.json <<'PY'

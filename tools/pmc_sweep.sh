@@ -10,7 +10,8 @@ for ctrs in "$@"; do
 import sys, glob, csv, collections
 acc = collections.defaultdict(float)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if "k_sweep" in r["Kernel_Name"]]
+    # (not k_sweep_roll<96, true>: the float64 instantiation's near-empty launch on the redo list, one per step)
+    rows = [r for r in csv.DictReader(open(f)) if "k_sweep" in r["Kernel_Name"] and "k_sweep_roll<96, true>" not in r["Kernel_Name"]]
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-20:]     # the timed launches
     for r in rows:
         if int(r["Dispatch_Id"]) in ids: acc[r["Counter_Name"]] += float(r["Counter_Value"]) / len(ids)
