@@ -278,14 +278,17 @@ int sb_occupancy_peek(sb_handle *h, int32_t local_hour, int32_t is_work_day, flo
  * (simulator/stochastic_convection_simulator.py:62-145; SB1: p = 1, distance = 5,
  * sim_config.gin:36-39): after every FD update the air cells of each room are shuffled by
  * random local swaps applied in random order (simulator_flexible_floor_plan.py:156).  The
- * reference draws from Python's global `random`; here the draws are Philox4x32-10 keyed by
- * `seed` with counter (global building index, call number, grid cell): the same random process
+ * reference draws from Python's global `random`; here the draws are a counter-based mixer
+ * (MurmurHash3's 32-bit finaliser; Philox4x32-10 for the whole-room permutation's keys) keyed by
+ * (`seed`, global building index, call number, grid cell, word number): the same random process
  * (statistically equivalent, sharding-independent), not the same stream.  p == 0 or
  * distance == 0 detaches (the reference returns early); distance == -1 with p == 1 is the reference's
  * whole-room random.shuffle (stochastic_convection_simulator.py:78-99): a keyed bijection on the room's
  * cells (k_convect_all); with p < 1 the reference falls into its 1000-cell window (:108-109) and so does
- * this.  Windows of more than 64 offsets (distance >= 20) draw the partner by rejection sampling inside
- * the disc -- uniform over the reference's candidate list.  Rooms of more than 2047 cells and distances
+ * this.  Windows of more than 64 offsets (distance >= 20) draw the partner by rejection -- uniform over
+ * the reference's candidate list: a cell of the room by rank, kept when inside the disc (rooms with fewer
+ * cells than the window's box), else a square of the box, kept when inside the disc and in the room; the
+ * cell itself is a candidate, so a draw is accepted sooner or later (after 16,382 candidates the cell stays).  Rooms of more than 2047 cells and distances
  * above 1000 are SB_ERR_UNSUPPORTED.  sb_step then runs the shuffle between the sweep and the reward.
  * transposed: the plan given to sb_create is the transpose of the caller's floor plan (the host
  * picks the cheaper orientation, sb_plan_info); cells are then numbered -- and candidates
