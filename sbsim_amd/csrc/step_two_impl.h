@@ -14,8 +14,10 @@
 //   row 2l+1 : U = the value just computed, D = lane l+1's row 2l+2 (old, DPP)
 // -- two DPP exchanges per two cells where the one-row layout needs four.  Rows 128.. (at most two)
 // are finished by the affine scan of step_roll.hip (lanes = columns).  A lives in LDS as
-// [lane][slot][2 rows]: one ds_read_b128 per step; coefficient sets as in step_roll.hip (two
-// ds_read_b128 per cell, addressed by 16-bit LDS offsets that arrive in class words from L2).
+// [lane][slot][2 rows] -- as much of it as the planner's level says (below); the rest streams from an
+// L2-resident strip -- one 16-byte read per step; coefficient sets as in step_roll.hip, addressed by a byte
+// per cell and step that arrives in class words from L1: four coefficients per cell (two ds_read_b128), or
+// two (SYM: one) for plans whose cells all satisfy T' = A + bV (U + D) + bH (L + R) (StepBuf<true> below).
 //
 // Sweeps are overlapped in BLOCKS (step_roll.hip overlaps all of them, undoing the started sweep from
 // copies -- another 252 registers here).  A block is a ramp-up (63 steps, lanes > s masked), rolling
@@ -28,8 +30,8 @@
 // period that finds max|delta| <= threshold has started the next sweep already -- the block is run
 // again from the stored grid with m = that sweep.  The iterates and the sweep count are always
 // those of the plain schedule; the prediction only decides the speed.  max|delta| of the two sweeps
-// in flight is separated by its sign as in step_roll.hip.  Two buildings fit in a CU's LDS, so two
-// of the four SIMDs run (LDS-grid kernel: one).
+// in flight is separated by its sign (a lane mask OR-ed into |delta|'s high word, one running max and one
+// running min).  Two, three or four buildings per CU (LEVEL: how much of A stays in LDS).
 #include <type_traits>
 
 #include "step_two_cfg.h"
