@@ -73,7 +73,7 @@ struct Dev {
   // ---- register path (step_reg.hip); reg == 0 when the floor plan is not eligible ----
   int reg;                 // 1: k_step_reg owns the step
   int NR;                  // slots per lane (>= trimmed width), one of the instantiated sizes
-  int P;                   // kernel mode: 1 / 2 wavefronts per building, 3 = 1 wavefront + tail rows, 4 = two rows per lane, 5 = two wavefronts in blocks, 6 = grid in global memory
+  int P;                   // kernel mode: 1 / 2 wavefronts per building, 3 = 1 wavefront + tail rows, 4 = two rows per lane, 5 = two to four wavefronts in blocks, 6 = grid in global memory
   int T;                   // mode 3: rows 64..64+T-1 are finished by the tail scan (T <= 2)
   int state_doubles;       // doubles of HBM state per building
   const uint8_t *tcls;     // mode 3: [T][NR] classes of the tail cells (class * 8)
@@ -90,7 +90,7 @@ struct Dev {
   int ZRS;                 // row stride of the zone-sum scratch [Z+1][ZRS] that aliases A (RS | 1)
   int Ws;                  // trimmed width
   int n_ring;              // exterior-space cells outside the trim box (all of class "ambient")
-  int lw[2], l0[2], rowbase[2], nch[2]; // per wave: rows, first lane, first row, 8-step chunks
+  int lw[4], l0[2], rowbase[2], nch[2]; // per wave: rows (mode 5: up to four wavefronts), first lane, first row, 8-step chunks
   int lag;                 // wave 1 runs `lag` chunk slots behind wave 0
   int nslots;              // chunk slots (barriers) per sweep
   float pred_haste;        // mode 4: when may the next sweep overlap (step_two.hip may_roll)
@@ -171,8 +171,10 @@ int launch_sweep_band(const Dev &d, hipStream_t stream);
 int prepare_sweep_band(const Dev &d);
 bool sweep_band_supported(int NR);
 int sweep_band_lds_slots(int NR);       // slots of A in LDS = A's row stride
-int sweep_band_seam_doubles(int NR);    // LDS doubles of the seam rows and the publish scratch
-int sweep_band_sync_doubles();          // LDS doubles of the progress counters and the published max|delta| parts
+int sweep_band_max_waves();             // wavefronts per building: 2 .. this
+int sweep_band_seam_doubles(int NR, int W); // LDS doubles of the seam rows and the publish scratch (W wavefronts)
+int sweep_band_sync_doubles(int W);     // LDS doubles of the progress counters and the published max|delta| parts
+int sweep_band_decision_lag(int NR, int W); // sweeps a decision of wavefront 0 cannot see yet
 int sweep_band_set_table();
 // step_stream.hip: mode 6 (the grid in global memory: plans that fit no other kernel)
 int launch_sweep_stream(const Dev &d, double *abuf, int waves, hipStream_t stream);

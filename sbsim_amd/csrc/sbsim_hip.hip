@@ -173,7 +173,7 @@ struct RegPlan {
   int NR = 0, P = 0, RS = 0, Ws = 0, r0 = 0, c0 = 0, n_ring = 0, T = 0, state_doubles = 0, ts = 32;
   std::vector<uint8_t> tcls, tcset;
   std::vector<double> csetab; // mode 3: distinct (bU, bD, bL, bR), the pad set (all zero) last
-  int lw[2] = {0, 0}, l0[2] = {0, 0}, rowbase[2] = {0, 0}, nch[2] = {0, 0};
+  int lw[4] = {0, 0, 0, 0}, l0[2] = {0, 0}, rowbase[2] = {0, 0}, nch[2] = {0, 0};
   int lag = 0, nslots = 0, steps = 0;
   int r_seam = 0, r_A = 0, r_xchg = 0, lds_bytes = 0, wg_per_cu = 0, AS = 0;
   int r_cmap = 0, wave_doubles = 0, waves_per_wg = 1; // mode 3: four buildings per workgroup share the class words
@@ -410,19 +410,27 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
   return true;
 }
 
-// Mode 5 (step_band.hip): two wavefronts per building, one row per lane (rows 0..63 / 64..127) + at
-// most two tail rows, up to 80 columns inside the exterior ring; sweeps overlapped in predicted blocks.
+// Mode 5 (step_band.hip): two to four wavefronts per building, one row per lane (rows 64 w .. 64 w + 63) + at
+// most two tail rows, up to 96 columns inside the exterior ring; sweeps overlapped in predicted blocks.
 bool plan_band(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const std::vector<int> &zone_of, RegPlan &r) {
   const int W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = plan->H * plan->W;
   auto coef = [&](int c, int j) { return plan->class_coef[c * 8 + j]; };
   int NR = 0;
-  for (int s : {76, 80})
+  for (int s : {76, 80, 96})
     if (!NR && s >= Ws && sweep_band_supported(s)) NR = s;
-  if (!NR || Hs <= 64 || Hs > 128 + 2) return false;
-  const int T = std::max(0, Hs - 128), Hw = Hs - T;
-  for (int x = x0 + Hw; x < x0 + Hs; ++x)
-    for (int y = y0; y < y0 + Ws; ++y)
-      if (zone_of[x * W + y] >= 0) return false; // the tail scan adds no zone sums
+  if (!NR || Hs <= 64) return false;
+  // wavefronts: the fewest whose rows + two tail rows hold the plan; a zone cell in a tail row needs one more
+  int NWV = 0, T = 0;
+  for (int w = 2; w <= sweep_band_max_waves() && !NWV; ++w) {
+    if (Hs > 64 * w + 2) continue;
+    const int t = std::max(0, Hs - 64 * w);
+    bool zone_free = true; // the tail scan adds no zone sums
+    for (int x = x0 + Hs - t; x < x0 + Hs; ++x)
+      for (int y = y0; y < y0 + Ws; ++y) zone_free = zone_free && zone_of[x * W + y] < 0;
+    if (zone_free) { NWV = w; T = t; }
+  }
+  if (!NWV) return false;
+  const int Hw = Hs - T, RS = 64 * NWV;
   int ts = 32;
   while (ts < ncls + 1) ts *= 2;
   if (ts > 256) return false;
@@ -443,33 +451,56 @@ bool plan_band(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const s
   set_of[pad] = (int)r.csetab.size() / 4; // the pad set: no neighbour counts
   for (int j = 0; j < 4; ++j) r.csetab.push_back(0.0);
   if ((int)r.csetab.size() / 4 > sweep_band_set_table()) { r.csetab.clear(); return false; }
-
-  const int AS = sweep_band_lds_slots(NR), ZRS = 65;
-  if ((Z + 1) * ZRS > 65535) { r.csetab.clear(); return false; }
-  int off = 4 * sweep_band_set_table() + 2 * ts;
-  r.r_seam = off; off += sweep_band_seam_doubles(NR);
-  r.r_xchg = off; off += sweep_band_sync_doubles();
-  off = (off + 1) & ~1;
-  r.r_A = off; off += std::max(2 * 64 * AS, (Z + 1) * ZRS); // the zone-sum scratch aliases A
-  r.AS = AS;
-  r.lds_bytes = off * 8;
-  if (const char *padb = getenv("SBSIM_DEBUG_LDS_PAD")) r.lds_bytes += atoi(padb);
-  r.wg_per_cu = std::min(2, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule)); // two wavefronts each, one per SIMD
-  if (r.wg_per_cu < 1) { r.csetab.clear(); return false; }
-
-  r.NR = NR; r.P = 5; r.RS = 128; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
-  r.T = T; r.ts = ts;
-  r.state_doubles = NR * 128 + T * NR;
-  r.lw[0] = 64; r.lw[1] = Hw - 64; r.l0[0] = r.l0[1] = 0; r.rowbase[0] = 0; r.rowbase[1] = 64;
-  r.nch[0] = r.nch[1] = 0; r.lag = 0; r.nslots = 0;
-  r.steps = NR + 4 * T;
   auto cell_class = [&](int R, int col) { // trimmed coordinates
     return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? (int)plan->cell_class[(x0 + R) * W + (y0 + col)] : pad;
   };
+  auto zone_at = [&](int R, int col) { // the zone of a wavefront-row cell; Z: none (the dump zone)
+    if (R >= Hw || col >= Ws) return Z;
+    const int z = zone_of[(x0 + R) * W + (y0 + col)];
+    return z >= 0 ? z : Z;
+  };
+  // ---- the zone-sum scratch: one slot per (zone, row) whose row holds a cell of the zone; zone Z (every
+  // cell outside a zone, the tail rows) has a slot for every lane of every wavefront
+  std::vector<std::vector<int>> zl(Z + 1);
+  for (int R = 0; R < RS; ++R) {
+    std::vector<char> seen(Z + 1, 0);
+    seen[Z] = 1;
+    for (int col = 0; col < Ws && R < Hw; ++col) seen[zone_at(R, col)] = 1;
+    for (int z = 0; z <= Z; ++z)
+      if (seen[z]) zl[z].push_back(R);
+  }
+  r.zs_off.assign(Z + 2, 0);
+  for (int z = 0; z <= Z; ++z) r.zs_off[z + 1] = r.zs_off[z] + (int)zl[z].size();
+  const int zs_slots = r.zs_off[Z + 1];
+  if (zs_slots > 65535) { r.csetab.clear(); return false; }
+  auto zslot = [&](int z, int R) {
+    const auto it = std::lower_bound(zl[z].begin(), zl[z].end(), R);
+    return r.zs_off[z] + (int)(it - zl[z].begin());
+  };
+
+  const int AS = sweep_band_lds_slots(NR);
+  int off = 4 * sweep_band_set_table() + 2 * ts;
+  r.r_seam = off; off += sweep_band_seam_doubles(NR, NWV);
+  r.r_xchg = off; off += sweep_band_sync_doubles(NWV);
+  off = (off + 1) & ~1;
+  r.r_A = off; off += std::max(RS * AS, zs_slots); // the zone-sum scratch aliases A
+  r.AS = AS;
+  r.lds_bytes = off * 8;
+  if (const char *padb = getenv("SBSIM_DEBUG_LDS_PAD")) r.lds_bytes += atoi(padb);
+  r.wg_per_cu = std::min(4 / NWV, kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule)); // one wavefront per SIMD
+  if (r.wg_per_cu < 1) { r.csetab.clear(); r.zs_off.clear(); return false; }
+
+  r.NR = NR; r.P = 5; r.RS = RS; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
+  r.T = T; r.ts = ts;
+  r.state_doubles = NR * RS + T * NR;
+  for (int w = 0; w < 4; ++w) r.lw[w] = w < NWV ? std::max(0, std::min(64, Hw - 64 * w)) : 0;
+  r.l0[0] = r.l0[1] = 0; r.rowbase[0] = 0; r.rowbase[1] = 64;
+  r.nch[0] = r.nch[1] = 0; r.lag = 0; r.nslots = 0;
+  r.steps = NR + 4 * T;
   const int NW = NR + 63, NWD = NR / 4;
-  std::vector<uint32_t> cw((size_t)2 * NW * 64, 0);
-  r.amapS.assign((size_t)2 * NWD * 64, 0);
-  r.zmapS.assign((size_t)2 * NWD * 64, 0);
+  std::vector<uint32_t> cw((size_t)NWV * NW * 64, 0);
+  r.amapS.assign((size_t)NWV * NWD * 64, 0);
+  r.zmapS.assign((size_t)NWV * NWD * 64, 0);
   r.tcls.assign((size_t)std::max(T, 1) * NR, (uint8_t)pad);
   r.tcset.assign((size_t)std::max(T, 1) * NR, (uint8_t)(8 * set_of[pad]));
   for (int t = 0; t < T; ++t)
@@ -477,7 +508,7 @@ bool plan_band(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const s
       r.tcls[(size_t)t * NR + c] = (uint8_t)cell_class(Hw + t, c);
       r.tcset[(size_t)t * NR + c] = (uint8_t)(8 * set_of[cell_class(Hw + t, c)]);
     }
-  for (int w = 0; w < 2; ++w)
+  for (int w = 0; w < NWV; ++w)
     for (int lane = 0; lane < 64; ++lane) {
       const int R = 64 * w + lane;
       const bool valid = R < Hw;
@@ -493,9 +524,7 @@ bool plan_band(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const s
           const int j = 4 * g + k, col = ((j - lane) % NR + NR) % NR;
           const bool cell = valid && col < Ws;
           aword |= (unsigned long long)((cell ? cell_class(R, col) : pad) * 16) << (16 * k);
-          int z = Z; // dump row
-          if (cell && zone_of[(x0 + R) * W + (y0 + col)] >= 0) z = zone_of[(x0 + R) * W + (y0 + col)];
-          zword |= (unsigned long long)(z * ZRS + lane) << (16 * k);
+          zword |= (unsigned long long)zslot(cell ? zone_at(R, col) : Z, R) << (16 * k);
         }
         r.amapS[((size_t)w * NWD + g) * 64 + lane] = aword;
         r.zmapS[((size_t)w * NWD + g) * 64 + lane] = zword;
@@ -509,9 +538,9 @@ bool plan_band(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const s
     for (int y = 0; y < W; ++y) {
       const int R = x - x0, col = y - y0;
       if (R < 0 || R >= Hs || col < 0 || col >= Ws) { r.cell_state[x * W + y] = -(++ring); continue; }
-      if (R >= Hw) { r.cell_state[x * W + y] = NR * 128 + (R - Hw) * NR + col; continue; }
+      if (R >= Hw) { r.cell_state[x * W + y] = NR * RS + (R - Hw) * NR + col; continue; }
       const int slot = (col + (R & 63)) % NR;
-      r.cell_state[x * W + y] = (slot / 2) * 256 + R * 2 + (slot & 1); // state layout [NR / 2][128][2]
+      r.cell_state[x * W + y] = (slot / 2) * 2 * RS + R * 2 + (slot & 1); // state layout [NR / 2][64 W][2]
     }
   r.ok = true;
   return true;
@@ -653,6 +682,8 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   if (Hs > 64 + 2 && env_flag("SBSIM_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   // mode 4: one wavefront, two rows per lane (67..130 rows, <= 80 columns)
   if (Hs > 64 + 2 && !env_flag("SBSIM_NO_TWO_ROW_PATH") && plan_two(plan, Hs, Ws, x0, y0, zone_of, r)) return;
+  // mode 5 again: beyond 128 rows (up to 258, <= 96 columns) three or four wavefronts share a building
+  if (Hs > 128 && !env_flag("SBSIM_NO_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   auto pick_slots = [&](int mode) { // narrowest instantiation that holds the width and the class count
     for (int s : kRegSlots) {
       if (mode == 3) {
@@ -936,9 +967,9 @@ void fill_launch_info(const sb_plan_desc *plan, const RegPlan &r, const LdsPlan 
     out->state_bytes_per_env_step = 16ll * r.state_doubles + rest;
   } else if (r.ok) {
     out->path = 1;
-    out->waves_per_building = (r.P == 2 || r.P == 5) ? 2 : 1;
+    out->waves_per_building = r.P == 5 ? r.RS / 64 : r.P == 2 ? 2 : 1;
     out->kernel = r.P; // sb_sweep_kernel: modes 1..5 are SB_KERNEL_REG .. SB_KERNEL_BAND
-    out->waves_per_workgroup = (r.P == 2 || r.P == 5) ? 2 : r.waves_per_wg; // mode 3: four buildings per workgroup
+    out->waves_per_workgroup = r.P == 5 ? r.RS / 64 : r.P == 2 ? 2 : r.waves_per_wg; // mode 3: four buildings per workgroup
     out->workgroups = std::max(1, std::min((n_buildings + r.waves_per_wg - 1) / r.waves_per_wg, cus * r.wg_per_cu));
     out->lds_bytes_per_workgroup = r.lds_bytes;
     out->sweep_steps = r.steps;
@@ -1068,7 +1099,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.pitch = d.W; d.NL = d.N; d.ts = r.ts;
     d.NR = r.NR; d.P = r.P; d.RS = r.RS; d.Ws = r.Ws; d.n_ring = r.n_ring;
     d.T = r.T; d.state_doubles = r.state_doubles; d.AS = r.AS; d.ZRS = r.RS | 1;
-    for (int w = 0; w < 2; ++w) { d.lw[w] = r.lw[w]; d.l0[w] = r.l0[w]; d.rowbase[w] = r.rowbase[w]; d.nch[w] = r.nch[w]; }
+    for (int w = 0; w < 2; ++w) { d.l0[w] = r.l0[w]; d.rowbase[w] = r.rowbase[w]; d.nch[w] = r.nch[w]; }
+    for (int w = 0; w < 4; ++w) d.lw[w] = r.lw[w];
     d.lag = r.lag; d.nslots = r.nslots; d.nsteps = r.steps;
     d.lds_reg_bytes = r.lds_bytes; d.wg_per_cu = r.wg_per_cu;
     d.r_seam = r.r_seam; d.r_A = r.r_A; d.r_xchg = r.r_xchg;
@@ -1076,7 +1108,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.pred_haste = 1.0f; d.pred_slack = 1.0f; // measured (tools/bench_two_rows.py); developer knobs: speed only,
     if (const char *e = getenv("SBSIM_DEBUG_PRED_HASTE")) d.pred_haste = (float)atof(e); // never the result
     if (const char *e = getenv("SBSIM_DEBUG_PRED_SLACK")) d.pred_slack = (float)atof(e);
-    d.pred_first = r.P == 5 ? 4 : 3; // step_band.hip decides one sweep later: one more period unseen
+    d.pred_first = r.P == 5 ? 3 + sweep_band_decision_lag(r.NR, r.RS / 64) : 3; // step_band.hip decides L sweeps later: as many more periods unseen
     if (const char *e = getenv("SBSIM_DEBUG_PRED_FIRST")) d.pred_first = std::max(1, atoi(e));
     SB_TRY(upload(h->zone_cells_l, plan->zone_cells, (size_t)plan->zone_off[plan->Z]));
     SB_TRY(upload(h->cmapS, r.cmapS.data(), r.cmapS.size()));

@@ -675,19 +675,27 @@ def _oracle_twin(plan, cfg, init_flat):
     ((5, 3), (24, 24), "rows", 4),     # 128x78: two rows per lane, all 64 lanes, no tail row
     ((4, 4), (15, 17), "rows", 4),     # 67x75: two rows per lane, 34 lanes (the sweep ends early)
     ((14, 7), (8, 10), "rows", 4),     # 129x80: two rows per lane, 80 slots + ONE tail row
+    # 131..258 rows, <= 96 columns: step_band.hip with three or four wavefronts per building (the library's choice)
+    ((9, 4), (16, 17), "rows", 53),    # 156x75 inside the exterior ring: 64 + 64 + 28 rows, 76 slots
+    ((10, 4), (18, 20), "rows", 53),   # 193x87: 3 x 64 rows + ONE tail row, 96 slots (24 of them in AGPRs)
+    ((10, 4), (19, 20), "rows", 54),   # 203x87, 40 zones (VERDICT r3 #4's 200 x 90 class): 3 x 64 + 11 rows, 96 slots
+    ((12, 3), (20, 24), "rows", 54),   # 255x78: 3 x 64 + 63 rows, 80 slots
+    ((4, 10), (20, 19), "columns", 54),  # the 203x87 plan transposed in the file: the same kernel, lanes = file columns
 ])
 def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, monkeypatch):
   """BASELINE.json configs[2] semantics: other floor-plan classes (different H x W and zone
   counts) through the same C ABI, each checked against its CPU-oracle twin.  path: 0 the LDS-grid
   kernel, 1 the library's choice among the register kernels, 4 / 5 that kernel (sb_sweep_kernel)."""
   from sbsim_amd.floorplan import rectangular_floor_plan
-  kern = None
-  if path >= 4:
+  kern, waves = None, None
+  if path >= 50:      # 53 / 54: step_band.hip by the library's own choice, three / four wavefronts per building
+    kern, waves, path = 5, path - 50, 1
+  elif path >= 4:
     kern, path = path, 1
     if kern == 5:
       monkeypatch.setenv("SBSIM_BAND_PATH", "1")
   _check_plan_against_oracle(rectangular_floor_plan(rooms, room_shape), rooms[0] * rooms[1], orientation, path, monkeypatch,
-                             expect_kernel=kern)
+                             expect_kernel=kern, expect_waves=waves)
 
 
 @pytest.mark.gpu
@@ -720,6 +728,32 @@ def test_block_kernels_iteration_limit(limit, kern, monkeypatch):
     monkeypatch.setenv("SBSIM_BAND_PATH", "1")
   _check_plan_against_oracle(rectangular_floor_plan((8, 5), (12, 14)), 40, "auto", 1, monkeypatch,
                              iteration_limit=limit, expect_kernel=kern)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("haste,slack", [(1.0, 1.0), (1.0, 0.0), (1.0, -100.0)])
+def test_band_kernel_four_wavefronts_tail_rows_and_overrun_blocks(haste, slack, monkeypatch):
+  """step_band.hip at its largest: 258 rows inside the exterior ring (4 x 64 + TWO tail rows; a 5-CV wall at the
+  bottom of a 255-row plan), wavefront 0 deciding three sweeps before the last wavefront's part exists; and the
+  prediction switched off (slack 0 / -100: every period rolls, every step runs past its last sweep and is run
+  again from the stored grid).  Sweep counts and temperatures must not notice."""
+  from sbsim_amd.floorplan import rectangular_floor_plan
+  fp = rectangular_floor_plan((12, 3), (20, 24))
+  for _ in range(3):
+    fp = np.insert(fp, fp.shape[0] - 2, fp[-2], axis=0)
+  assert fp.shape == (260, 80)
+  monkeypatch.setenv("SBSIM_DEBUG_PRED_HASTE", str(haste))
+  monkeypatch.setenv("SBSIM_DEBUG_PRED_SLACK", str(slack))
+  _check_plan_against_oracle(fp, 36, "rows", 1, monkeypatch, expect_steps=80 + 8, expect_kernel=5, expect_waves=4, B=4, T=10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limit", [1, 2, 3, 5, 9])
+def test_band_kernel_four_wavefronts_iteration_limit(limit, monkeypatch):
+  """simulator.py:348-368 with a limit that bites, four wavefronts per building (203 x 87 inside the ring)."""
+  from sbsim_amd.floorplan import rectangular_floor_plan
+  _check_plan_against_oracle(rectangular_floor_plan((10, 4), (19, 20)), 40, "rows", 1, monkeypatch,
+                             iteration_limit=limit, expect_kernel=5, expect_waves=4, B=4, T=8)
 
 
 def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatch, expect_steps=None,
