@@ -135,7 +135,8 @@ struct Dev {
   int n_src, n_hist, hist_normalize; // optional HistogramReducer
   const int *src_dest, *hist_col, *hist_off;
   const double *hist_bins;
-  long long *dbg;          // optional [16] phase time stamps of wave 0's first building
+  long long *dbg;          // optional [16] phase time stamps of wave 0's first building (+ [2048] with dbg_timeline)
+  int dbg_timeline;        // SBSIM_DEBUG_TIMELINE=1 (developer builds of step_band.hip)
   sb_params p;
 };
 
@@ -174,7 +175,7 @@ int sweep_band_lds_slots(int NR);       // slots of A in LDS = A's row stride
 int sweep_band_max_waves();             // wavefronts per building: 2 .. this
 int sweep_band_seam_doubles(int NR, int W); // LDS doubles of the seam rows and the publish scratch (W wavefronts)
 int sweep_band_sync_doubles(int W);     // LDS doubles of the progress counters and the published max|delta| parts
-int sweep_band_decision_lag(int NR, int W); // sweeps a decision of wavefront 0 cannot see yet
+int sweep_band_decision_lag(int NR, int W); // periods until a sweep's max|delta| is known in every wavefront
 int sweep_band_set_table();
 // step_stream.hip: mode 6 (the grid in global memory: plans that fit no other kernel)
 int launch_sweep_stream(const Dev &d, double *abuf, int waves, hipStream_t stream);

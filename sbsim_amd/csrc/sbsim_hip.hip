@@ -1108,7 +1108,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.pred_haste = 1.0f; d.pred_slack = 1.0f; // measured (tools/bench_two_rows.py); developer knobs: speed only,
     if (const char *e = getenv("SBSIM_DEBUG_PRED_HASTE")) d.pred_haste = (float)atof(e); // never the result
     if (const char *e = getenv("SBSIM_DEBUG_PRED_SLACK")) d.pred_slack = (float)atof(e);
-    d.pred_first = r.P == 5 ? 3 + sweep_band_decision_lag(r.NR, r.RS / 64) : 3; // step_band.hip decides L sweeps later: as many more periods unseen
+    d.pred_first = 3; // (step_band.hip: > 1 = its first block may roll on the previous step's count)
     if (const char *e = getenv("SBSIM_DEBUG_PRED_FIRST")) d.pred_first = std::max(1, atoi(e));
     SB_TRY(upload(h->zone_cells_l, plan->zone_cells, (size_t)plan->zone_off[plan->Z]));
     SB_TRY(upload(h->cmapS, r.cmapS.data(), r.cmapS.size()));
@@ -1270,9 +1270,10 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   d.scal = h->scal.p;
   d.O = obs->n_obs; d.col_ahu = obs->col_ahu; d.col_blr = obs->col_boiler; d.col_aux = obs->col_aux;
   d.col_zone = h->col_zone.p; d.obs_mean = h->obs_mean.p; d.obs_sigma = h->obs_sigma.p;
-  d.dbg = nullptr;
+  d.dbg = nullptr; d.dbg_timeline = 0;
   if (getenv("SBSIM_PHASE_TIMING")) { // developer aid: cycle stamps of wave 0's first building
-    if (alloc_zero(h->dbg, 16) == SB_OK) d.dbg = h->dbg.p;
+    d.dbg_timeline = getenv("SBSIM_DEBUG_TIMELINE") ? 1 : 0; // + [2048]: step_band.hip's time line of one building-step (-DSB_PHASE_STAMPS builds)
+    if (alloc_zero(h->dbg, 16 + (d.dbg_timeline ? 2048 : 0)) == SB_OK) d.dbg = h->dbg.p;
   }
 
   const int e = d.reg ? (d.P == 6 ? prepare_sweep_stream(d, h->info.waves_per_workgroup) : d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
@@ -1488,13 +1489,14 @@ int sb_tap_post(sb_handle *h, int32_t building, const sb_tap_bld *bld, const dou
   return SB_OK;
 }
 
-/* Developer aid (not part of the parity/bench path): 16 int64 cycle stamps, host pointer. */
+/* Developer aid (not part of the parity/bench path): 16 int64 cycle stamps, host pointer (16 + 2048 when the handle
+   was created under SBSIM_DEBUG_TIMELINE=1). */
 int sb_debug_phase_cycles(sb_handle *h, long long *out_host) {
   if (!h || !out_host) return fail(SB_ERR_INVALID, "sb_debug_phase_cycles: null argument");
   if (!h->d.dbg) return fail(SB_ERR_INVALID, "sb_debug_phase_cycles: set SBSIM_PHASE_TIMING=1 before sb_create");
   SB_ON_DEVICE(h->device);
   SB_HIP(hipDeviceSynchronize());
-  SB_HIP(hipMemcpy(out_host, h->d.dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  SB_HIP(hipMemcpy(out_host, h->d.dbg, (16 + (h->d.dbg_timeline ? 2048 : 0)) * sizeof(long long), hipMemcpyDeviceToHost));
   return SB_OK;
 }
 

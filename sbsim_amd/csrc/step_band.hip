@@ -25,12 +25,13 @@
 //     instruction cache once.
 //   * max|delta| of a sweep is the maximum over the wavefronts (and the tail rows): each publishes its
 //     part per sweep; the decisions -- roll on, end the block, run it again -- are functions of the
-//     published sequence only, evaluated by all wavefronts alike.  Wavefront 0 reaches a decision
-//     point before the last wavefront's part of the latest sweeps can exist -- L = ceil((W - 1) x 74
-//     / NR) sweeps of them (1, 2, 3 for W = 2, 3, 4): a decision waits for sweep G - L at most and
-//     extrapolates L + 1 sweeps ahead (may the next period roll?), so a block's rolling part ends
-//     L + 1 + slack sweeps before the predicted last one and the step finishes in one or two short
-//     blocks that start from complete knowledge.
+//     published parts only, evaluated by all wavefronts alike.  The last wavefront's rows finish a sweep
+//     W - 1 periods after wavefront 0's: a decision after sweep G reads wavefront k's parts up to sweep
+//     G - k - 1 (its own up to G; a period of slack, so that no decision waits), predicts every
+//     wavefront's last sweep from the decay of ITS part and rolls on while the latest of them is beyond
+//     the next sweep.  Whether a sweep was the step's last is known for certain W periods later; a block
+//     that has run past it by then is run again.  A step's first block aims at one sweep less than the
+//     building's previous step took until its own parts say more.
 // The iterates and the sweep count are always those of the plain schedule (tests: oracle twins,
 // step_lds.hip on the same batch); the prediction only decides the speed.
 #include <type_traits>
@@ -48,8 +49,11 @@ using namespace sweep;
 constexpr int kSets = 32;  // entries of the coefficient-set table (at LDS address 0)
 constexpr int kWA = 11;    // class words (one step each) are read this many steps ahead (an L2 hit is ~800 cycles away)
 constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in the hand-over
-constexpr int kGrp = 8;    // steps between two checks of the neighbouring wavefronts' progress
-constexpr int kHist = 16;  // ring of published max|delta| parts, by sweep number: wavefront 0 may be L + 1 <= 4 sweeps ahead of the last one, whose decisions look back L + 1 more
+#ifndef SB_BAND_GRP
+#define SB_BAND_GRP 16 // (8: the sweeps 5-9 % slower, tools/bench_mid_plans.py: every check drains the wavefront's LDS queue)
+#endif
+constexpr int kGrp = SB_BAND_GRP; // steps between two checks of the neighbouring wavefronts' progress
+constexpr int kHist = 16;  // ring of published max|delta| parts, by sweep number: wavefront 0 may be five sweeps ahead of the last one, whose decisions look back five more (8 entries: overwritten under a reader -- found by the spin limit's trap)
 constexpr int kWMax = 4;   // wavefronts per building: one per SIMD
 static_assert(kWA % 8 != 0 && (63 + kWA) % 8 != 0, "step_set: the start words leave the offset inside a chunk");
 
@@ -96,7 +100,16 @@ struct Sync {
   lds_vi mine, up, dn;
   int off_up, off_dn; // + 64 / - NR - 62; a wavefront without that neighbour: far below zero
   long long *dbg;     // developer builds (-DSB_PHASE_STAMPS): spin counters
+  long long *tl;      // ... and (SBSIM_DEBUG_TIMELINE=1) a time line of one building-step of workgroup 0: [512] per wavefront, (cycle << 12) | step or code
+  mutable int tl_i;
 };
+#ifdef SB_PHASE_STAMPS
+__device__ __forceinline__ void tl_mark(const Sync &sy, int code) {
+  if (sy.tl && (threadIdx.x & 63) == 0 && sy.tl_i < 512) sy.tl[sy.tl_i++] = ((long long)__builtin_readcyclecounter() << 12) | (long long)(code & 0xfff);
+}
+#else
+__device__ __forceinline__ void tl_mark(const Sync &, int) {}
+#endif
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -109,8 +122,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 // Class words: one 32-bit word per step = the LDS byte offset (set * 32) of the cell's coefficient
 // set, read from global memory (L2 hits) kWA steps ahead; [wavefront][NR + 63 steps][64 lanes].
 __device__ __forceinline__ unsigned class_word(const Ctx &x) { return *(const unsigned *)(x.cmap + x.voff); }
-// The first kWA words of a rolling period (steps 63 ..) are the same every time: up to 80 slots they are read
-// once per kernel and kept in registers (a block's first words are read again).
+// The first kWA words of a rolling period (steps 63 ..) are the same every time: read once per kernel and kept
+// in registers where the read-ahead cannot run on across the period's end (words_run_on; a block's first words
+// are read again).
 // Word S + kWA is read at step S through base + 32-bit offset + immediate: the offset register moves
 // once per 8 steps.
 // Values that are touched once per period (or per building) are homed in AGPRs by hand: the grid
@@ -126,6 +140,8 @@ __device__ __forceinline__ int from_agpr(int a) {
   asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
   return v;
 }
+template <int NR>
+constexpr bool words_run_on() { return NR % (kWA + 1) == 0 && NR % 8 == 0; }
 template <bool KEEP>
 struct StartWords {
   int period[KEEP ? kWA : 1]; // AGPRs
@@ -143,16 +159,14 @@ __device__ __forceinline__ void first_words(Ctx &x, int lane) { // words 0 .. kW
 #pragma unroll
   for (int k = 0; k < kWA; ++k) x.w[k] = *(const unsigned *)(x.cmap + o + (unsigned)(k * 256));
 }
-template <bool KEEP>
+template <int NR, bool KEEP>
 __device__ __forceinline__ void period_words(Ctx &x, const StartWords<KEEP> &sw, int lane) { // a rolling period starts at step 63
-  x.voff = (unsigned)opaque(lane * 4 + ((63 + kWA) / 8) * 2048);
   if constexpr (KEEP) {
+    x.voff = (unsigned)opaque(lane * 4 + ((63 + kWA) / 8) * 2048);
 #pragma unroll
     for (int k = 0; k < kWA; ++k) x.w[(63 + k) % (kWA + 1)] = (unsigned)from_agpr(sw.period[k]);
-  } else { // read again (96 slots: the registers are needed elsewhere); the sweep's end and the next decision hide the round trip
-    const unsigned o = (unsigned)opaque(lane * 4 + 63 * 256);
-#pragma unroll
-    for (int k = 0; k < kWA; ++k) x.w[(63 + k) % (kWA + 1)] = *(const unsigned *)(x.cmap + o + (unsigned)(k * 256));
+  } else {
+    static_assert(KEEP || words_run_on<NR>(), "the read-ahead has run on into the next period (step_set)");
   }
 }
 // The slots of A that do not fit in LDS.
@@ -209,7 +223,11 @@ struct Win {
   double p, c;
 };
 
-template <int NR, int S>
+// The class words of a rolling period repeat with period NR from step 63 on (step s + NR works on the same
+// column as step s, one sweep later).  Where NR is a multiple of the ring's kWA + 1 entries the read-ahead simply
+// runs on across a period's end -- word s + kWA - NR into the slot of word s + kWA -- and the next period starts
+// with its first words in place; otherwise they come from the StartWords.
+template <int NR, int S, bool ROLL>
 __device__ __forceinline__ lds_d2 step_set(Ctx &x) { // the coefficient set of step S; reads word S + kWA
   if constexpr (S + kWA < NR + 63) {
     if constexpr ((S + kWA) % 8 == 0 && S > 0 && S != 63) { // (the start words leave the offset at its chunk)
@@ -217,15 +235,25 @@ __device__ __forceinline__ lds_d2 step_set(Ctx &x) { // the coefficient set of s
       asm volatile("" : "+v"(x.voff)); // a running offset: nothing for the compiler to hoist
     }
     x.w[(S + kWA) % (kWA + 1)] = *(const unsigned *)(x.cmap + x.voff + (unsigned)(((S + kWA) % 8) * 256));
+  } else if constexpr (ROLL && words_run_on<NR>()) {
+    constexpr int T = S + kWA - NR; // >= 63: the next period's step
+    if constexpr (T == 63) {
+      x.voff -= (unsigned)(((NR + 62) / 8 - 63 / 8) * 2048);
+      asm volatile("" : "+v"(x.voff));
+    } else if constexpr (T % 8 == 0) {
+      x.voff += 2048u;
+      asm volatile("" : "+v"(x.voff));
+    }
+    x.w[(S + kWA) % (kWA + 1)] = *(const unsigned *)(x.cmap + x.voff + (unsigned)((T % 8) * 256));
   }
   return (lds_d2)x.w[S % (kWA + 1)];
 }
 
 // LDS reads of the pair (S, S + 1), S odd.
-template <int NR, int S, int NAR>
+template <int NR, int S, bool ROLL, int NAR>
 __device__ __forceinline__ void load_pair(PairBuf &p, Ctx &x, const ARegs<NAR> &Areg) {
   static_assert(S % 2 == 1, "pairs start at odd steps");
-  const lds_d2 s0 = step_set<NR, S>(x), s1 = step_set<NR, S + 1>(x);
+  const lds_d2 s0 = step_set<NR, S, ROLL>(x), s1 = step_set<NR, S + 1, ROLL>(x);
 #if SB_BAND_EXP >= 2
   p.rU = d2{0.0, 0.0};
   p.rD = d2{0.0, 0.0};
@@ -303,6 +331,7 @@ __device__ __forceinline__ void wait_for(lds_vi ctr, int need, long long *dbg = 
 // values must exist), the one below at most NR + 62 steps back (row 64 w + 64's values of the previous
 // sweep must exist, and it must have read the upper neighbours this wavefront is about to overwrite).
 __device__ __forceinline__ void sync_steps(const Sync &sy, int done, int upto) {
+  tl_mark(sy, done & 0x7ff);
   *sy.mine = done;
   if (upto + sy.off_up > 0) wait_for(sy.up, upto + sy.off_up, sy.dbg ? sy.dbg + 6 : nullptr);
   if (upto + sy.off_dn > 0) wait_for(sy.dn, upto + sy.off_dn, sy.dbg ? sy.dbg + 7 : nullptr);
@@ -322,7 +351,7 @@ __device__ __forceinline__ void run_pairs(Row<NR, NV> &e, Win &w, const ARegs<NA
       sync_steps(sy, tb + S, tb + S + n);
     }
     PairBuf &cur = pb[((S - 1) / 2) & 1], &nxt = pb[((S + 1) / 2) & 1];
-    if constexpr (S + 2 < NR + 63) load_pair<NR, S + 2>(nxt, x, Areg);
+    if constexpr (S + 2 < NR + 63) load_pair<NR, S + 2, ROLL>(nxt, x, Areg);
     __builtin_amdgcn_sched_barrier(0);
     step<NR, NV, S, ROLL>(e, w, cur.ud0, cur.lr0, cur.A.x, cur.rU.x, cur.rD.x, acc, x);
     __builtin_amdgcn_sched_barrier(0);
@@ -439,8 +468,6 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
   const int W = (int)(blockDim.x >> 6);
   constexpr int kNL = lds_slots(NR), kAS = kNL, kNAR = NR - kNL > 0 ? NR - kNL : 1, kRG = seam_region(NR), NV = row_vgpr_slots(NR);
   static_assert(NR % 4 == 0 && NR >= 68, "slots");
-  // sweeps of which the last wavefront's part may not exist yet when wavefront 0 decides (header)
-  const int L = ((W - 1) * (64 + kGrp + 2) + NR - 1) / NR;
 
   double *tabc = lds;                    // [kSets][4]: bU bD bL bR per coefficient set
   double *tapg = lds + 4 * kSets;        // [ts][2]: (ap, g) per class; g of this building
@@ -485,6 +512,8 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
   sy.off_up = first_w ? -(1 << 29) : 64;
   sy.off_dn = last_w ? -(1 << 29) : -NR - 62;
   sy.dbg = a.dbg;
+  sy.tl = nullptr;
+  sy.tl_i = 0;
   const int rows_mine = a.lw[wv];        // lanes that own rows
   const int last_step = NR + rows_mine - 2;
   // the lane's tail cells (the last wavefront; static per floor plan)
@@ -496,7 +525,7 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
     tset[t] = (a.ncset - 1) * 32 * 0x10001; // the pad set (the table's last)
     if (t < a.T && tactive) tset[t] = ((int)a.tcset[t * NR + tc0] << 2) | ((int)a.tcset[t * NR + tc0 + 1] << 18);
   }
-  StartWords<(NR <= 80)> sw;
+  StartWords<!words_run_on<NR>()> sw;
   load_start_words(sw, x, lane);
   // (a.amapS / a.zmapS + the wavefront's part + lane: formed where they are used, from an opaque lane number -- as
   // kernel-lifetime 64-bit values they live in scratch)
@@ -507,9 +536,7 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
 #ifdef SB_PHASE_STAMPS
 #define SB_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && threadIdx.x == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #define SB_COUNT(i) do { if (a.dbg && threadIdx.x == 0) atomicAdd((unsigned long long *)a.dbg + (i), 1ull); } while (0)
-#define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && q == 2 && n0 == 0 && threadIdx.x == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
-#define SB_STAMP2(i) do { } while (0)
 #define SB_STAMP(i) do { } while (0)
 #define SB_COUNT(i) do { } while (0)
 #endif
@@ -538,6 +565,9 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
   for (int b = blockIdx.x, bn = 0; b < a.B; b = bn, ++iter) {
     if (threadIdx.x == 0) misc[0] = a.sweep_wgs + atomicAdd(a.next_b, 1);
     SB_STAMP(0);
+#ifdef SB_PHASE_STAMPS
+    sy.tl = (a.dbg && a.dbg_timeline && blockIdx.x == 0 && iter == 2) ? a.dbg + 16 + 512 * wv : nullptr;
+#endif
     first_words(x, lane);
     double *Ttail = a.temp + (size_t)b * a.state_doubles + (size_t)NR * a.RS; // [T][NR]
     double *tp = a.temp + (size_t)b * a.state_doubles; // uniform; the lane's row: + 16 R bytes
@@ -580,26 +610,82 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
         }
       };
       typedef const volatile d2 __attribute__((address_space(3))) *lds_vd2;
-      auto sweep_md = [&](int G) -> double {
-        const unsigned r0 = lds_addr(mrec + 2 * (G % kHist));
-        double m = 0.0;
-        for (int k = 0; k < W; ++k) { // waits for every part
-          int spins = 0;
-          for (;;) {
-            const d2 pk = *(lds_vd2)(r0 + (unsigned)(k * kHist * 16));
-            if (__builtin_amdgcn_readfirstlane(__double2loint(pk.y)) == G) {
-              m = fmax(m, pk.x);
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 24)) __builtin_trap();
+      // wavefront k's part of sweep G (waits for it)
+      auto wait_part = [&](int k, int G) -> double {
+        const unsigned rec = lds_addr(mrec + 2 * (k * kHist + (G % kHist)));
+        int spins = 0;
+        double v;
+        for (;;) {
+          const d2 pk = *(lds_vd2)rec;
+          if (__builtin_amdgcn_readfirstlane(__double2loint(pk.y)) == G) {
+            v = pk.x;
+            break;
           }
-#ifdef SB_PHASE_STAMPS
-          if (a.dbg && spins && lane == 0) atomicAdd((unsigned long long *)a.dbg + 8, (unsigned long long)spins);
-#endif
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 24)) __builtin_trap();
         }
+#ifdef SB_PHASE_STAMPS
+        if (a.dbg && spins && lane == 0) atomicAdd((unsigned long long *)a.dbg + 8, (unsigned long long)spins);
+#endif
         asm volatile("" ::: "memory");
+        return v;
+      };
+      auto sweep_md = [&](int G) -> double { // max |delta| of sweep G: every wavefront's part
+        double m = 0.0;
+        for (int k = 0; k < W; ++k) m = fmax(m, wait_part(k, G));
         return m;
+      };
+      // A decision's reads, all in flight at once (under load an LDS round trip is ~500 cycles; one after the other
+      // a dozen of them stalled every wavefront for a third of a period -- tools/band_timeline.py).  part k of
+      // sweep g, g <= 0: none.  A record that is not there yet (rare: the lags below leave a period of slack) is waited for.
+      struct Parts { double v[3 * kWMax]; };
+      auto read_parts = [&](const int (&gs)[3 * kWMax], Parts &out) {
+        d2 rec[3 * kWMax];
+#pragma unroll
+        for (int i = 0; i < 3 * kWMax; ++i) {
+          const int k = i / 3;
+          rec[i] = d2{0.0, 0.0};
+          if (k < W && gs[i] > 0) rec[i] = *(lds_vd2)lds_addr(mrec + 2 * (k * kHist + (gs[i] % kHist)));
+        }
+#pragma unroll
+        for (int i = 0; i < 3 * kWMax; ++i) {
+          const int k = i / 3;
+          out.v[i] = 0.0;
+          if (k < W && gs[i] > 0)
+            out.v[i] = __builtin_amdgcn_readfirstlane(__double2loint(rec[i].y)) == gs[i] ? rec[i].x : wait_part(k, gs[i]);
+        }
+      };
+      // The step's last sweep as the published parts predict it: sweep n is the last one when EVERY wavefront's
+      // part is below the threshold, so n = max over the wavefronts of where each one's decay gets there.  When
+      // wavefront v stands at its decision point after sweep G, wavefront k's parts are there without waiting
+      // up to sweep G (k = 0) / G - k - 1 (k > 0: one period of slack on top of the k periods its rows lag; at
+      // G - k the chain of hand-overs would stall wavefront 0 in every period -- measured, tools/band_timeline.py).
+      // Every wavefront evaluates the same parts, so all decide alike.  have: wavefronts with two parts;
+      // md_c: max |delta| of sweep G - W, complete in every wavefront (0 when there is no such sweep in this block).
+      auto predicted_last = [&](int G, int n0_, int &have, double &md_c) -> float {
+        int gs[3 * kWMax];
+#pragma unroll
+        for (int k = 0; k < kWMax; ++k) {
+          const int g = k == 0 ? G : G - k - 1;
+          gs[3 * k] = g >= 2 ? g : 0;
+          gs[3 * k + 1] = g >= 2 ? g - 1 : 0;
+          gs[3 * k + 2] = G - W > n0_ ? G - W : 0;
+        }
+        Parts pt;
+        read_parts(gs, pt);
+        float np = 0.0f;
+        have = 0;
+        md_c = G - W > n0_ ? 0.0 : 1e300;
+#pragma unroll
+        for (int k = 0; k < kWMax; ++k)
+          if (k < W) {
+            if (gs[3 * k] > 0) {
+              np = fmaxf(np, (float)gs[3 * k] + sweeps_to_go((float)pt.v[3 * k + 1], (float)pt.v[3 * k], thr, a.pred_haste));
+              ++have;
+            }
+            if (gs[3 * k + 2] > 0) md_c = fmax(md_c, pt.v[3 * k + 2]);
+          }
+        return np;
       };
       // the end of this wavefront's sweep G: the tail rows (the last wavefront), its part of max |delta|
       auto sweep_end = [&](int G) {
@@ -643,7 +729,7 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
             double *dn_mine = S_dn + wv * kRG;
             static_for<0, NR>([&](auto cc) { dn_mine[decltype(cc)::value] = e.template get<decltype(cc)::value>(); });
           }
-          if ((int)threadIdx.x < W * kHist) *(lds_vi)(lds_addr(mrec + 2 * threadIdx.x) + 8u) = 0; // no part of this block is published
+          if (n0 == 0 && m == 0 && (int)threadIdx.x < W * kHist) *(lds_vi)(lds_addr(mrec + 2 * threadIdx.x) + 8u) = 0; // no part of this step is published (a step's parts stay: later blocks predict from them)
           __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
           acc.cur = 0.0;
@@ -653,12 +739,13 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
           q = 0;
           w.p = e.template get<NR - 1>();
           w.c = e.template get<0>();
+          tl_mark(sy, 0xf01); // block start
           sync_steps(sy, 0, 3); // the wavefront above's first new values must exist
           { // step 0 (lane 0, column 0) on its own: pairs start at odd steps
-            const lds_d2 st = step_set<NR, 0>(x);
+            const lds_d2 st = step_set<NR, 0, false>(x);
             const d2 ud = st[0], lr = st[1];
             const double A0 = *(lds_d)(x.arow + 8u), rU0 = *(lds_d)(x.ubase + 8u * 63u), rD0 = *(lds_d)(x.dbase);
-            load_pair<NR, 1>(pb[0], x, Areg);
+            load_pair<NR, 1, false>(pb[0], x, Areg);
             step<NR, NV, 0, false>(e, w, ud, lr, A0, rU0, rD0, acc, x);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -673,54 +760,45 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
             if (m > 0) go = q + 1 < m;
             else if (!roll0 || G + 2 > p.iter_limit) go = 0; // the final period must fit under the limit
             else {
-              // published history: sweep K = G - L is the latest one every wavefront can complete while this
-              // one stands here (waiting for a later one would be a deadlock); K - 1 and K - 2 are there without
-              // waiting unless a wavefront below has fallen behind
-              const int K = G - L;
-              float h3 = d1, h2 = d0; // sweeps K - 2, K - 1 (before this block: the last block's)
-              if (K - 1 > n0) {
-                const double md2 = sweep_md(K - 1);
-                if (md2 <= p.conv_threshold) { overrun = true; m = K - 1 - n0; break; }
-                h2 = (float)md2;
-                h3 = K - 2 > n0 ? (float)sweep_md(K - 2) : d0;
-              }
-              const bool far = K - 1 >= 2 && K - 1 >= n0 && sweeps_to_go(h3, h2, thr, a.pred_haste) > a.pred_slack + (float)(L + 2);
-              // a first block without news of its own sweeps' decay rolls up to its target
-              const int by_hint = q + 2 <= first_m;
-              if (far) go = 1;
-              else if (K > n0) { // near convergence: wait for the latest sweep that can be complete
-                const double md1 = sweep_md(K);
-                if (md1 <= p.conv_threshold) { overrun = true; m = K - n0; break; }
-                const float h1 = (float)md1;
-                if (K >= 2) {
-                  const float togo = sweeps_to_go(h2, h1, thr, a.pred_haste);
-                  go = togo > a.pred_slack + (float)L && (n0 > 0 || by_hint || togo > a.pred_slack + (float)(L + 2));
-                } else {
-                  go = by_hint;
-                }
-              } else { // nothing of this block is complete yet (q <= L): sweep n0 is the last one known
-                go = n0 >= 2 ? (int)(sweeps_to_go(d1, d0, thr, a.pred_haste) > a.pred_slack + (float)q) : by_hint;
-              }
+              // sweep G - W is complete in every wavefront without waiting: did it converge (and this block run past it)?
+              int have;
+              double md_c;
+              const float n_pred = predicted_last(G, n0, have, md_c);
+              if (md_c <= p.conv_threshold) { overrun = true; m = G - W - n0; break; }
+              const float need = (float)G + a.pred_slack; // sweep G + 1 is not the last one: the next period may roll
+              // (an overrun costs the block twice, a block that ends too early one more ramp: when in doubt, end it)
+              if (have == W) go = n_pred > need;
+              else if (have > 0 && n_pred > need + 1.0f) go = 1; // the wavefronts that have news are far from done
+              else if (have > 0 && !(n_pred > need)) go = 0;     // ... are about to be done: the others will not be far behind
+              else if (n0 >= 2) go = sweeps_to_go(d1, d0, thr, a.pred_haste) > a.pred_slack + (float)q; // the last block's decay
+              else go = q + 2 <= first_m; // a first block without news of its own rolls up to its target
             }
+            tl_mark(sy, 0xf02); // decision made
             if (!__builtin_amdgcn_readfirstlane(go)) break;
             asm volatile("" : "+v"(x.arow), "+v"(x.ubase), "+v"(x.dbase), "+v"(x.pub)); // not loop invariants: nothing to hoist (and spill)
             __builtin_amdgcn_sched_barrier(0);
-            SB_STAMP2(10); // the third rolling period of wavefront 0: its steps, then its end and the next decision
+#ifdef SB_PHASE_STAMPS // developer aid: wavefront 0's rolling periods, summed over all buildings ([10] cycles, [11] periods)
+            const long long t_p0 = (long long)__builtin_readcyclecounter();
+#endif
             run_pairs<NR, NV, 63, NR + 63, true>(e, w, Areg, pb, x, acc, sy, q * NR, last_step);
             __builtin_amdgcn_sched_barrier(0);
             *sy.mine = q * NR + NR + 63; // every step of the period is done
-            SB_STAMP2(11);
 #ifdef SB_PHASE_STAMPS
-            if (a.dbg && blockIdx.x == 0 && iter == 3 && q == 3 && n0 == 0 && threadIdx.x == 0) a.dbg[12] = (long long)__builtin_readcyclecounter();
+            if (a.dbg && threadIdx.x == 0) {
+              atomicAdd((unsigned long long *)a.dbg + 10, (unsigned long long)((long long)__builtin_readcyclecounter() - t_p0));
+              atomicAdd((unsigned long long *)a.dbg + 11, 1ull);
+            }
 #endif
             ++q;
             ++n_sweeps;
-            period_words(x, sw, lane);
+            period_words<NR>(x, sw, lane);
+            tl_mark(sy, 0xf03); // period's steps done
             sweep_end(n0 + q);
+            tl_mark(sy, 0xf04); // part published
             acc.cur = -acc.neg;
             acc.neg = 0.0;
             acc.sg = lane == 0 ? (int)0x80000000 : 0;
-            load_pair<NR, 63>(pb[1], x, Areg); // after the tail scan: lane 63's lower neighbours are new
+            load_pair<NR, 63, false>(pb[1], x, Areg); // after the tail scan: lane 63's lower neighbours are new
           }
           if (!overrun) {
             __builtin_amdgcn_sched_barrier(0);
@@ -730,12 +808,13 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
             *sy.mine = 1 << 30; // the other wavefronts need nothing more from this one
             ++n_sweeps;
             first_words(x, lane);
+            tl_mark(sy, 0xf05); // final period's steps done
             sweep_end(n_sweeps);
             // the block's last sweeps, complete: did one before the last converge already?  (A decision
-            // looks at the sweeps L (or L + 1) before its own: the last L + 2, here.)
+            // checks the sweep W before its own: the last W, here.)
             const int Gl = n_sweeps;
             if (m == 0)
-              for (int j = Gl - (L + 2) > n0 ? Gl - (L + 2) : n0 + 1; j < Gl; ++j)
+              for (int j = Gl - (W + 1) > n0 ? Gl - (W + 1) : n0 + 1; j < Gl; ++j)
                 if (sweep_md(j) <= p.conv_threshold) { overrun = true; m = j - n0; break; }
             if (!overrun) {
               const double mdl = sweep_md(Gl);
@@ -831,7 +910,6 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
   }
 #undef SB_STAMP
 #undef SB_COUNT
-#undef SB_STAMP2
 #undef SB_LOAD_AUX
 }
 
@@ -862,7 +940,7 @@ int sweep_band_max_waves() { return kWMax; }
 int sweep_band_lds_slots(int NR) { return lds_slots(NR); }
 int sweep_band_seam_doubles(int NR, int W) { return (2 * W + 2) * seam_region(NR) + W * (64 + NR + 8); }
 int sweep_band_sync_doubles(int W) { return 32 * W + 2 * W * kHist + 8; }
-int sweep_band_decision_lag(int NR, int W) { return ((W - 1) * (64 + kGrp + 2) + NR - 1) / NR; }
+int sweep_band_decision_lag(int NR, int W) { (void)NR; return W; } // periods until a sweep's max|delta| is known for certain
 int sweep_band_set_table() { return kSets; }
 int prepare_sweep_band(const Dev &d) { return dispatch(d, nullptr, true); }
 int launch_sweep_band(const Dev &d, hipStream_t stream) { return dispatch(d, stream, false); }

@@ -17,11 +17,12 @@ dev = torch.device("cuda", 0)
 K = int(os.environ.get("K", "8"))
 WARM = int(os.environ.get("WARM", "3"))   # steps before the timed ones (the sweep count per step grows over the first ~30)
 B = int(os.environ.get("B", "4096"))
+ONLY = os.environ.get("PLANS")   # e.g. PLANS=0,1
 PLANS = [("205x89 / 40 zones", (10, 4), (19, 20)), ("195x89 / 40 zones", (10, 4), (18, 20)), ("158x77 / 36 zones", (9, 4), (16, 17)),
          ("257x80 / 36 zones", (12, 3), (20, 24))]
-for name, rooms, shape in PLANS:
+for name, rooms, shape in [p for i, p in enumerate(PLANS) if ONLY is None or str(i) in ONLY.split(",")]:
   rates = {}
-  for label, flag in (("step_band", None), ("step_lds", "SBSIM_NO_BAND_PATH")):
+  for label, flag in (("step_band", None), ("step_lds", "SBSIM_NO_BAND_PATH"))[:1 if os.environ.get("BAND_ONLY") else 2]:
     if flag:
       os.environ[flag] = "1"
     plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
@@ -66,7 +67,9 @@ for name, rooms, shape in PLANS:
       print(f"  per building-step: blocks {d[13] / n:.2f} + single sweeps {d[14] / n:.2f}, blocks run again {d[15] / n:.3f}; spins (64 cycles each) "
             f"for the wavefront above {d[6] / n:.0f}, below {d[7] / n:.0f}, for a sweep's max|delta| {d[8] / n:.0f}; cycles from a building's start: "
             f"{[d[i] - d[0] for i in (1, 2, 3, 4, 5)]} (A pass done, sweeps done, handed over, reduced), n_sweeps {d[9]}; "
-            f"wavefront 0's third rolling period {d[11] - d[10]} cycles, to the same point of the fourth {d[12] - d[10]}", flush=True)
+            f"wavefront 0's rolling periods: {d[10] / max(d[11], 1):.0f} cycles each, {d[11] / n:.2f} per building-step", flush=True)
     env.close()
+  if os.environ.get("BAND_ONLY"):
+    continue
   same = bool((rates["step_band"][1] == rates["step_lds"][1]).all())
   print(f"{name}: step_band / step_lds = {rates['step_band'][0] / rates['step_lds'][0]:.2f}x; sweep counts of all {B} buildings x {K} steps equal: {same}", flush=True)

@@ -3,7 +3,7 @@
 # Re-compiles the named translation units with extra flags and links them with the product's other objects into
 # tools/libexp_<name>.so (git-ignored, travels to the GPU box); run with SBSIM_LIB=$PWD/tools/libexp_<name>.so.
 # e.g. the cycle stamps of tools/prof_sweeps.py / tools/bench_two_rows.py (SBSIM_PHASE_TIMING=1):
-#   tools/build_variant.sh stamps step_roll.hip,step_two_76.hip,step_two_80.hip -DSB_PHASE_STAMPS
+#   tools/build_variant.sh stamps step_roll.hip,step_two_76.hip,step_two_80.hip,step_band.hip -DSB_PHASE_STAMPS
 set -e
 name=$1; srcs=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
