@@ -8,6 +8,9 @@ plan = r9_plan()
 if os.environ.get("PLAN"):   # PLAN=SB2-synth / SB1-synth: the two-rows-per-lane kernel against the LDS-grid kernel
     _, rooms, shape = next(c for c in MIXED_CLASSES if c[0] == os.environ["PLAN"])
     plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
+if os.environ.get("PLAN_ROOMS"):   # PLAN_ROOMS=10,4,19,20: rooms (rows, columns) of (height, width) -- e.g. step_band.hip's 205 x 89 plan
+    r0, r1, h, w = (int(v) for v in os.environ["PLAN_ROOMS"].split(","))
+    plan = FloorPlan.from_file_input(rectangular_floor_plan((r0, r1), (h, w)), Materials.sb1(), 10.0, 300.0)
 envs = []
 # FIRST=band / stream: that kernel (step_band.hip / step_stream.hip) instead of the library's choice, against the LDS-grid kernel
 first = {"band": "SBSIM_BAND_PATH", "stream": "SBSIM_FORCE_STREAM_PATH"}.get(os.environ.get("FIRST", ""))
