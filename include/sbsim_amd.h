@@ -362,6 +362,12 @@ int sb_shard_append(const char *dir, const char *prefix, int64_t unix_seconds, c
 
 /* Parity taps (all DEVICE outputs, float64). */
 int sb_get_temps(sb_handle *h, double *out_dev /* [B][H*W] */, void *stream);
+/* building.temp <- temps_dev [B][H*W] (DEVICE, row-major) between two steps, every device state kept: what an
+ * external process that edits the temperature array in place does to the reference -- Building.apply_convection
+ * (building.py:891-893) with a convection simulator that runs on the host (sbsim_amd/host_convection.py: the
+ * reference's seeded shuffle draw for draw, stochastic_convection_simulator.py:59-145).  The zone means follow the new
+ * grid; exterior-space cells keep their values. */
+int sb_set_temps(sb_handle *h, const double *temps_dev, void *stream);
 int sb_get_zone_temps(sb_handle *h, double *out_dev /* [B][Z] post-update means */, void *stream);
 /* [B][16]: ahu_heat_sp ahu_cool_sp ahu_flow ahu_count blr_setpoint blr_flow blr_count
  * blr_return blr_tank_temp blr_tank_change last_duration recirc cumJ_blower cumJ_ac

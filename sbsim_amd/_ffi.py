@@ -110,7 +110,7 @@ SWEEP_KERNELS = {0: "k_sweep_lds", 1: "k_sweep_reg", 2: "k_sweep_reg (two wavefr
 
 
 EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",
-           "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_convection_attach", "sb_step", "sb_step_phases", "sb_get_temps", "sb_get_zone_temps",
+           "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_convection_attach", "sb_step", "sb_step_phases", "sb_get_temps", "sb_set_temps", "sb_get_zone_temps",
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles",
            "sb_floorplan_padded_shape", "sb_floorplan_preprocess", "sb_pb_reward_info", "sb_pb_reward_response",
            "sb_pb_observation_response", "sb_pb_action_response", "sb_shard_append", "sb_pb_device_info",
@@ -153,7 +153,7 @@ def load():
   L.sb_convection_attach.argtypes = [vp, C.c_double, C.c_int32, C.c_uint64, C.c_int64, C.c_int32]
   L.sb_step.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp]
   L.sb_step_phases.argtypes = [vp, vp, C.POINTER(StepIn), vp, vp, vp, vp, C.c_int32]
-  for name in ("sb_get_temps", "sb_get_zone_temps", "sb_get_scalars", "sb_get_modes",
+  for name in ("sb_get_temps", "sb_set_temps", "sb_get_zone_temps", "sb_get_scalars", "sb_get_modes",
                "sb_get_zone_power"):
     getattr(L, name).argtypes = [vp, vp, vp]
   L.sb_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_longlong)]

@@ -188,12 +188,28 @@ class HipSimulatorBuilding:
   def __init__(self, plan: FloorPlan, config: Optional[SimConfig] = None, n_replicas: int = 1, building: int = 0,
                device: int = 0, weather=None, occupancy=None, start_timestamp=dt.datetime(2023, 7, 6, 7, 0, 0),
                holiday_calendar="us", agent_id: str = "", scenario_id: str = "",
-               air_handler_id: str = "air_handler_id", boiler_id: str = "boiler_id"):
+               air_handler_id: str = "air_handler_id", boiler_id: str = "boiler_id",
+               convection_simulator=None, reproducible_convection: bool = False):
+    """convection_simulator: host_inputs.StochasticConvectionSimulator(p, distance, seed) -- the shuffle after every
+    finite-difference update (simulator_flexible_floor_plan.py:71, 156).  By default it runs on the device
+    (statistically the reference's process); reproducible_convection=True (one building only) runs the
+    reference's seeded shuffle on the host instead, draw for draw (host_convection.py): the temperature array
+    is then bit-identical to the reference's for the same seed."""
     self.config = config or SimConfig.sb1()
+    self._host_convection = None
+    if convection_simulator is not None and reproducible_convection:
+      if n_replicas != 1:
+        raise ValueError("reproducible_convection replays ONE random stream: n_replicas must be 1")
+      from .host_convection import SeededHostConvection
+      c = convection_simulator
+      self._host_convection = SeededHostConvection(c.p, c.distance, c.seed)
+      self._rooms = [[(int(x), int(y)) for x, y in zip(*np.unravel_index(cells, plan.shape))] for cells in plan.zone_cell_lists()]
+      convection_simulator = None
     # identity normalisation: request_observations returns native values (Environment normalises them itself)
     self.env = BatchedEnvironment(plan, n_replicas, config=self.config, weather=weather, occupancy=occupancy,
                                   start_timestamp=start_timestamp, device=device, observation_normalization=None,
-                                  holiday_calendar=holiday_calendar, collect_info=True)
+                                  holiday_calendar=holiday_calendar, collect_info=True,
+                                  convection_simulator=convection_simulator)
     if self.env._occ_count is not None:
       raise ValueError("HipSimulatorBuilding takes a host-side occupancy model (one building)")
     sim = self.env.sim
@@ -311,6 +327,12 @@ class HipSimulatorBuilding:
     si.reject_dev = self._reject.data_ptr()
     self._occupancy_at_reward = float(si.occupancy)
     env.sim.step(self._actions, si, env._obs, env._reward, env._info)
+    if self._host_convection is not None:     # Building.apply_convection (building.py:891-893), the reference's own draws
+      grid = env.sim.temps()
+      host = grid[0].cpu().numpy()
+      self._host_convection.apply(self._rooms, host)
+      grid[0] = torch.from_numpy(host).to(grid.device)
+      env.sim.set_temps(grid)
     env._prev_thermostat_ts = env._now
     env._now = env._now + env._step_interval
     self._requested = False

@@ -27,7 +27,8 @@ constexpr int kGuardHost = 16; // must match kGuard in step_lds.hip
 
 // ---------------------------------------------------------------- kernels
 // Simulator.reset(): grid (either state layout), zone means, device scalars.
-__global__ void k_reset(Dev a, double initial_temp, const double *temps, int first, int steps_since_reset) {
+// temps_only (sb_set_temps): the grid inside the building and the zone means follow `temps`; every device state stays.
+__global__ void k_reset(Dev a, double initial_temp, const double *temps, int first, int steps_since_reset, int temps_only) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -41,7 +42,7 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps, int fir
         const int cs = a.cell_state[g];
         if (cs >= 0) {
           T[cs] = v;
-        } else {
+        } else if (!temps_only) {
           a.ring[(size_t)b * a.n_ring + (-cs - 1)] = v;
           rlo = fmin(rlo, v);
           rhi = fmax(rhi, v);
@@ -71,13 +72,14 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps, int fir
       if (lane == 0) {
         size_t o = (size_t)b * a.Z + z;
         a.zmean[o] = zs / (double)(b1 - b0);
+        if (temps_only) continue;
         a.zair[o] = 0.0;   // vav.py:93-99
         a.damper[o] = 0.1;
         a.mode[o] &= kModeMask; // ... the reheat valve closes; the thermostat keeps its mode
         a.qz[o] = 0.0;     // building.py:791 input_q <- 0
       }
     }
-    if (lane == 0) {
+    if (lane == 0 && !temps_only) {
       double *S = a.scal + (size_t)b * kNScal;
       S[0] = a.p.ahu_heat_sp; S[1] = a.p.ahu_cool_sp; S[2] = 0.0; S[3] = 0.0; // air_handler.py:131-139
       S[4] = a.p.blr_setpoint; S[5] = 0.0; S[6] = 0.0; S[7] = 0.0;           // boiler.py:110-121
@@ -1309,9 +1311,20 @@ int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *s
   const int wpb = 4;
   const int blocks = std::min((h->d.B + wpb - 1) / wpb, 4096);
   hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(64 * wpb), 0, (hipStream_t)stream, h->d, initial_temp,
-                     temps_dev, h->was_reset ? 0 : 1, h->steps_since_reset);
+                     temps_dev, h->was_reset ? 0 : 1, h->steps_since_reset, 0);
   h->was_reset = true;
   h->steps_since_reset = 0;
+  SB_HIP(hipGetLastError());
+  return SB_OK;
+}
+
+int sb_set_temps(sb_handle *h, const double *temps_dev, void *stream) {
+  if (!h || !temps_dev) return fail(SB_ERR_INVALID, "sb_set_temps: null argument");
+  if (!h->was_reset) return fail(SB_ERR_INVALID, "sb_set_temps: sb_reset first");
+  SB_ON_DEVICE(h->device);
+  const int wpb = 4;
+  const int blocks = std::min((h->d.B + wpb - 1) / wpb, 4096);
+  hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(64 * wpb), 0, (hipStream_t)stream, h->d, 0.0, temps_dev, 0, 0, 1);
   SB_HIP(hipGetLastError());
   return SB_OK;
 }

@@ -442,6 +442,14 @@ class BatchedSimulator:
       return t.transpose(1, 2).contiguous()
     return self._get(self._lib.sb_get_temps, (self.B, self.H, self.W), torch.float64)
 
+  def set_temps(self, temps: torch.Tensor) -> None:
+    """sb_set_temps: building.temp <- temps ([B, H, W] float64 on the device) between two steps; every
+    device state stays (what Building.apply_convection does to the reference's array, building.py:891-893)."""
+    if temps.dtype != torch.float64 or tuple(temps.shape) != (self.B, self.H, self.W):
+      raise ValueError(f"temps must be float64 [{self.B}, {self.H}, {self.W}]")
+    t = temps.transpose(1, 2).contiguous() if self.transposed else temps.contiguous()
+    _ffi.check(self._lib.sb_set_temps(self._h, C.c_void_p(t.data_ptr()), self._stream()), "sb_set_temps")
+
   def zone_temps(self) -> torch.Tensor:
     return self._get(self._lib.sb_get_zone_temps, (self.B, self.Z), torch.float64)
 

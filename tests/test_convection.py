@@ -213,3 +213,72 @@ def test_convection_attach_argument_checks():
   with pytest.raises(_ffi.SbsimError, match=r"p must be in \[0, 1\]"):
     sim.convection_attach(1.5, 5, seed=1)
   sim.close()
+
+
+def test_seeded_host_convection_replays_the_reference_draw_for_draw():
+  """host_convection.py against the reference's own seeded shuffles (oracle/gen_golden_convection_seeded.py ran
+  `StochasticConvectionSimulator(p, distance, seed).apply_convection` three times per case): the array after every
+  call is IDENTICAL -- rooms in room-dict order (first appearance in raster order), the windowed shuffle, the
+  whole-room permutation, distance -1 with p < 1 and a window wider than the rooms."""
+  from sbsim_amd.host_convection import SeededHostConvection
+  g = load("convection_seeded.npz")
+  H, W = int(g["H"]), int(g["W"])
+  rooms = [[(x, y) for x in range(x0, x0 + h) for y in range(y0, y0 + w)] for x0, y0, h, w in g["rooms"]]
+  rooms.sort(key=lambda cells: cells[0])     # building_utils.py:406-414: keys in order of first appearance
+  for ci, (p, dist, seed) in enumerate(g["cases"]):
+    sim = SeededHostConvection(p, int(dist), int(seed))
+    temp = np.arange(H * W, dtype=np.float64).reshape(H, W)
+    for k in range(g["after"].shape[1]):
+      sim.apply(rooms, temp)
+      assert np.array_equal(temp.astype(np.int32), g["after"][ci, k]), (ci, k)
+  quiet = SeededHostConvection(0.0, 5, 1)    # p == 0 / distance == 0: the reference returns early (:68-70)
+  temp = np.arange(H * W, dtype=np.float64).reshape(H, W)
+  quiet.apply(rooms, temp)
+  assert np.array_equal(temp, np.arange(H * W, dtype=np.float64).reshape(H, W))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plan_rooms,room_shape", [((3, 3), (20, 30)), ((2, 2), (5, 9)), ((8, 5), (12, 14))])
+def test_single_building_adapter_with_reproducible_convection(plan_rooms, room_shape):
+  """HipSimulatorBuilding(convection_simulator=..., reproducible_convection=True): after a step the device grid is the
+  finite-difference update's grid with the reference's seeded shuffle applied -- bit for bit (a twin adapter without
+  convection gives the grid before the shuffle) -- the zone means follow it, every device state stays, and the next
+  steps run from it.  sb_set_temps on its own: what goes in comes out, on the three state layouts."""
+  _need_gpu()
+  import torch
+  from sbsim_amd import building_adapter as ba
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  from sbsim_amd.host_convection import SeededHostConvection
+  from sbsim_amd.host_inputs import StochasticConvectionSimulator
+  plan = FloorPlan.from_file_input(rectangular_floor_plan(plan_rooms, room_shape), Materials.sb1(), 10.0, 300.0)
+  conv = StochasticConvectionSimulator(1.0, 5, seed=17)
+  a = ba.HipSimulatorBuilding(plan, holiday_calendar=None, convection_simulator=conv, reproducible_convection=True)
+  b = ba.HipSimulatorBuilding(plan, holiday_calendar=None)
+  rooms = [[(int(x), int(y)) for x, y in zip(*np.unravel_index(cells, plan.shape))] for cells in plan.zone_cell_lists()]
+  twin = SeededHostConvection(1.0, 5, 17)
+  # a non-uniform start, the same in both
+  rs = np.random.RandomState(3)
+  start = a.env.sim.temps()
+  inside = torch.tensor(~np.asarray(plan.exterior_space, dtype=bool), device="cuda")
+  start[0][inside] = torch.tensor(293.0 + rs.rand(int(inside.sum())), dtype=torch.float64, device="cuda")   # (exterior-space cells keep their values)
+  for bld in (a, b):
+    bld.env.sim.set_temps(start)
+    assert torch.equal(bld.env.sim.temps(), start)
+  a.wait_time()
+  b.wait_time()
+  before = b.env.sim.temps()[0].cpu().numpy()
+  expect = before.copy()
+  twin.apply(rooms, expect)
+  got = a.env.sim.temps()[0].cpu().numpy()
+  assert np.array_equal(got, expect) and not np.array_equal(got, before)
+  zt = a.env.sim.zone_temps()[0].cpu().numpy()
+  means = np.array([got.reshape(-1)[cells].mean() for cells in plan.zone_cell_lists()])
+  assert np.abs(zt - means).max() < 1e-11
+  assert torch.equal(a.env.sim.scalars(), b.env.sim.scalars())          # AHU / boiler state untouched by the shuffle
+  for _ in range(3):   # the next steps start from the shuffled grid, the draws go on where the last call stopped
+    a.wait_time()
+  assert np.isfinite(a.env.sim.temps().cpu().numpy()).all()
+  with pytest.raises(ValueError, match="n_replicas must be 1"):
+    ba.HipSimulatorBuilding(plan, n_replicas=2, holiday_calendar=None, convection_simulator=conv, reproducible_convection=True)
+  a.close()
+  b.close()
