@@ -311,6 +311,16 @@ int sb_floorplan_preprocess(const int8_t *floor_plan, const int8_t *zone_map, in
                             uint8_t *exterior_space, uint8_t *wall_kind, uint8_t *interior_wall,
                             int16_t *zone_label, int32_t *n_rooms);
 
+/* Thermal diffusers (thermal_diffuser_utils.py:34-262, building.py:301-345): per room of zone_label (as
+ * sb_floorplan_preprocess labels them) an evenly spaced grid of its bounding box when the room is rectangular enough,
+ * else numpy.random.default_rng(23).choice of its control volumes, reproduced bit for bit; candidates inside
+ * interior_wall are dropped; diffusers [H][W] gets 1 / n in the n cells of a room that remain, 0 elsewhere.
+ * spacing: control volumes between diffusers (10), buffer_from_walls: 3 in the reference. */
+int sb_floorplan_diffusers(const int16_t *zone_label, const uint8_t *interior_wall, int32_t H, int32_t W, int32_t n_rooms,
+                           int32_t spacing, int32_t buffer_from_walls, double *diffusers);
+/* Developer / test entry: the indices numpy.random.default_rng(seed).choice(pop, size, replace=False) returns. */
+int sb_debug_numpy_choice(uint32_t seed, int64_t pop, int64_t size, int64_t *out);
+
 /* SURVEY.md 8(f) rank 4 (second half) -- ProtoWriter-compatible episode shards, host-only:
  * the reference's four per-step messages encoded from plain arrays (proto3 wire format, no
  * protobuf library) and appended, length-prefixed, to hourly files

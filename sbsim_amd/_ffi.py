@@ -112,7 +112,7 @@ SWEEP_KERNELS = {0: "k_sweep_lds", 1: "k_sweep_reg", 2: "k_sweep_reg (two wavefr
 EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",
            "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_convection_attach", "sb_step", "sb_step_phases", "sb_get_temps", "sb_set_temps", "sb_get_zone_temps",
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles",
-           "sb_floorplan_padded_shape", "sb_floorplan_preprocess", "sb_pb_reward_info", "sb_pb_reward_response",
+           "sb_floorplan_padded_shape", "sb_floorplan_preprocess", "sb_floorplan_diffusers", "sb_debug_numpy_choice", "sb_pb_reward_info", "sb_pb_reward_response",
            "sb_pb_observation_response", "sb_pb_action_response", "sb_shard_append", "sb_pb_device_info",
            "sb_pb_zone_info", "sb_pb_variable_info", "sb_record_append", "sb_tap_pre", "sb_tap_post")
 
@@ -179,6 +179,8 @@ def load():
   L.sb_pb_variable_info.restype = C.c_int64
   L.sb_floorplan_padded_shape.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
   L.sb_floorplan_preprocess.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+  L.sb_floorplan_diffusers.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
+  L.sb_debug_numpy_choice.argtypes = [C.c_uint32, C.c_int64, C.c_int64, vp]
   _lib = L
   return L
 

@@ -93,6 +93,33 @@ class Materials:
                      exterior_wall=Material(0.05, 700.0, 1.0))
 
 
+def diffusers_native(zone_label: np.ndarray, interior_walls: np.ndarray, n_rooms: int, spacing: int = 10,
+                     buffer_from_walls: int = 3) -> np.ndarray:
+  """sb_floorplan_diffusers (csrc/floorplan.cpp): thermal_diffuser_utils.py:34-262 + building.py:301-345 for every
+  room -- the evenly spaced grid, or numpy.random.default_rng(23).choice for rooms that are not rectangular enough
+  (reproduced bit for bit in C++) -- 1 / n in each of a room's n diffuser cells."""
+  zl = np.ascontiguousarray(zone_label, dtype=np.int16)
+  iw = np.ascontiguousarray(interior_walls, dtype=np.uint8)
+  out = np.zeros(zl.shape, dtype=np.float64)
+  _ffi.check(_ffi.load().sb_floorplan_diffusers(zl.ctypes.data, iw.ctypes.data, zl.shape[0], zl.shape[1], int(n_rooms),
+                                                int(spacing), int(buffer_from_walls), out.ctypes.data), "sb_floorplan_diffusers")
+  return out
+
+
+def diffusers_numpy(zone_label: np.ndarray, interior_walls: np.ndarray, n_rooms: int, spacing: int = 10,
+                    buffer_from_walls: int = 3) -> np.ndarray:
+  """The same in NumPy (the round-3 implementation; now the cross-check of the native one in tests/)."""
+  H, W = zone_label.shape
+  diffusers = np.zeros((H, W), dtype=np.float64)
+  for z in range(n_rooms):
+    flat = np.nonzero(zone_label.reshape(-1) == z)[0]
+    cells = np.stack([flat // W, flat % W], axis=1)
+    inds = _diffuser_cells(cells, interior_walls, spacing, buffer_from_walls)
+    for x, y in inds:
+      diffusers[x, y] = 1.0 / float(len(inds))
+  return diffusers
+
+
 def _evenly_spaced(start: int, end: int, spacing: int) -> List[int]:
   """thermal_diffuser_utils.py:35-64 _evenly_spaced_inds_from_domain."""
   ind_len = end - start
@@ -172,15 +199,8 @@ class FloorPlan:
                                getattr(materials.air, prop))).astype(np.float64)
 
     if diffusers is None:
-      diffusers = np.zeros(shape, dtype=np.float64)
-      H, W = shape
-      for z in range(n_rooms):
-        flat = np.nonzero(zone_label.reshape(-1) == z)[0]
-        cells = np.stack([flat // W, flat % W], axis=1)
-        # the reference tests the *un-shrunk* interior-wall map here (building.py:751-756)
-        inds = _diffuser_cells(cells, interior_walls, diffuser_spacing, buffer_from_walls)
-        for x, y in inds:
-          diffusers[x, y] = 1.0 / float(len(inds))
+      # the reference tests the *un-shrunk* interior-wall map here (building.py:751-756)
+      diffusers = diffusers_native(zone_label, interior_walls, n_rooms, diffuser_spacing, buffer_from_walls)
     return cls(conductivity=assign("conductivity"), heat_capacity=assign("heat_capacity"),
                density=assign("density"), exterior_space=exterior_space, zone_label=zone_label,
                diffusers=np.asarray(diffusers, dtype=np.float64), cv_size_cm=float(cv_size_cm),

@@ -86,3 +86,64 @@ def test_zone_map_and_argument_checks():
     preprocess_native(np.zeros((1, 8), dtype=np.int8))
   with pytest.raises(ValueError, match="same shape"):
     preprocess_native(plan, zone_map[:-1])
+
+
+def _snake_plan(rs, H=60, W=70):
+  """A plan whose rooms include a long staircase corridor (rectangularity < 0.1: the reference's seeded random branch),
+  ordinary rooms and very small ones."""
+  plan = np.full((H, W), WALL, dtype=np.int8)
+  plan[0, :] = plan[-1, :] = plan[:, 0] = plan[:, -1] = EXTERIOR_SPACE
+  # a one-cell-wide staircase corridor across the upper part: ~ 5 % of its bounding box
+  x, y = 3, 3
+  while y < W - 6 and x < 26:
+    plan[x, y:y + 4] = INTERIOR_SPACE
+    y += 3
+    plan[x:x + 2, y] = INTERIOR_SPACE
+    x += 1
+  # rooms below it
+  top = x + 3
+  for i, (h, w) in enumerate([(18, 22), (9, 13), (3, 2), (25, 14)]):
+    y0 = 3 + sum(wd + 2 for _, wd in [(18, 22), (9, 13), (3, 2), (25, 14)][:i])
+    plan[top:min(top + h, H - 3), y0:y0 + w] = INTERIOR_SPACE
+  # a few random pillars
+  for _ in range(12):
+    px, py = rs.randint(top, H - 4), rs.randint(3, W - 4)
+    if plan[px, py] == INTERIOR_SPACE:
+      plan[px, py] = WALL
+  return plan
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("spacing,buffer", [(10, 3), (4, 0), (7, 2)])
+def test_native_diffusers_equal_the_numpy_path(seed, spacing, buffer):
+  """sb_floorplan_diffusers (thermal_diffuser_utils.py:34-262 in C++, including numpy.random.default_rng(23).choice for
+  rooms that are not rectangular enough) against the NumPy implementation it replaced -- which calls NumPy's own
+  generator -- on plans with a staircase corridor, ordinary and tiny rooms; the reference's own plans:
+  tests/test_host_golden.py."""
+  from sbsim_amd.floorplan import diffusers_native, diffusers_numpy
+  rs = np.random.RandomState(seed)
+  plan = _snake_plan(rs)
+  shape, ext, kind, iw, label, n_rooms = preprocess_native(plan)
+  cells = [np.argwhere(label == z) for z in range(n_rooms)]
+  rect = [len(c) / (max(np.ptp(c[:, 0]), 1) * max(np.ptp(c[:, 1]), 1)) for c in cells]
+  assert min(rect) < 0.1 < max(rect)          # both branches run
+  a = diffusers_native(label, iw, n_rooms, spacing, buffer)
+  b = diffusers_numpy(label, iw, n_rooms, spacing, buffer)
+  assert np.array_equal(a, b)
+  for z in range(n_rooms):                     # each room's diffusers share its power
+    s = a[label == z].sum()
+    assert s == 0.0 or abs(s - 1.0) < 1e-12
+
+
+def test_numpy_generator_restatement_known_answers():
+  """The C++ restatement of numpy.random.default_rng(seed).choice(pop, size, replace=False) (SeedSequence -> PCG64 ->
+  Lemire's bounded integers -> Floyd's sampling / the tail shuffle) against NumPy itself."""
+  import ctypes as C
+  from sbsim_amd import _ffi
+  lib = _ffi.load()
+  for seed in (23, 0, 1, 12345, 2**31 + 7):
+    for pop, size in [(1, 1), (3, 1), (10, 3), (10, 10), (137, 2), (5000, 50), (9999, 300), (10001, 100), (10001, 201),
+                      (20000, 1000), (50000, 400), (50000, 1001)]:
+      out = np.zeros(size, dtype=np.int64)
+      _ffi.check(lib.sb_debug_numpy_choice(seed, pop, size, out.ctypes.data), "sb_debug_numpy_choice")
+      assert np.array_equal(out, np.random.default_rng(seed).choice(pop, size, replace=False)), (seed, pop, size)
