@@ -120,6 +120,29 @@ def test_plan_info_for_plans_beyond_one_cu_and_the_opt_in_kernel(monkeypatch):
   assert 2 * ((band["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
 
 
+def test_plan_info_for_plans_of_131_to_258_rows(monkeypatch):
+  """Round 4: plans beyond 128 rows (up to 258, up to 96 columns inside the exterior ring) run on step_band.hip with
+  three or four wavefronts per building, one building per CU (its LDS holds A of every wavefront); SBSIM_NO_BAND_PATH=1
+  puts them back on the LDS-grid / streaming kernel; a plan wider than 96 columns both ways does not qualify."""
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  mk = lambda rooms, shape: FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
+  p4 = mk((10, 4), (19, 20))          # 205 x 89: 203 x 87 inside the ring
+  rc, i4 = _plan_info(p4, n_obs=3 * 40 + 19, n_buildings=4096)
+  assert rc == 0 and i4["path"] == 1 and i4["kernel"] == 5 and i4["waves_per_building"] == 4 == i4["waves_per_workgroup"]
+  assert i4["sweep_steps"] == 96 and i4["workgroups"] == 256 and i4["lds_bytes_per_workgroup"] <= 160 * 1024
+  rc, i3 = _plan_info(mk((10, 4), (18, 20)), n_obs=3 * 40 + 19)   # 193 x 87: three wavefronts + ONE tail row
+  assert rc == 0 and i3["kernel"] == 5 and i3["waves_per_building"] == 3 and i3["sweep_steps"] == 96 + 4
+  rc, i3b = _plan_info(mk((9, 4), (16, 17)), n_obs=3 * 36 + 19)   # 156 x 75: 76 slots
+  assert rc == 0 and i3b["kernel"] == 5 and i3b["waves_per_building"] == 3 and i3b["sweep_steps"] == 76
+  rc, it = _plan_info(p4.transposed(), n_obs=3 * 40 + 19)         # lanes = the file's columns: 87 rows x 203 columns
+  assert rc == 0 and it["kernel"] != 5
+  rc, wide = _plan_info(mk((6, 6), (24, 24)), n_obs=3 * 36 + 19)  # 153 x 153 inside the ring: too wide either way
+  assert rc == 0 and wide["kernel"] != 5
+  monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
+  rc, off = _plan_info(p4, n_obs=3 * 40 + 19)
+  assert rc == 0 and off["kernel"] == 0 and off["waves_per_building"] == 1
+
+
 def test_plan_checks_reject_bad_tables_without_a_gpu():
   """Host-side validation shared by sb_plan_info and sb_create: status codes, not crashes."""
   import numpy as np
