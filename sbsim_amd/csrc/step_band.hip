@@ -67,6 +67,13 @@ constexpr int seam_region(int NR) { return NR + 72; }                    // doub
 // Slots of the lane's grid row homed in VGPRs (the rest: AGPRs).  Up to 80 slots the row, the pair
 // buffers and the class-word ring fit the 256 registers VALU instructions can address.
 constexpr int row_vgpr_slots(int NR) { return NR <= 80 ? NR : 72; }
+// Pairs of steps whose LDS reads are in flight ahead of the arithmetic (SB_BAND_PD).  Two were no faster than one
+// (tools/band_period.py: 10.4 against 10.1 us per 96-step period; lgkmcnt counts to 15 and a pair has nine LDS
+// instructions, so the second pair's reads wait for the first's anyway) and cost 172 B of scratch at 96 slots.
+#ifndef SB_BAND_PD
+#define SB_BAND_PD 1
+#endif
+constexpr int kPD = SB_BAND_PD, kPR = kPD + 1; // ... and the ring of pair buffers
 
 typedef const double __attribute__((address_space(3))) *lds_d;
 typedef double __attribute__((address_space(3))) *lds_dw;
@@ -341,17 +348,19 @@ __device__ __forceinline__ void sync_steps(const Sync &sy, int done, int upto) {
 // Pairs S, S + 2, .. < S1 (S odd) of a block whose period started at local step tb (the block's step
 // count is tb + S); the LDS reads of the next pair are issued before the arithmetic of a pair.
 template <int NR, int NV, int S, int S1, bool ROLL, int NAR>
-__device__ __forceinline__ void run_pairs(Row<NR, NV> &e, Win &w, const ARegs<NAR> &Areg, PairBuf (&pb)[2], Ctx &x, Acc &acc,
+__device__ __forceinline__ void run_pairs(Row<NR, NV> &e, Win &w, const ARegs<NAR> &Areg, PairBuf (&pb)[kPR], Ctx &x, Acc &acc,
                                           const Sync &sy, int tb, int last_step) {
   if constexpr (S < S1) {
     if constexpr (!ROLL && S >= NR && (S - NR) % 4 == 1)
       if (S > last_step) return; // uniform: only lanes without rows are left
     if constexpr (S % kGrp == (S < 63 ? 1 : 63 % kGrp)) { // the group's last pair reads ahead for the pair after it
-      constexpr int n = (S1 - S < kGrp ? S1 - S : kGrp) + 2;
+      constexpr int n = (S1 - S < kGrp ? S1 - S : kGrp) + 2 * kPD; // the group's steps + the pairs read ahead
+#if SB_BAND_EXP != 5 // (timing experiment 5: no progress checks -- the wavefronts run free, the seam values are garbage)
       sync_steps(sy, tb + S, tb + S + n);
+#endif
     }
-    PairBuf &cur = pb[((S - 1) / 2) & 1], &nxt = pb[((S + 1) / 2) & 1];
-    if constexpr (S + 2 < NR + 63) load_pair<NR, S + 2, ROLL>(nxt, x, Areg);
+    PairBuf &cur = pb[((S - 1) / 2) % kPR], &nxt = pb[((S - 1) / 2 + kPD) % kPR];
+    if constexpr (S + 2 * kPD < NR + 63) load_pair<NR, S + 2 * kPD, ROLL>(nxt, x, Areg);
     __builtin_amdgcn_sched_barrier(0);
     step<NR, NV, S, ROLL>(e, w, cur.ud0, cur.lr0, cur.A.x, cur.rU.x, cur.rD.x, acc, x);
     __builtin_amdgcn_sched_barrier(0);
@@ -595,7 +604,7 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
 
     int n_sweeps = 0, converged = 0;
     {
-      PairBuf pb[2];
+      PairBuf pb[kPR];
       Acc acc;
       const float thr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)p.conv_threshold))); // uniform: an SGPR
       const int prev_sweeps = __builtin_amdgcn_readfirstlane(a.nsw[b] & 0xffff); // of this building's previous step
@@ -740,12 +749,12 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
           w.p = e.template get<NR - 1>();
           w.c = e.template get<0>();
           tl_mark(sy, 0xf01); // block start
-          sync_steps(sy, 0, 3); // the wavefront above's first new values must exist
+          sync_steps(sy, 0, 1 + 2 * kPD); // the wavefront above's first new values must exist
           { // step 0 (lane 0, column 0) on its own: pairs start at odd steps
             const lds_d2 st = step_set<NR, 0, false>(x);
             const d2 ud = st[0], lr = st[1];
             const double A0 = *(lds_d)(x.arow + 8u), rU0 = *(lds_d)(x.ubase + 8u * 63u), rD0 = *(lds_d)(x.dbase);
-            load_pair<NR, 1, false>(pb[0], x, Areg);
+            static_for<0, kPD>([&](auto kc) { load_pair<NR, 1 + 2 * decltype(kc)::value, false>(pb[decltype(kc)::value % kPR], x, Areg); });
             step<NR, NV, 0, false>(e, w, ud, lr, A0, rU0, rD0, acc, x);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -798,7 +807,8 @@ __global__ void __launch_bounds__(64 * kWMax) __attribute__((amdgpu_waves_per_eu
             acc.cur = -acc.neg;
             acc.neg = 0.0;
             acc.sg = lane == 0 ? (int)0x80000000 : 0;
-            load_pair<NR, 63, false>(pb[1], x, Areg); // after the tail scan: lane 63's lower neighbours are new
+            // (after the tail scan: lane 63's lower neighbours are new)
+            static_for<0, kPD>([&](auto kc) { load_pair<NR, 63 + 2 * decltype(kc)::value, false>(pb[(31 + decltype(kc)::value) % kPR], x, Areg); });
           }
           if (!overrun) {
             __builtin_amdgcn_sched_barrier(0);
