@@ -214,3 +214,42 @@ def test_hip_simulator_building_rejections_and_damper_commands():
   b.wait_time()
   assert float(b.env._reward[0]) == float("-inf")
   b.close()
+
+
+@pytest.mark.gpu
+def test_hip_simulator_building_on_a_four_wavefront_plan(monkeypatch):
+  """The single-building adapter on a 205 x 89 / 40-zone plan (step_band.hip, four wavefronts per building; one
+  building = one workgroup): request_action -> wait_time -> request_observations -> reward_info, against a second
+  adapter on the LDS-grid kernel (SBSIM_NO_BAND_PATH=1) given the same requests: sweep counts EQUAL, observations and
+  rewards equal to float32 rounding, grids within 1e-9 K."""
+  torch = pytest.importorskip("torch")
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+  from sbsim_amd import building_adapter as ba
+  from sbsim_amd.environment import SimConfig
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  plan = FloorPlan.from_file_input(rectangular_floor_plan((10, 4), (19, 20)), Materials.sb1(), 10.0, 300.0)
+  cfg = SimConfig.sb1()
+  b = ba.HipSimulatorBuilding(plan, cfg, holiday_calendar=None)
+  monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
+  ref = ba.HipSimulatorBuilding(plan, cfg, holiday_calendar=None)
+  monkeypatch.delenv("SBSIM_NO_BAND_PATH")
+  assert b.env.sim.launch_info["kernel"] == 5 and b.env.sim.launch_info["waves_per_building"] == 4
+  assert ref.env.sim.launch_info["kernel"] == 0 and len(b.zones) == 40
+  rs = np.random.RandomState(5)
+  for t in range(6):
+    sw, sa = float(rs.uniform(310.0, 350.0)), float(rs.uniform(285.0, 295.0))
+    out = []
+    for bld in (b, ref):
+      resp = bld.request_action(ba.ActionRequest(timestamp=bld.current_timestamp, single_action_requests=[
+          ba.SingleActionRequest("boiler_id", "supply_water_setpoint", sw),
+          ba.SingleActionRequest("air_handler_id", "supply_air_heating_temperature_setpoint", sa)]))
+      assert all(r.response_type == ba.ActionResponseType.ACCEPTED for r in resp.single_action_responses)
+      bld.wait_time()
+      obs = bld.request_observations(bld.observation_request_for_all_fields())
+      out.append((np.array([r.continuous_value for r in obs.single_observation_responses]), bld.last_reward, bld._info_row[4]))
+    assert out[0][2] == out[1][2] >= 1                       # Gauss-Seidel sweeps of the step
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-6, atol=1e-6) and abs(out[0][1] - out[1][1]) < 1e-6
+  assert np.abs(b.env.sim.temps().cpu().numpy() - ref.env.sim.temps().cpu().numpy()).max() < 1e-9
+  b.close()
+  ref.close()
