@@ -238,13 +238,17 @@ def test_seeded_host_convection_replays_the_reference_draw_for_draw():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("plan_rooms,room_shape", [((3, 3), (20, 30)), ((2, 2), (5, 9)), ((8, 5), (12, 14))])
-def test_single_building_adapter_with_reproducible_convection(plan_rooms, room_shape):
+@pytest.mark.parametrize("plan_rooms,room_shape,force_lds", [((3, 3), (20, 30), False), ((2, 2), (5, 9), False), ((8, 5), (12, 14), False),
+                                                            ((9, 4), (16, 17), False), ((3, 3), (20, 30), True)])
+def test_single_building_adapter_with_reproducible_convection(plan_rooms, room_shape, force_lds, monkeypatch):
   """HipSimulatorBuilding(convection_simulator=..., reproducible_convection=True): after a step the device grid is the
   finite-difference update's grid with the reference's seeded shuffle applied -- bit for bit (a twin adapter without
   convection gives the grid before the shuffle) -- the zone means follow it, every device state stays, and the next
-  steps run from it.  sb_set_temps on its own: what goes in comes out, on the three state layouts."""
+  steps run from it.  sb_set_temps on its own: what goes in comes out, on five state layouts (k_sweep_roll, k_sweep_reg,
+  k_sweep_two, k_sweep_band on three wavefronts, the LDS-grid kernel)."""
   _need_gpu()
+  if force_lds:
+    monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
   import torch
   from sbsim_amd import building_adapter as ba
   from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
