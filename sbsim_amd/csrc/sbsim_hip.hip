@@ -418,7 +418,7 @@ bool plan_band(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const s
   const int W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = plan->H * plan->W;
   auto coef = [&](int c, int j) { return plan->class_coef[c * 8 + j]; };
   int NR = 0;
-  for (int s : {76, 80, 96})
+  for (int s : {76, 80, 84, 88, 92, 96}) // the narrowest instantiation that holds the width: a period is NR steps
     if (!NR && s >= Ws && sweep_band_supported(s)) NR = s;
   if (!NR || Hs <= 64) return false;
   // wavefronts: the fewest whose rows + two tail rows hold the plan; a zone cell in a tail row needs one more
@@ -1110,7 +1110,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.pred_haste = 1.0f; d.pred_slack = 1.0f; // measured (tools/bench_two_rows.py); developer knobs: speed only,
     if (const char *e = getenv("SBSIM_DEBUG_PRED_HASTE")) d.pred_haste = (float)atof(e); // never the result
     if (const char *e = getenv("SBSIM_DEBUG_PRED_SLACK")) d.pred_slack = (float)atof(e);
-    d.pred_first = 3; // (step_band.hip: > 1 = its first block may roll on the previous step's count)
+    d.pred_first = r.P == 5 ? 2 : 3; // step_two.hip: periods a first block rolls unseen (+ 1); step_band.hip: its first block aims at the previous step's count - (pred_first - 2) (measured: 2 beats 3 and 4 by 2-4 %; 1: it never rolls unseen)
     if (const char *e = getenv("SBSIM_DEBUG_PRED_FIRST")) d.pred_first = std::max(1, atoi(e));
     SB_TRY(upload(h->zone_cells_l, plan->zone_cells, (size_t)plan->zone_off[plan->Z]));
     SB_TRY(upload(h->cmapS, r.cmapS.data(), r.cmapS.size()));

@@ -129,9 +129,12 @@ def test_plan_info_for_plans_of_131_to_258_rows(monkeypatch):
   p4 = mk((10, 4), (19, 20))          # 205 x 89: 203 x 87 inside the ring
   rc, i4 = _plan_info(p4, n_obs=3 * 40 + 19, n_buildings=4096)
   assert rc == 0 and i4["path"] == 1 and i4["kernel"] == 5 and i4["waves_per_building"] == 4 == i4["waves_per_workgroup"]
-  assert i4["sweep_steps"] == 96 and i4["workgroups"] == 256 and i4["lds_bytes_per_workgroup"] <= 160 * 1024
+  assert i4["sweep_steps"] == 88 and i4["workgroups"] == 256 and i4["lds_bytes_per_workgroup"] <= 160 * 1024   # 87 columns: 88 slots
   rc, i3 = _plan_info(mk((10, 4), (18, 20)), n_obs=3 * 40 + 19)   # 193 x 87: three wavefronts + ONE tail row
-  assert rc == 0 and i3["kernel"] == 5 and i3["waves_per_building"] == 3 and i3["sweep_steps"] == 96 + 4
+  assert rc == 0 and i3["kernel"] == 5 and i3["waves_per_building"] == 3 and i3["sweep_steps"] == 88 + 4
+  rc, i96 = _plan_info(mk((10, 4), (19, 22)), n_obs=3 * 40 + 19)  # 203 x 95: the widest instantiation
+  assert rc == 0 and i96["kernel"] == 5 and i96["waves_per_building"] == 4 and i96["sweep_steps"] == 96
+  assert i96["lds_bytes_per_workgroup"] <= 160 * 1024
   rc, i3b = _plan_info(mk((9, 4), (16, 17)), n_obs=3 * 36 + 19)   # 156 x 75: 76 slots
   assert rc == 0 and i3b["kernel"] == 5 and i3b["waves_per_building"] == 3 and i3b["sweep_steps"] == 76
   rc, it = _plan_info(p4.transposed(), n_obs=3 * 40 + 19)         # lanes = the file's columns: 87 rows x 203 columns

@@ -677,10 +677,13 @@ def _oracle_twin(plan, cfg, init_flat):
     ((14, 7), (8, 10), "rows", 4),     # 129x80: two rows per lane, 80 slots + ONE tail row
     # 131..258 rows, <= 96 columns: step_band.hip with three or four wavefronts per building (the library's choice)
     ((9, 4), (16, 17), "rows", 53),    # 156x75 inside the exterior ring: 64 + 64 + 28 rows, 76 slots
-    ((10, 4), (18, 20), "rows", 53),   # 193x87: 3 x 64 rows + ONE tail row, 96 slots (24 of them in AGPRs)
-    ((10, 4), (19, 20), "rows", 54),   # 203x87, 40 zones (VERDICT r3 #4's 200 x 90 class): 3 x 64 + 11 rows, 96 slots
+    ((10, 4), (18, 20), "rows", 53),   # 193x87: 3 x 64 rows + ONE tail row, 88 slots (16 of them in AGPRs)
+    ((10, 4), (19, 20), "rows", 54),   # 203x87, 40 zones (VERDICT r3 #4's 200 x 90 class): 3 x 64 + 11 rows, 88 slots
     ((12, 3), (20, 24), "rows", 54),   # 255x78: 3 x 64 + 63 rows, 80 slots
     ((4, 10), (20, 19), "columns", 54),  # the 203x87 plan transposed in the file: the same kernel, lanes = file columns
+    ((9, 4), (16, 19), "rows", 53),    # 156x83: 84 slots
+    ((10, 4), (18, 21), "rows", 53),   # 193x91: 92 slots + ONE tail row
+    ((10, 4), (19, 22), "rows", 54),   # 203x95: 96 slots (24 in AGPRs; the class words' read-ahead runs on across a period's end)
 ])
 def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, monkeypatch):
   """BASELINE.json configs[2] semantics: other floor-plan classes (different H x W and zone

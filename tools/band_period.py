@@ -34,7 +34,7 @@ for name, rooms, shape in [("205x89", (10, 4), (19, 20)), ("195x89", (10, 4), (1
     torch.cuda.synchronize()
     ms.append(e0.elapsed_time(e1))
   li = env.sim.launch_info
-  nr = li["sweep_steps"] - (4 if name == "195x89" else 0)
+  nr = li["sweep_steps"] - (4 if name == "195x89" else 0)   # (the 195 x 89 plan has a tail row: + 4 steps)
   per = np.mean(ms[2:]) * 1e3 / LIMIT
   print(f"{name}: kernel {li['kernel']}, {li['waves_per_building']} wavefronts, sweeps {float(env._info[:, 4].mean()):.0f}: {per:.2f} us per sweep = "
         f"{per / nr * 1e3:.0f} ns per step of {nr} (at 2.4 GHz: {per / nr * 2.4e3:.0f} cycles)", flush=True)

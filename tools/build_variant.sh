@@ -3,7 +3,7 @@
 # Re-compiles the named translation units with extra flags and links them with the product's other objects into
 # tools/libexp_<name>.so (git-ignored, travels to the GPU box); run with SBSIM_LIB=$PWD/tools/libexp_<name>.so.
 # e.g. the cycle stamps of tools/prof_sweeps.py / tools/bench_two_rows.py (SBSIM_PHASE_TIMING=1):
-#   tools/build_variant.sh stamps step_roll.hip,step_two_76.hip,step_two_80.hip,step_band.hip -DSB_PHASE_STAMPS
+#   tools/build_variant.sh stamps step_roll.hip,step_two_76.hip,step_two_80.hip,step_band_76.hip,step_band_80.hip,step_band_84.hip,step_band_88.hip,step_band_92.hip,step_band_96.hip -DSB_PHASE_STAMPS
 set -e
 name=$1; srcs=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -18,7 +18,7 @@ for src in ${srcs//,/ }; do
 done
 wait
 objs=""
-for o in sbsim_hip step_reg step_roll step_two step_two_76 step_two_80 step_band step_stream step_lds generators floorplan episode; do
+for o in sbsim_hip step_reg step_roll step_two step_two_76 step_two_80 step_band step_band_76 step_band_80 step_band_84 step_band_88 step_band_92 step_band_96 step_stream step_lds generators floorplan episode; do
   case " $bases " in *" $o "*) objs="$objs $obj/${o}_$name.o";; *) objs="$objs $obj/$o.o";; esac
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $root/tools/libexp_$name.so

@@ -86,7 +86,7 @@ bash $PWD/tools/pmc_sweep.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY S
   "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
   "SQ_WAVES SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_MISSES" > $out/pmc_sq.txt 2>&1
 # cycle stamps of one building's phases inside the sweep kernel, and the per-sweep / fixed cost split
-# (the stamps are compiled in with -DSB_PHASE_STAMPS only: tools/build_variant.sh stamps step_roll.hip,step_two_76.hip,step_two_80.hip,step_band.hip -DSB_PHASE_STAMPS)
+# (the stamps are compiled in with -DSB_PHASE_STAMPS only: tools/build_variant.sh stamps step_roll.hip,step_two_76.hip,step_two_80.hip,step_band_76.hip,...,step_band_96.hip -DSB_PHASE_STAMPS)
 [ -f $PWD/tools/libexp_stamps.so ] && SBSIM_LIB=$PWD/tools/libexp_stamps.so SBSIM_PHASE_TIMING=1 LIMS=1,2,4 timeout 600 python $PWD/tools/prof_sweeps.py 2>&1 | grep -v amdgpu.ids > $out/phase_cycles.txt
 # the same bench after 100 warm-up steps: the steady state beside the driver's transient window
 timeout 600 python $PWD/bench.py --steps 20 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_steady.json
