@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 6
+#define SB_ABI_VERSION 7
 #define SB_NUM_ACTIONS 2   /* the SB1 action set (sim_config.gin:239-242): boiler supply_water_setpoint, AHU
                             * supply_air_heating_temperature_setpoint -- the default of sb_params.n_actions */
 #define SB_ACTION_KEEP (-3.0e38f)

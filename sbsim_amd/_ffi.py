@@ -14,7 +14,7 @@ SB_NUM_ACTIONS = 2     # the SB1 action set; sb_params.n_actions is the width of
 SB_MAX_ACTIONS = 16
 SB_ACTION_KEEP = -3.0e38   # sb_step_in.actions_native: this column leaves its field alone
 SB_NUM_AUX = 7
-SB_ABI_VERSION = 6   # include/sbsim_amd.h
+SB_ABI_VERSION = 7   # include/sbsim_amd.h
 # sb_action_kind
 SB_ACT_BOILER_SUPPLY_WATER_SETPOINT, SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT = 0, 1
 SB_ACT_AHU_SUPPLY_AIR_COOLING_SETPOINT, SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND = 2, 3
