@@ -684,8 +684,10 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   if (Hs > 64 + 2 && env_flag("SBSIM_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   // mode 4: one wavefront, two rows per lane (67..130 rows, <= 80 columns)
   if (Hs > 64 + 2 && !env_flag("SBSIM_NO_TWO_ROW_PATH") && plan_two(plan, Hs, Ws, x0, y0, zone_of, r)) return;
-  // mode 5 again: beyond 128 rows (up to 258, <= 96 columns) three or four wavefronts share a building
-  if (Hs > 128 && !env_flag("SBSIM_NO_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
+  // mode 5 again, for what mode 4 does not hold: beyond 128 rows (up to 258) three or four wavefronts share a
+  // building; 67..130 rows with 81..96 columns two (measured 1.2-2.6x the two-wavefront k_sweep_reg / the LDS-grid
+  // kernel on 109 x 92, 113 x 93 and 125 x 97: tools/bench_mid_plans.py)
+  if (Hs > 64 + 2 && !env_flag("SBSIM_NO_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   auto pick_slots = [&](int mode) { // narrowest instantiation that holds the width and the class count
     for (int s : kRegSlots) {
       if (mode == 3) {

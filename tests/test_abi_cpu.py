@@ -141,7 +141,11 @@ def test_plan_info_for_plans_of_131_to_258_rows(monkeypatch):
   assert rc == 0 and it["kernel"] != 5
   rc, wide = _plan_info(mk((6, 6), (24, 24)), n_obs=3 * 36 + 19)  # 153 x 153 inside the ring: too wide either way
   assert rc == 0 and wide["kernel"] != 5
+  rc, w2 = _plan_info(mk((6, 4), (17, 21)), n_obs=3 * 24 + 19, n_buildings=4096)   # 111 x 91: too wide for step_two.hip -> two wavefronts, 92 slots
+  assert rc == 0 and w2["kernel"] == 5 and w2["waves_per_building"] == 2 and w2["sweep_steps"] == 92 and w2["workgroups"] == 512
   monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")
+  rc, w2off = _plan_info(mk((6, 4), (17, 21)), n_obs=3 * 24 + 19)
+  assert rc == 0 and w2off["kernel"] == 2
   rc, off = _plan_info(p4, n_obs=3 * 40 + 19)
   assert rc == 0 and off["kernel"] == 0 and off["waves_per_building"] == 1
 

@@ -73,7 +73,8 @@ def test_one_day_rollout_against_reference_golden(tag, kernel, monkeypatch):
   if kernel.startswith("lds"):
     monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
   if kernel == "reg-pair":
-    monkeypatch.setenv("SBSIM_NO_TWO_ROW_PATH", "1")   # the library's own choice for 96 x 66 is "reg-two"
+    monkeypatch.setenv("SBSIM_NO_TWO_ROW_PATH", "1")   # the library's own choice for 96 x 66 is "reg-two",
+    monkeypatch.setenv("SBSIM_NO_BAND_PATH", "1")      # without it step_band.hip on two wavefronts ("reg-band")
   if kernel == "reg-band":
     monkeypatch.setenv("SBSIM_BAND_PATH", "1")
   sim = BatchedSimulator(_plan(load("plan_r9_sb1.npz")), SimConfig.sb1(), B, float(g["h_conv"]),
@@ -652,7 +653,7 @@ def _oracle_twin(plan, cfg, init_flat):
 
 @pytest.mark.parametrize("rooms,room_shape,orientation,path", [
     ((8, 5), (12, 14), "auto", 0),     # "SB2-synth": 40 zones, 109x80 grid, 51 cell classes -> LDS grid (2 per CU, as many as the register variant)
-    ((6, 4), (17, 21), "rows", 1),     # 107x89 inside the ring, 24 zones, > 31 cell classes -> registers, 2 waves, 64-entry tables
+    ((6, 4), (17, 21), "rows", 1),     # 111x91 inside the exterior ring, 24 zones, > 31 cell classes -> registers: step_band.hip on two wavefronts, 92 slots (until round 4: k_sweep_reg on two)
     ((4, 3), (25, 28), "rows", 0),     # 109x92: two of them fit a CU's LDS -> LDS grid preferred over the 96-slot pair variant
     ((14, 9), (8, 7), "auto", 0),      # "SB1-synth": 126 zones (the real SB1's VAV count), 131x78 grid, 3 bands
     ((2, 3), (9, 10), "rows", 1),      # small: 22x34 inside the ring -> registers, 1 wave, 66 slots

@@ -1,6 +1,7 @@
-"""Developer aid: floor plans of 131..258 rows -- step_band.hip (three / four wavefronts per building) against the
-kernel such a plan ran on before (step_lds.hip: one wavefront per building, SBSIM_NO_BAND_PATH=1): sweep-kernel
-time per step and cell-sweeps/s.  Usage (GPU box): python tools/bench_mid_plans.py"""
+"""Developer aid: the floor plans step_band.hip runs by the library's choice -- 131..258 rows (three / four wavefronts
+per building) and 67..130 rows with 81..96 columns (two) -- against the kernel such a plan ran on before
+(SBSIM_NO_BAND_PATH=1: step_lds.hip, step_stream.hip or k_sweep_reg on two wavefronts): sweep-kernel time per step
+and cell-sweeps/s.  Usage (GPU box): python tools/bench_mid_plans.py"""
 import ctypes
 import os
 import sys
@@ -19,10 +20,12 @@ WARM = int(os.environ.get("WARM", "3"))   # steps before the timed ones (the swe
 B = int(os.environ.get("B", "4096"))
 ONLY = os.environ.get("PLANS")   # e.g. PLANS=0,1
 PLANS = [("205x89 / 40 zones", (10, 4), (19, 20)), ("195x89 / 40 zones", (10, 4), (18, 20)), ("158x77 / 36 zones", (9, 4), (16, 17)),
-         ("257x80 / 36 zones", (12, 3), (20, 24))]
+         ("257x80 / 36 zones", (12, 3), (20, 24)),
+         # 67..130 rows, 81..96 columns: two wavefronts per building (before: k_sweep_reg on two wavefronts / the LDS-grid kernel)
+         ("113x93 / 24 zones", (6, 4), (17, 21)), ("125x97 / 20 zones", (5, 4), (23, 22)), ("109x92 / 12 zones", (4, 3), (25, 28))]
 for name, rooms, shape in [p for i, p in enumerate(PLANS) if ONLY is None or str(i) in ONLY.split(",")]:
   rates = {}
-  for label, flag in (("step_band", None), ("step_lds", "SBSIM_NO_BAND_PATH"))[:1 if os.environ.get("BAND_ONLY") else 2]:
+  for label, flag in (("step_band", None), ("before", "SBSIM_NO_BAND_PATH"))[:1 if os.environ.get("BAND_ONLY") else 2]:
     if flag:
       os.environ[flag] = "1"
     plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
@@ -71,5 +74,5 @@ for name, rooms, shape in [p for i, p in enumerate(PLANS) if ONLY is None or str
     env.close()
   if os.environ.get("BAND_ONLY"):
     continue
-  same = bool((rates["step_band"][1] == rates["step_lds"][1]).all())
-  print(f"{name}: step_band / step_lds = {rates['step_band'][0] / rates['step_lds'][0]:.2f}x; sweep counts of all {B} buildings x {K} steps equal: {same}", flush=True)
+  same = bool((rates["step_band"][1] == rates["before"][1]).all())
+  print(f"{name}: step_band / before = {rates['step_band'][0] / rates['before'][0]:.2f}x; sweep counts of all {B} buildings x {K} steps equal: {same}", flush=True)
