@@ -699,6 +699,11 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   // mode 1: one wavefront; mode 3: one wavefront + one or two tail rows finished by a scan
   // (no zone cell may sit in a tail row); mode 2: two wavefronts
   int P = Hs <= 64 ? 1 : 0, NR = P ? pick_slots(1) : 0;
+  // ... but not on k_sweep_reg<NR,1> (round 1's kernel: a sweep of NR + rows - 1 steps, no overlap) when k_sweep_roll's
+  // period is no longer than that: the roll kernel without tail rows, the lanes beyond the plan own pad rows
+  // (measured, 65,536 buildings: 47 x 98 / 6 zones 6.8 -> 1.9 ms per step, 62 x 97 4.8 -> 2.5, 49 x 50 8.9 -> 7.6;
+  // 25 x 38 and 17 x 25 stay: 3.3 against 4.4, 2.6 against 4.9)
+  if (P == 1 && NR && !env_flag("SBSIM_NO_ROLL_SMALL") && pick_slots(3) && NR + Hs - 1 >= pick_slots(3)) { P = 3; NR = pick_slots(3); }
   if (!P && Hs <= 64 + 2 && pick_slots(3)) {
     bool zone_free = true;
     for (int x = x0 + 64; x <= x1; ++x)
@@ -726,7 +731,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
     return;
   }
   r.NR = NR; r.P = P; r.RS = RS; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
-  r.T = P == 3 ? Hs - 64 : 0;
+  r.T = P == 3 ? std::max(0, Hs - 64) : 0;
   r.state_doubles = NR * RS + r.T * NR;
   const int maxch = (NR + 63 + 7) / 8;
   if (P == 3) {
@@ -873,7 +878,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
           const int j = 4 * g + k;
           const int col = ((j - lp) % NR + NR) % NR;
           int z = Z; // dump row
-          if (valid && j < NR && col < Ws) {
+          if (valid && R < Hs && j < NR && col < Ws) { // (mode 3 below 64 rows: the lanes beyond the plan own pad rows)
             const int zz = zone_of[(x0 + R) * W + (y0 + col)];
             if (zz >= 0) z = zz;
           }

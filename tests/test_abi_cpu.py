@@ -85,6 +85,11 @@ def test_plan_info_picks_the_step_kernel_without_a_gpu():
   small = FloorPlan.from_file_input(rectangular_floor_plan((1, 2), (6, 8)), Materials.sb1(), 10.0, 300.0)
   rc, one = _plan_info(small)
   assert rc == 0 and one["path"] == 1 and one["waves_per_building"] == 1 and one["kernel"] == 1
+  # a plan of <= 64 rows whose k_sweep_reg sweep (NR + rows - 1 steps) is at least as long as k_sweep_roll's 96-step
+  # period runs on k_sweep_roll without tail rows (round 4): 45 x 96 inside the ring
+  wide = FloorPlan.from_file_input(rectangular_floor_plan((2, 3), (20, 30)), Materials.sb1(), 10.0, 300.0)
+  rc, wr = _plan_info(wide)
+  assert rc == 0 and wr["kernel"] == 3 and wr["waves_per_workgroup"] == 4 and wr["sweep_steps"] == 96
 
 
 def test_plan_info_for_plans_beyond_one_cu_and_the_opt_in_kernel(monkeypatch):

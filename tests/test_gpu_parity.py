@@ -659,10 +659,11 @@ def _oracle_twin(plan, cfg, init_flat):
     ((2, 3), (9, 10), "rows", 1),      # small: 22x34 inside the ring -> registers, 1 wave, 66 slots
     ((5, 1), (12, 10), "generic", 0),  # H > 64, narrow grid, forced onto the generic (all-LDS) sweep
     ((2, 2), (5, 9), "rows", 1),       # 15x23 inside the ring -> registers, 1 wave, 32 slots
-    ((2, 3), (20, 30), "rows", 1),     # 45x96 -> registers, 1 wave, 96 slots
+    ((2, 3), (20, 30), "rows", 30),    # 45x96 -> k_sweep_roll without tail rows (lanes 45..63 own pad rows); until round 4: k_sweep_reg, 96 slots
     ((2, 5), (30, 12), "columns", 1),  # transposed 68x65 -> registers, 2 waves (uneven split), 66 slots
     ((2, 3), (30, 30), "rows", 1),     # 65x96 -> registers, 1 wave + ONE tail row
-    ((4, 5), (10, 8), "rows", 1),      # 47x48, 20 zones -> registers, zone reduce in two 16-zone passes
+    ((4, 5), (10, 8), "rows", 30),     # 47x48, 20 zones -> k_sweep_roll too (its 96-step period against a 112-step sweep of k_sweep_reg)
+    ((4, 5), (10, 8), "rows", 31),     # ... and on k_sweep_reg (SBSIM_NO_ROLL_SMALL=1): zone reduce in two 16-zone passes
     ((4, 2), (30, 17), "columns", 0),  # the same family on the LDS-grid kernel, lanes = columns
     # 67..130 rows, <= 80 columns: step_two.hip (path 4: one wavefront, two rows per lane) is the library's
     # choice; step_band.hip (path 5: two wavefronts, one row per lane) sits behind SBSIM_BAND_PATH=1
@@ -692,7 +693,12 @@ def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, 
   kernel, 1 the library's choice among the register kernels, 4 / 5 that kernel (sb_sweep_kernel)."""
   from sbsim_amd.floorplan import rectangular_floor_plan
   kern, waves = None, None
-  if path >= 50:      # 53 / 54: step_band.hip by the library's own choice, three / four wavefronts per building
+  if path == 31:      # k_sweep_reg<NR,1> where the library would take k_sweep_roll
+    monkeypatch.setenv("SBSIM_NO_ROLL_SMALL", "1")
+    kern, path = 1, 1
+  elif path == 30:    # k_sweep_roll by the library's own choice (a plan of <= 64 rows)
+    kern, path = 3, 1
+  elif path >= 50:      # 53 / 54: step_band.hip by the library's own choice, three / four wavefronts per building
     kern, waves, path = 5, path - 50, 1
   elif path >= 4:
     kern, path = path, 1
