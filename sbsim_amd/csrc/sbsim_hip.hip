@@ -689,11 +689,13 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   // kernel on 109 x 92, 113 x 93 and 125 x 97: tools/bench_mid_plans.py)
   if (Hs > 64 + 2 && !env_flag("SBSIM_NO_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   auto pick_slots = [&](int mode) { // narrowest instantiation that holds the width and the class count
-    for (int s : kRegSlots) {
-      if (mode == 3) {
-        if (s >= Ws && sweep_roll_supported(s) && ncls + 1 <= 32) return s;
-      } else if (s >= Ws && sweep_reg_supported(s, mode) && ncls + 1 <= sweep_reg_table_stride(s, mode)) return s;
+    if (mode == 3) {
+      for (int s : {64, 96})
+        if (s >= Ws && sweep_roll_supported(s) && ncls + 1 <= 32 && !(s == 64 && env_flag("SBSIM_NO_ROLL_64"))) return s;
+      return 0;
     }
+    for (int s : kRegSlots)
+      if (s >= Ws && sweep_reg_supported(s, mode) && ncls + 1 <= sweep_reg_table_stride(s, mode)) return s;
     return 0;
   };
   // mode 1: one wavefront; mode 3: one wavefront + one or two tail rows finished by a scan

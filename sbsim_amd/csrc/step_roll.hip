@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
 
 } // namespace
 
-bool sweep_roll_supported(int NR) { return NR == 96; }
+bool sweep_roll_supported(int NR) { return NR == 64 || NR == 96; }
 int sweep_roll_lds_slots(int NR) { return lds_slots(NR); }
 int sweep_roll_a_stride(int NR) { return a_stride(NR); }
 int sweep_roll_seam_doubles(int NR, int T) { (void)T; return tail_row(NR); } // the first tail row, by column
@@ -649,31 +649,47 @@ int sweep_roll_waves() { return kWaves; }
 
 int sweep_roll_redo_workgroups() { return 8; } // the exact kernel's launch on the redo list (a handful of buildings per step at most)
 
-int prepare_sweep_roll(const Dev &d) {
-  if (d.NR != 96) return (int)hipErrorInvalidValue;
-  const int e = (int)hipFuncSetAttribute((const void *)k_sweep_roll<96, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+namespace {
+
+template <int NR>
+int prepare(const Dev &d) {
+  const int e = (int)hipFuncSetAttribute((const void *)k_sweep_roll<NR, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          d.lds_reg_bytes);
   if (e != (int)hipSuccess) return e;
-  return (int)hipFuncSetAttribute((const void *)k_sweep_roll<96, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  return (int)hipFuncSetAttribute((const void *)k_sweep_roll<NR, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   d.lds_reg_bytes);
 }
 
 // The fast kernel, then the exact one on whatever the fast one could not decide (it returns at once when the
 // list is empty).  d.roll_exact (SBSIM_ROLL_EXACT=1): the exact kernel alone, on every building.
-int launch_sweep_roll(const Dev &d, hipStream_t stream) {
-  if (d.NR != 96) return (int)hipErrorInvalidValue;
+template <int NR>
+int launch(const Dev &d, hipStream_t stream) {
   const dim3 grid((d.sweep_wgs + kWaves - 1) / kWaves), block(64 * kWaves);
   if (d.roll_exact) {
-    hipLaunchKernelGGL((k_sweep_roll<96, true>), grid, block, (size_t)d.lds_reg_bytes, stream, d);
+    hipLaunchKernelGGL((k_sweep_roll<NR, true>), grid, block, (size_t)d.lds_reg_bytes, stream, d);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL((k_sweep_roll<96, false>), grid, block, (size_t)d.lds_reg_bytes, stream, d);
+  hipLaunchKernelGGL((k_sweep_roll<NR, false>), grid, block, (size_t)d.lds_reg_bytes, stream, d);
   Dev r = d;
   r.redo_mode = 1;
   r.next_b = d.redo_ctr + 1;
   r.sweep_wgs = sweep_roll_redo_workgroups() * kWaves;
-  hipLaunchKernelGGL((k_sweep_roll<96, true>), dim3(sweep_roll_redo_workgroups()), block, (size_t)d.lds_reg_bytes, stream, r);
+  hipLaunchKernelGGL((k_sweep_roll<NR, true>), dim3(sweep_roll_redo_workgroups()), block, (size_t)d.lds_reg_bytes, stream, r);
   return (int)hipGetLastError();
+}
+
+} // namespace
+
+int prepare_sweep_roll(const Dev &d) {
+  if (d.NR == 96) return prepare<96>(d);
+  if (d.NR == 64) return prepare<64>(d);
+  return (int)hipErrorInvalidValue;
+}
+
+int launch_sweep_roll(const Dev &d, hipStream_t stream) {
+  if (d.NR == 96) return launch<96>(d, stream);
+  if (d.NR == 64) return launch<64>(d, stream);
+  return (int)hipErrorInvalidValue;
 }
 
 } // namespace sb

@@ -90,6 +90,11 @@ def test_plan_info_picks_the_step_kernel_without_a_gpu():
   wide = FloorPlan.from_file_input(rectangular_floor_plan((2, 3), (20, 30)), Materials.sb1(), 10.0, 300.0)
   rc, wr = _plan_info(wide)
   assert rc == 0 and wr["kernel"] == 3 and wr["waves_per_workgroup"] == 4 and wr["sweep_steps"] == 96
+  # ... and plans of <= 64 columns on its 64-slot instantiation: 47 x 48 (k_sweep_reg: 66 + 46 steps per sweep)
+  narrow = FloorPlan.from_file_input(rectangular_floor_plan((4, 5), (10, 8)), Materials.sb1(), 10.0, 300.0)
+  rc, nr = _plan_info(narrow, n_obs=3 * 20 + 19)
+  assert rc == 0 and nr["kernel"] == 3 and nr["waves_per_workgroup"] == 4 and nr["sweep_steps"] == 64
+  assert nr["lds_bytes_per_workgroup"] <= 160 * 1024   # four buildings per workgroup, one workgroup per CU
 
 
 def test_plan_info_for_plans_beyond_one_cu_and_the_opt_in_kernel(monkeypatch):

@@ -662,7 +662,9 @@ def _oracle_twin(plan, cfg, init_flat):
     ((2, 3), (20, 30), "rows", 30),    # 45x96 -> k_sweep_roll without tail rows (lanes 45..63 own pad rows); until round 4: k_sweep_reg, 96 slots
     ((2, 5), (30, 12), "columns", 1),  # transposed 68x65 -> registers, 2 waves (uneven split), 66 slots
     ((2, 3), (30, 30), "rows", 1),     # 65x96 -> registers, 1 wave + ONE tail row
-    ((4, 5), (10, 8), "rows", 30),     # 47x48, 20 zones -> k_sweep_roll too (its 96-step period against a 112-step sweep of k_sweep_reg)
+    ((4, 5), (10, 8), "rows", 30),     # 47x48, 20 zones -> k_sweep_roll<64> (its 64-step period against a 112-step sweep of k_sweep_reg)
+    ((4, 5), (10, 8), "rows", 32),     # ... and on k_sweep_roll<96> (SBSIM_NO_ROLL_64=1)
+    ((2, 2), (30, 29), "rows", 30),    # 65x63 -> k_sweep_roll<64> + ONE tail row
     ((4, 5), (10, 8), "rows", 31),     # ... and on k_sweep_reg (SBSIM_NO_ROLL_SMALL=1): zone reduce in two 16-zone passes
     ((4, 2), (30, 17), "columns", 0),  # the same family on the LDS-grid kernel, lanes = columns
     # 67..130 rows, <= 80 columns: step_two.hip (path 4: one wavefront, two rows per lane) is the library's
@@ -696,7 +698,10 @@ def test_mixed_floor_plans_against_oracle(rooms, room_shape, orientation, path, 
   if path == 31:      # k_sweep_reg<NR,1> where the library would take k_sweep_roll
     monkeypatch.setenv("SBSIM_NO_ROLL_SMALL", "1")
     kern, path = 1, 1
-  elif path == 30:    # k_sweep_roll by the library's own choice (a plan of <= 64 rows)
+  elif path == 30:    # k_sweep_roll by the library's own choice (a plan of <= 66 rows)
+    kern, path = 3, 1
+  elif path == 32:    # the 96-slot instantiation where the library would take the 64-slot one
+    monkeypatch.setenv("SBSIM_NO_ROLL_64", "1")
     kern, path = 3, 1
   elif path >= 50:      # 53 / 54: step_band.hip by the library's own choice, three / four wavefronts per building
     kern, waves, path = 5, path - 50, 1
