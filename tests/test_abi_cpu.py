@@ -95,6 +95,11 @@ def test_plan_info_picks_the_step_kernel_without_a_gpu():
   rc, nr = _plan_info(narrow, n_obs=3 * 20 + 19)
   assert rc == 0 and nr["kernel"] == 3 and nr["waves_per_workgroup"] == 4 and nr["sweep_steps"] == 64
   assert nr["lds_bytes_per_workgroup"] <= 160 * 1024   # four buildings per workgroup, one workgroup per CU
+  # 65..80 columns: the 80-slot instantiation (72 of its A slots in LDS, like the 96-slot one); 65 x 78: + one tail row
+  for shape, steps in (((20, 24), 80), ((30, 24), 84)):
+    mid = FloorPlan.from_file_input(rectangular_floor_plan((2, 3), shape), Materials.sb1(), 10.0, 300.0)
+    rc, mr = _plan_info(mid)
+    assert rc == 0 and mr["kernel"] == 3 and mr["sweep_steps"] == steps and mr["lds_bytes_per_workgroup"] <= 160 * 1024
 
 
 def test_plan_info_for_plans_beyond_one_cu_and_the_opt_in_kernel(monkeypatch):
