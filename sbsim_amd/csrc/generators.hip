@@ -153,7 +153,8 @@ constexpr int kConvMaxTries = 1 << 14; // partner candidates of a wide-window dr
 // Room-major: the lane keeps its cells' table entries in registers while the workgroup walks
 // through its share of the buildings.
 template <int Q>
-__global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
+__global__ void __launch_bounds__(kConvMaxThreads) __attribute__((amdgpu_waves_per_eu(Q <= 2 ? 8 : Q == 3 ? 6 : Q == 4 ? 4 : 2)))
+k_convect(ConvArgs o) {
   const int kConvThreads = blockDim.x;
   extern __shared__ __attribute__((aligned(16))) unsigned long long conv_lds[];
   uint2 *rec = (uint2 *)conv_lds;                // [max_room] {stamp, other | next << 16}
@@ -167,79 +168,86 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
     const int c0 = o.zone_off[z], n = o.zone_off[z + 1] - c0;
     // the lane's cells: what every building needs of them, in registers (the rest of a ConvCell -- its index in the
     // handle's grid -- only the wide-window path reads, from memory: eight waves per SIMD need <= 64 registers)
-    int c_g0[Q], c_sidx[Q], c_rank[Q], c_cnt[Q];
+    int c_g0[Q], c_sidx[Q], c_rc[Q]; // c_rc: the cell's rank in its room | its partner count << 16
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const int i = tid + q * kConvThreads;
       const ConvCell c = o.cells[c0 + (i < n ? i : 0)];
-      c_g0[q] = c.g0; c_sidx[q] = c.sidx; c_rank[q] = c.pad; c_cnt[q] = __popcll(c.mask);
+      c_g0[q] = c.g0; c_sidx[q] = c.sidx; c_rc[q] = c.pad | (__popcll(c.mask) << 16);
     }
     for (int i = tid; i < n; i += kConvThreads) head[i] = kConvEnd; // (re-armed with every building's store phase)
     __syncthreads();
+    // the draws of a building -- its values (HBM), the partner (a table read: L1 / L2), the time stamps: the Q reads of
+    // a lane are in flight together, and the NEXT building's are issued before this building's follow phase (which
+    // waits for LDS only), so a building's memory latency hides behind its predecessor's pointer chase
+    auto draw = [&](int b, double (&val)[Q], int (&oth)[Q]) {
+      const double *st = o.temp + (size_t)b * o.stride;
+      const uint32_t stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int i = tid + q * kConvThreads;
+          oth[q] = i;
+          if (i < n) {
+            val[q] = st[c_sidx[q]];
+            const uint32_t key = stream ^ ((uint32_t)c_g0[q] * 0x9E3779B1u);
+            const double u = (double)(conv_word(key, 0) >> 8) * (1.0 / 16777216.0);
+            int other = i;
+            if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table: the partner by rejection --
+              // uniform over the reference's candidate list (:122-131; the cell itself is a candidate)
+              const int span = 2 * o.wide_r + 1, W0 = o.transposed ? o.H : o.W; // W0: row length of the caller's grid
+              if (n < span * span) { // the room has fewer cells than the window's box: a cell of the room (by rank), kept when inside the disc
+                const int x0 = c_g0[q] / W0, y0 = c_g0[q] - x0 * W0;
+                for (int k = 2; k < kConvMaxTries; ++k) {
+                  const int j = o.by_rank[c0 + (int)(((unsigned long long)conv_word(key, (uint32_t)k) * (unsigned long long)n) >> 32)];
+                  const int gj = o.cells[c0 + j].g0, dx = gj / W0 - x0, dy = gj - (gj / W0) * W0 - y0;
+                  if (dx * dx + dy * dy <= o.wide_d) { other = j; break; }
+                }
+              } else { // a square of the box, kept when inside the disc and in the room
+                const int gh = o.cells[c0 + i].gh, xh = gh / o.W, yh = gh - xh * o.W;
+                for (int k = 2; k < kConvMaxTries; ++k) {
+                  const uint32_t w = conv_word(key, (uint32_t)k);
+                  const int dx = (int)(((w & 0xffffu) * (uint32_t)span) >> 16) - o.wide_r;
+                  const int dy = (int)(((w >> 16) * (uint32_t)span) >> 16) - o.wide_r;
+                  const int hx = xh + (o.transposed ? dy : dx), hy = yh + (o.transposed ? dx : dy);
+                  if (dx * dx + dy * dy <= o.wide_d && hx >= 0 && hx < o.H && hy >= 0 && hy < o.W && (int)o.room[hx * o.W + hy] == z) {
+                    other = o.local[hx * o.W + hy];
+                    break;
+                  }
+                }
+              }
+            } else if (!(u > o.p)) { // :119: uniform over the room's cells inside the offset window -- the cell's own
+              // partner list (the valid offsets in (dx, dy) raster order, as list indices; built by sb_convection_attach)
+              const int cnt = c_rc[q] >> 16;
+              const int pick = (int)(((unsigned long long)conv_word(key, 2) * (unsigned long long)cnt) >> 32);
+              other = (int)o.partner[(size_t)(c0 + i) * (size_t)o.pw + (size_t)pick];
+            }
+            oth[q] = other;
+          }
+        }
+    };
+    double val[Q], val_n[Q];
+    int oth[Q], oth_n[Q];
+    if ((int)blockIdx.x < o.B) draw(blockIdx.x, val, oth);
     for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
       double *st = o.temp + (size_t)b * o.stride;
       const uint32_t stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call);
-      double val[Q];
-      int oth[Q];
-      uint32_t stamp[Q];
-      // the draws first -- the partner is a table read (L1 / L2): the Q reads of a lane are in flight together
-      // -- then the records and the list links (LDS atomics)
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int i = tid + q * kConvThreads;
-        oth[q] = i;
-        stamp[q] = 0;
-        if (i < n) {
-          val[q] = st[c_sidx[q]];
-          const uint32_t key = stream ^ ((uint32_t)c_g0[q] * 0x9E3779B1u);
-          const double u = (double)(conv_word(key, 0) >> 8) * (1.0 / 16777216.0);
-          int other = i;
-          if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table: the partner by rejection --
-            // uniform over the reference's candidate list (:122-131; the cell itself is a candidate)
-            const int span = 2 * o.wide_r + 1, W0 = o.transposed ? o.H : o.W; // W0: row length of the caller's grid
-            if (n < span * span) { // the room has fewer cells than the window's box: a cell of the room (by rank), kept when inside the disc
-              const int x0 = c_g0[q] / W0, y0 = c_g0[q] - x0 * W0;
-              for (int k = 2; k < kConvMaxTries; ++k) {
-                const int j = o.by_rank[c0 + (int)(((unsigned long long)conv_word(key, (uint32_t)k) * (unsigned long long)n) >> 32)];
-                const int gj = o.cells[c0 + j].g0, dx = gj / W0 - x0, dy = gj - (gj / W0) * W0 - y0;
-                if (dx * dx + dy * dy <= o.wide_d) { other = j; break; }
-              }
-            } else { // a square of the box, kept when inside the disc and in the room
-              const int gh = o.cells[c0 + i].gh, xh = gh / o.W, yh = gh - xh * o.W;
-              for (int k = 2; k < kConvMaxTries; ++k) {
-                const uint32_t w = conv_word(key, (uint32_t)k);
-                const int dx = (int)(((w & 0xffffu) * (uint32_t)span) >> 16) - o.wide_r;
-                const int dy = (int)(((w >> 16) * (uint32_t)span) >> 16) - o.wide_r;
-                const int hx = xh + (o.transposed ? dy : dx), hy = yh + (o.transposed ? dx : dy);
-                if (dx * dx + dy * dy <= o.wide_d && hx >= 0 && hx < o.H && hy >= 0 && hy < o.W && (int)o.room[hx * o.W + hy] == z) {
-                  other = o.local[hx * o.W + hy];
-                  break;
-                }
-              }
-            }
-          } else if (!(u > o.p)) { // :119: uniform over the room's cells inside the offset window -- the cell's own
-            // partner list (the valid offsets in (dx, dy) raster order, as list indices; built by sb_convection_attach)
-            const int cnt = c_cnt[q];
-            const int pick = (int)(((unsigned long long)conv_word(key, 2) * (unsigned long long)cnt) >> 32);
-            other = (int)o.partner[(size_t)(c0 + i) * (size_t)o.pw + (size_t)pick];
-          }
-          oth[q] = other;
-          stamp[q] = (((conv_word(key, 1) >> 12) << 11) | (uint32_t)c_rank[q]) + 1u; // pad: the cell's rank
-        }
-      }
+      // the records and the list links (LDS atomics)
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
         if (i < n) {
           const int other = oth[q];
+          const uint32_t key = stream ^ ((uint32_t)c_g0[q] * 0x9E3779B1u);
           uint2 r;
-          r.x = other != i ? stamp[q] : 0u;
+          r.x = other != i ? (((conv_word(key, 1) >> 12) << 11) | ((uint32_t)c_rc[q] & 0xffffu)) + 1u : 0u; // the time stamp; pad: the cell's rank
           const uint32_t nxt = other != i ? atomicExch(&head[other], (uint32_t)i) : kConvEnd;
           r.y = (uint32_t)other | (nxt << 16);
           rec[i] = r;
         }
       }
       __syncthreads();
+      const bool more = b + (int)gridDim.x < o.B;
+      if (more) draw(b + (int)gridDim.x, val_n, oth_n);
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
@@ -276,6 +284,10 @@ __global__ void __launch_bounds__(kConvMaxThreads) k_convect(ConvArgs o) {
         }
       }
       __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { val[q] = val_n[q]; oth[q] = oth_n[q]; }
+      }
     }
   }
 }
