@@ -255,12 +255,10 @@ __device__ __forceinline__ int default_control(int mode, double tz, double hsp, 
 // value is either passed through or counted into its measurement's histogram
 // (histogram_reducer.py:136-146: clip to [bins[0], bins[-1]], bin i = [bins[i], bins[i+1]),
 // the last bin holds v >= bins[-1]).
-__device__ __forceinline__ void put_obs(const Dev &a, float *row, int src, double native) {
+__device__ __forceinline__ void put_obs_at(const Dev &a, float *row, double sg, double mu, int dest, double native) {
   float x = (float)native;
-  double sg = a.obs_sigma[src];
-  double v = sg > 0.0 ? ((double)x - a.obs_mean[src]) / sg : 0.0;
+  double v = sg > 0.0 ? ((double)x - mu) / sg : 0.0;
   const float vf = (float)v;
-  const int dest = a.n_src ? a.src_dest[src] : src;
   if (dest >= 0) {
     row[dest] = vf;
     return;
@@ -274,6 +272,22 @@ __device__ __forceinline__ void put_obs(const Dev &a, float *row, int src, doubl
     if (m >= bins[j]) idx = j;
   row[a.hist_col[k] + idx] += 1.0f;
 }
+// n <= N values at once, in order: their normalisation constants and destinations are read before the first value is
+// written (one value at a time, every value waited for its own three reads: most of k_post's time)
+template <int N>
+__device__ __forceinline__ void put_obs_n(const Dev &a, float *row, int n, const int (&src)[N], const double (&native)[N]) {
+  double sg[N], mu[N];
+  int dest[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int sk = k < n ? src[k] : src[0];
+    sg[k] = a.obs_sigma[sk]; mu[k] = a.obs_mean[sk];
+    dest[k] = a.n_src ? a.src_dest[sk] : sk;
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (k < n) put_obs_at(a, row, sg[k], mu[k], dest[k], native[k]);
+}
 
 // One building's observation row, written by one thread.  S: the building's scalar state
 // (kNScalOut doubles).  Device columns in sorted (device, field) order (air_handler.py:66-95 /
@@ -283,15 +297,25 @@ __device__ inline void write_obs(const Dev &a, int b, float *obs, const float *a
   float *row = obs + (size_t)b * a.O;
   for (int k = 0; k < a.n_hist; ++k)
     for (int j = a.hist_off[k]; j < a.hist_off[k + 1]; ++j) row[a.hist_col[k] + j - a.hist_off[k]] = 0.0f;
-  for (int z = 0; z < a.Z; ++z) {
-    const int c0 = a.col_zone[z];
-    put_obs(a, row, c0 + 0, a.damper[(size_t)b * a.Z + z]); // supply_air_damper_percentage_command
-    put_obs(a, row, c0 + 1, a.p.vav_max_air_flow);          // supply_air_flowrate_setpoint
-    put_obs(a, row, c0 + 2, a.zair[(size_t)b * a.Z + z]);   // zone_air_temperature_sensor
+  for (int z0 = 0; z0 < a.Z; z0 += 4) { // four zones = twelve values at a time
+    int src[12];
+    double val[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int z = z0 + k < a.Z ? z0 + k : z0, c0 = a.col_zone[z];
+      src[3 * k] = c0; src[3 * k + 1] = c0 + 1; src[3 * k + 2] = c0 + 2;
+      val[3 * k] = a.damper[(size_t)b * a.Z + z];   // supply_air_damper_percentage_command
+      val[3 * k + 1] = a.p.vav_max_air_flow;        // supply_air_flowrate_setpoint
+      val[3 * k + 2] = a.zair[(size_t)b * a.Z + z]; // zone_air_temperature_sensor
+    }
+    put_obs_n<12>(a, row, 3 * (a.Z - z0 < 4 ? a.Z - z0 : 4), src, val);
   }
   const int n_ahu = a.p.ahu_has_weather ? 9 : 8;
   const double flow = S[2];
-  for (int i = 0; i < n_ahu; ++i) {
+  int src[12];
+  double val[12];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
     int f = i; // field index in the 9-entry AHU list (index 4 = outside_air_temperature_sensor)
     if (!a.p.ahu_has_weather && f >= 4) f += 1;
     double v;
@@ -306,11 +330,17 @@ __device__ inline void write_obs(const Dev &a, int b, float *obs, const float *a
       case 7: v = S[0]; break;                              // supply_air_heating_temperature_setpoint
       default: v = flow / a.p.ahu_max_flow; break;          // supply_fan_speed_percentage_command
     }
-    put_obs(a, row, a.col_ahu + i, v);
+    src[i] = a.col_ahu + i; val[i] = v;
   }
-  put_obs(a, row, a.col_blr + 0, S[6]); // heating_request_count
-  put_obs(a, row, a.col_blr + 1, S[4]); // supply_water_setpoint
-  put_obs(a, row, a.col_blr + 2, S[8]); // supply_water_temperature_sensor
+  // the boiler's three follow the AHU's eight or nine
+  const double blr[3] = {S[6], S[4], S[8]}; // heating_request_count, supply_water_setpoint, supply_water_temperature_sensor
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (a.p.ahu_has_weather) { src[9 + i] = a.col_blr + i; val[9 + i] = blr[i]; }
+    else { src[8 + i] = a.col_blr + i; val[8 + i] = blr[i]; }
+  }
+  if (!a.p.ahu_has_weather) { src[11] = src[0]; val[11] = 0.0; }
+  put_obs_n<12>(a, row, n_ahu + 3, src, val);
   if (a.hist_normalize) // counts / devices, in float64 then fp32 like the reference's DataFrame
     for (int k = 0; k < a.n_hist; ++k) {
       const int n = a.hist_off[k + 1] - a.hist_off[k];
@@ -429,14 +459,23 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   const double mixed = p.ahu_recirc * recirc + (1 - p.ahu_recirc) * v.t_now;
   v.t_sa = ahu_supply(mixed, v.heat_sp, v.cool_sp);
   double *gt = a.gtabg + (size_t)b * a.ts;
-  for (int c = 0; c < a.ts; ++c) {
-    double gg = 0.0;
-    if (c < a.ncls) {
-      const int zc = a.czone[c];
-      const double q = zc >= 0 ? a.qz[zb + zc] : 0.0;
-      gg = fma(a.ctab[c * 8 + 6], q, a.ctab[c * 8 + 5] * v.t_now);
+  // (in chunks of eight, loads before stores: a store to gt may alias the next class's loads for all the compiler knows,
+  // and one class per round trip to L2 -- class -> its zone -> that zone's q -- was most of this kernel's time)
+  for (int c0 = 0; c0 < a.ts; c0 += 8) {
+    double gg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = c0 + k;
+      gg[k] = 0.0;
+      if (c < a.ncls) {
+        const int zc = a.czone[c];
+        const double q = zc >= 0 ? a.qz[zb + zc] : 0.0;
+        gg[k] = fma(a.ctab[c * 8 + 6], q, a.ctab[c * 8 + 5] * v.t_now);
+      }
     }
-    gt[c] = gg;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (c0 + k < a.ts) gt[c0 + k] = gg[k];
   }
   const double hsp = in.comfort_now ? p.comfort_lo : p.eco_lo;
   const double csp = in.comfort_now ? p.comfort_hi : p.eco_hi;
@@ -445,9 +484,20 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   const int comfort_prev = in.reject_dev ? (int)S[18] : in.comfort_prev;
   double ahu_flow = 0.0, blr_flow = 0.0, num = 0.0, den = 0.0;
   int ahu_count = 0, blr_count = 0;
-  for (int z = 0; z < a.Z; ++z) {
-    const double tz = a.zmean[zb + z];  // pre-update zone mean (vav.zone_air_temperature)
-    const int mraw = a.mode[zb + z];
+  for (int z0 = 0; z0 < a.Z; z0 += 8) { // eight zones' inputs first (see gt above), then their arithmetic in zone order
+   double tz8[8], dm8[8];
+   int mr8[8];
+#pragma unroll
+   for (int k = 0; k < 8; ++k) {
+     const size_t i = zb + (size_t)(z0 + k < a.Z ? z0 + k : z0);
+     tz8[k] = a.zmean[i]; mr8[k] = a.mode[i]; dm8[k] = rejected ? a.damper[i] : 0.0;
+   }
+#pragma unroll
+   for (int k = 0; k < 8; ++k) {
+    const int z = z0 + k;
+    if (z >= a.Z) break;
+    const double tz = tz8[k];           // pre-update zone mean (vav.zone_air_temperature)
+    const int mraw = mr8[k];
     int mode = mraw & kModeMask;        // thermostat.py:114-148
     bool valve_open = (mraw & kValveBit) != 0;
     if (!rejected) {
@@ -458,7 +508,7 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
       a.mode[zb + z] = mode | (valve_open ? kValveBit : 0);
     }
     double damper = (mode == 1 || mode == 2) ? 1.0 : 0.1;
-    if (rejected) damper = a.damper[zb + z];                // nobody touched the VAV: what it had
+    if (rejected) damper = dm8[k];                          // nobody touched the VAV: what it had
     for (int i = 0; i < p.n_actions; ++i)                   // set_action after update_settings
       if ((damper_set >> i & 1u) && p.act_zone[i] == z) damper = damper_cmd[i];
     const double valve = valve_open ? 1.0 : 0.0;
@@ -479,6 +529,7 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
     if (reheat > 0) { blr_flow += reheat; ++blr_count; }
     num += valve * tzs;
     den += valve;
+   }
   }
   v.ahu_flow = ahu_flow; v.blr_flow = blr_flow; v.ahu_count = ahu_count; v.blr_count = blr_count;
   v.blr_return = num / (den + 1e-6);
@@ -523,13 +574,25 @@ __device__ inline void post_building(const Dev &a, const StepArgs &s, int b) {
   const double hsp2 = (double)(float)(in.comfort_next ? p.comfort_lo : p.eco_lo);
   const double csp2 = (double)(float)(in.comfort_next ? p.comfort_hi : p.eco_hi);
   double cumulative = 0.0, total_occ = 0.0;
-  for (int z = 0; z < a.Z; ++z) {
-    const double tzp = a.zsum[zb + z] / (double)(a.zone_off[z + 1] - a.zone_off[z]);
+  for (int z0 = 0; z0 < a.Z; z0 += 8) { // eight zones' inputs first (as in pre_building), then their arithmetic in zone order
+   double zs8[8], oc8[8];
+   int zn8[8];
+#pragma unroll
+   for (int k = 0; k < 8; ++k) {
+     const int zz = z0 + k < a.Z ? z0 + k : z0;
+     zs8[k] = a.zsum[zb + zz];
+     zn8[k] = a.zone_off[zz + 1] - a.zone_off[zz];
+     oc8[k] = in.occupancy_bz_dev ? (double)in.occupancy_bz_dev[zb + zz]
+                                  : (double)(float)(in.occupancy_dev ? in.occupancy_dev[zz] : in.occupancy);
+   }
+#pragma unroll
+   for (int k = 0; k < 8; ++k) {
+    const int z = z0 + k;
+    if (z >= a.Z) break;
+    const double tzp = zs8[k] / (double)zn8[k];
     a.zmean[zb + z] = tzp;
     const double t = (double)(float)tzp;
-    const double occ = in.occupancy_bz_dev
-                           ? (double)in.occupancy_bz_dev[zb + z]
-                           : (double)(float)(in.occupancy_dev ? in.occupancy_dev[z] : in.occupancy);
+    const double occ = oc8[k];
     double prod; // base_setpoint_energy_carbon_reward.py:78-123
     if (t < hsp2) prod = p.max_prod / (1.0 + exp(-p.prod_stiff * (t - (hsp2 - p.prod_delta))));
     else if (t > csp2)
@@ -537,6 +600,7 @@ __device__ inline void post_building(const Dev &a, const StepArgs &s, int b) {
     else prod = p.max_prod;
     cumulative += prod * occ * p.dt / 3600.0;
     total_occ += occ;
+   }
   }
 
   const double intake = v.ahu_flow * p.ahu_dp / p.ahu_eff;                         // air_handler.py:287-320
