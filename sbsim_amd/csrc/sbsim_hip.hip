@@ -690,7 +690,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   if (Hs > 64 + 2 && !env_flag("SBSIM_NO_BAND_PATH") && plan_band(plan, Hs, Ws, x0, y0, zone_of, r)) return;
   auto pick_slots = [&](int mode) { // narrowest instantiation that holds the width and the class count
     if (mode == 3) {
-      for (int s : {64, 80, 96}) // SBSIM_NO_ROLL_64=1: the 96-slot instantiation alone (the tree before round 4's last additions)
+      for (int s : {64, 72, 80, 88, 96}) // SBSIM_NO_ROLL_64=1: the 96-slot instantiation alone (the tree before round 4's last additions)
         if (s >= Ws && sweep_roll_supported(s) && ncls + 1 <= 32 && !(s < 96 && env_flag("SBSIM_NO_ROLL_64"))) return s;
       return 0;
     }

@@ -49,8 +49,8 @@ constexpr int kSeamPad = 8;
 // 70 slots (the stride is 2 mod 4 doubles: rows are 16-byte aligned and 16 lanes' ds_read_b128 cover
 // all banks) and a second array [64][2] with slots 70, 71 (a stride of 72 would be four-way conflicted,
 // 74 does not fit).
-constexpr int lds_slots(int NR) { return NR > 72 ? 72 : ((NR / 2) % 2 ? NR : NR + 2); }
-constexpr int a_stride(int NR) { return NR > 72 ? 70 : ((NR / 2) % 2 ? NR : NR + 2); }
+constexpr int lds_slots(int NR) { return NR >= 72 ? 72 : ((NR / 2) % 2 ? NR : NR + 2); }
+constexpr int a_stride(int NR) { return NR >= 72 ? 70 : ((NR / 2) % 2 ? NR : NR + 2); }
 constexpr int kWaves = 4;     // wavefronts = buildings per workgroup
 constexpr int tail_row(int NR) { return NR + 4; } // tail rows in LDS: column c at [2 + c], zero guards around
 
@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
 
 } // namespace
 
-bool sweep_roll_supported(int NR) { return NR == 64 || NR == 80 || NR == 96; }
+bool sweep_roll_supported(int NR) { return NR == 64 || NR == 72 || NR == 80 || NR == 88 || NR == 96; }
 int sweep_roll_lds_slots(int NR) { return lds_slots(NR); }
 int sweep_roll_a_stride(int NR) { return a_stride(NR); }
 int sweep_roll_seam_doubles(int NR, int T) { (void)T; return tail_row(NR); } // the first tail row, by column
@@ -682,14 +682,18 @@ int launch(const Dev &d, hipStream_t stream) {
 
 int prepare_sweep_roll(const Dev &d) {
   if (d.NR == 96) return prepare<96>(d);
+  if (d.NR == 88) return prepare<88>(d);
   if (d.NR == 80) return prepare<80>(d);
+  if (d.NR == 72) return prepare<72>(d);
   if (d.NR == 64) return prepare<64>(d);
   return (int)hipErrorInvalidValue;
 }
 
 int launch_sweep_roll(const Dev &d, hipStream_t stream) {
   if (d.NR == 96) return launch<96>(d, stream);
+  if (d.NR == 88) return launch<88>(d, stream);
   if (d.NR == 80) return launch<80>(d, stream);
+  if (d.NR == 72) return launch<72>(d, stream);
   if (d.NR == 64) return launch<64>(d, stream);
   return (int)hipErrorInvalidValue;
 }

@@ -667,6 +667,8 @@ def _oracle_twin(plan, cfg, init_flat):
     ((2, 2), (30, 29), "rows", 30),    # 65x63 -> k_sweep_roll<64> + ONE tail row
     ((2, 3), (20, 24), "rows", 30),    # 45x78 -> k_sweep_roll<80>
     ((2, 3), (30, 24), "rows", 30),    # 65x78 -> k_sweep_roll<80> + ONE tail row
+    ((2, 3), (20, 21), "rows", 30),    # 45x69 -> k_sweep_roll<72> (all of A in LDS: 70 + 2 slots)
+    ((2, 3), (30, 27), "rows", 30),    # 65x87 -> k_sweep_roll<88> + ONE tail row
     ((4, 5), (10, 8), "rows", 31),     # ... and on k_sweep_reg (SBSIM_NO_ROLL_SMALL=1): zone reduce in two 16-zone passes
     ((4, 2), (30, 17), "columns", 0),  # the same family on the LDS-grid kernel, lanes = columns
     # 67..130 rows, <= 80 columns: step_two.hip (path 4: one wavefront, two rows per lane) is the library's
