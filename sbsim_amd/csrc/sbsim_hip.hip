@@ -418,7 +418,7 @@ bool plan_band(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const s
   const int W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = plan->H * plan->W;
   auto coef = [&](int c, int j) { return plan->class_coef[c * 8 + j]; };
   int NR = 0;
-  for (int s : {76, 80, 84, 88, 92, 96}) // the narrowest instantiation that holds the width: a period is NR steps
+  for (int s : {68, 72, 76, 80, 84, 88, 92, 96}) // the narrowest instantiation that holds the width: a period is NR steps
     if (!NR && s >= Ws && sweep_band_supported(s)) NR = s;
   if (!NR || Hs <= 64) return false;
   // wavefronts: the fewest whose rows + two tail rows hold the plan; a zone cell in a tail row needs one more

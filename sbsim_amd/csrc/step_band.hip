@@ -1,11 +1,13 @@
 // step_band.hip -- mode 5, one row per lane on two to four wavefronts per building: what the planner asks and the
-// dispatch to the instantiations, which live in one translation unit per slot count (step_band_76.hip ..
+// dispatch to the instantiations, which live in one translation unit per slot count (step_band_68.hip ..
 // step_band_96.hip <- step_band_impl.h) so that they compile in parallel.
 #include "sb_device.h"
 #include "step_band_cfg.h"
 
 namespace sb {
 
+int sweep_band_run68(const Dev &d, hipStream_t stream, bool prepare);
+int sweep_band_run72(const Dev &d, hipStream_t stream, bool prepare);
 int sweep_band_run76(const Dev &d, hipStream_t stream, bool prepare);
 int sweep_band_run80(const Dev &d, hipStream_t stream, bool prepare);
 int sweep_band_run84(const Dev &d, hipStream_t stream, bool prepare);
@@ -19,6 +21,8 @@ using namespace band;
 int dispatch(const Dev &d, hipStream_t stream, bool prepare) {
   if (d.RS < 128 || d.RS > 64 * kWMax || d.RS % 64) return (int)hipErrorInvalidValue;
   switch (d.NR) {
+    case 68: return sweep_band_run68(d, stream, prepare);
+    case 72: return sweep_band_run72(d, stream, prepare);
     case 76: return sweep_band_run76(d, stream, prepare);
     case 80: return sweep_band_run80(d, stream, prepare);
     case 84: return sweep_band_run84(d, stream, prepare);

@@ -1,0 +1,8 @@
+// step_band_72.hip -- k_sweep_band's instantiation for 72 slots per lane (step_band_impl.h; step_band.hip dispatches)
+#include "step_band_impl.h"
+
+namespace sb {
+
+int sweep_band_run72(const Dev &d, hipStream_t stream, bool prepare) { return launch<72>(d, stream, prepare); }
+
+} // namespace sb

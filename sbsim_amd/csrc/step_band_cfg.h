@@ -18,7 +18,7 @@ constexpr int kWMax = 4;   // wavefronts per building: one per SIMD
 // (j + 1) mod NR: the pair of an odd step is 16-byte aligned.
 constexpr int lds_slots(int NR) { return 66; }
 constexpr int seam_region(int NR) { return NR + 72; }                    // doubles per seam row: 64 finite ones in front (steps < 63)
-constexpr int kSlotCounts[] = {76, 80, 84, 88, 92, 96};                  // the instantiations (step_band_NN.hip)
+constexpr int kSlotCounts[] = {68, 72, 76, 80, 84, 88, 92, 96};                  // the instantiations (step_band_NN.hip)
 
 } // namespace band
 } // namespace sb
