@@ -168,12 +168,14 @@ k_convect(ConvArgs o) {
     const int c0 = o.zone_off[z], n = o.zone_off[z + 1] - c0;
     // the lane's cells: what every building needs of them, in registers (the rest of a ConvCell -- its index in the
     // handle's grid -- only the wide-window path reads, from memory: eight waves per SIMD need <= 64 registers)
-    int c_g0[Q], c_sidx[Q], c_rc[Q]; // c_rc: the cell's rank in its room | its partner count << 16
+    // two words per cell: its index in the caller's grid (20 bits) | its partner count << 20; its index in the state
+    // (21 bits) | its rank in its room << 21 (sb_convection_attach checks the widths)
+    uint32_t c_a[Q], c_b[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const int i = tid + q * kConvThreads;
       const ConvCell c = o.cells[c0 + (i < n ? i : 0)];
-      c_g0[q] = c.g0; c_sidx[q] = c.sidx; c_rc[q] = c.pad | (__popcll(c.mask) << 16);
+      c_a[q] = (uint32_t)c.g0 | ((uint32_t)__popcll(c.mask) << 20); c_b[q] = (uint32_t)c.sidx | ((uint32_t)c.pad << 21);
     }
     for (int i = tid; i < n; i += kConvThreads) head[i] = kConvEnd; // (re-armed with every building's store phase)
     __syncthreads();
@@ -188,15 +190,15 @@ k_convect(ConvArgs o) {
           const int i = tid + q * kConvThreads;
           oth[q] = i;
           if (i < n) {
-            val[q] = st[c_sidx[q]];
-            const uint32_t key = stream ^ ((uint32_t)c_g0[q] * 0x9E3779B1u);
+            val[q] = st[c_b[q] & 0x1fffffu];
+            const uint32_t key = stream ^ ((c_a[q] & 0xfffffu) * 0x9E3779B1u);
             const double u = (double)(conv_word(key, 0) >> 8) * (1.0 / 16777216.0);
             int other = i;
             if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table: the partner by rejection --
               // uniform over the reference's candidate list (:122-131; the cell itself is a candidate)
               const int span = 2 * o.wide_r + 1, W0 = o.transposed ? o.H : o.W; // W0: row length of the caller's grid
               if (n < span * span) { // the room has fewer cells than the window's box: a cell of the room (by rank), kept when inside the disc
-                const int x0 = c_g0[q] / W0, y0 = c_g0[q] - x0 * W0;
+                const int g0 = (int)(c_a[q] & 0xfffffu), x0 = g0 / W0, y0 = g0 - x0 * W0;
                 for (int k = 2; k < kConvMaxTries; ++k) {
                   const int j = o.by_rank[c0 + (int)(((unsigned long long)conv_word(key, (uint32_t)k) * (unsigned long long)n) >> 32)];
                   const int gj = o.cells[c0 + j].g0, dx = gj / W0 - x0, dy = gj - (gj / W0) * W0 - y0;
@@ -217,7 +219,7 @@ k_convect(ConvArgs o) {
               }
             } else if (!(u > o.p)) { // :119: uniform over the room's cells inside the offset window -- the cell's own
               // partner list (the valid offsets in (dx, dy) raster order, as list indices; built by sb_convection_attach)
-              const int cnt = c_rc[q] >> 16;
+              const int cnt = (int)(c_a[q] >> 20);
               const int pick = (int)(((unsigned long long)conv_word(key, 2) * (unsigned long long)cnt) >> 32);
               other = (int)o.partner[(size_t)(c0 + i) * (size_t)o.pw + (size_t)pick];
             }
@@ -237,9 +239,9 @@ k_convect(ConvArgs o) {
         const int i = tid + q * kConvThreads;
         if (i < n) {
           const int other = oth[q];
-          const uint32_t key = stream ^ ((uint32_t)c_g0[q] * 0x9E3779B1u);
+          const uint32_t key = stream ^ ((c_a[q] & 0xfffffu) * 0x9E3779B1u);
           uint2 r;
-          r.x = other != i ? (((conv_word(key, 1) >> 12) << 11) | ((uint32_t)c_rc[q] & 0xffffu)) + 1u : 0u; // the time stamp; pad: the cell's rank
+          r.x = other != i ? (((conv_word(key, 1) >> 12) << 11) | (c_b[q] >> 21)) + 1u : 0u; // the time stamp; pad: the cell's rank
           const uint32_t nxt = other != i ? atomicExch(&head[other], (uint32_t)i) : kConvEnd;
           r.y = (uint32_t)other | (nxt << 16);
           rec[i] = r;
@@ -279,7 +281,7 @@ k_convect(ConvArgs o) {
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
         if (i < n) {
-          st[c_sidx[q]] = vout[i];
+          st[c_b[q] & 0x1fffffu] = vout[i];
           head[i] = kConvEnd; // for the next building (the follow phase is over: every lane is past the barrier above)
         }
       }
@@ -411,6 +413,8 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   // :125-131: window [-distance, distance) in both directions, squared distance <= distance
   // (in the order of the caller's grid: the handle may hold the transposed floor plan)
   if (d.N >= (1 << 20)) return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: more than 2^20 grid cells");
+  if ((d.reg ? (size_t)d.state_doubles : (size_t)d.Np) >= ((size_t)1 << 21))
+    return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: a building's state of more than 2^21 doubles");
   std::vector<int> odx, ody, offd; // offsets in the handle's coordinates, linear steps
   const int reach = std::min(distance, 32); // dx^2 <= distance <= 1000
   for (int dx = -reach; dx < reach; ++dx)
