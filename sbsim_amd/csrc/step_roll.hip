@@ -1,5 +1,6 @@
-// step_roll.hip -- the sweep kernel for floor plans of 65..66 rows inside their exterior ring
-// (R9: 66 x 96): one wavefront per building, the grid in registers, rows 64.. finished by a scan,
+// step_roll.hip -- the sweep kernel for floor plans of up to 66 rows inside their exterior ring
+// (R9: 66 x 96; below 64 rows the other lanes own pad rows; NR = 64, 72, 80, 88 or 96 slots by the plan's
+// width): one wavefront per building, the grid in registers, rows 64.. finished by a scan,
 // consecutive Gauss-Seidel sweeps overlapped ("rolling" sweeps).  simulator.py:278-371.
 //
 // Layout and schedule are those of step_reg.hip (lane l owns row l, column c in register slot
@@ -48,7 +49,8 @@ constexpr int kSeamPad = 8;
 // LDS, so four buildings -- one per SIMD -- and the shared tables (7 KB) fill a CU's 160 KB.  Rows of
 // 70 slots (the stride is 2 mod 4 doubles: rows are 16-byte aligned and 16 lanes' ds_read_b128 cover
 // all banks) and a second array [64][2] with slots 70, 71 (a stride of 72 would be four-way conflicted,
-// 74 does not fit).
+// 74 does not fit).  NR = 72, 80, 88: the same 70 + 2 slots in LDS (NR - 72 in registers); NR = 64: all of them,
+// rows of 66.
 constexpr int lds_slots(int NR) { return NR >= 72 ? 72 : ((NR / 2) % 2 ? NR : NR + 2); }
 constexpr int a_stride(int NR) { return NR >= 72 ? 70 : ((NR / 2) % 2 ? NR : NR + 2); }
 constexpr int kWaves = 4;     // wavefronts = buildings per workgroup
