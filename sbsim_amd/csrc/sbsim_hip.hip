@@ -216,8 +216,8 @@ bool plan_two(const sb_plan_desc *plan, int Hs, int Ws, int x0, int y0, const st
   const int W = plan->W, Z = plan->Z, ncls = plan->n_classes, N = plan->H * plan->W;
   auto coef = [&](int c, int j) { return plan->class_coef[c * 8 + j]; };
   int NR = 0;
-  for (int s : {76, 80})
-    if (!NR && s >= Ws && sweep_two_supported(s)) NR = s;
+  for (int s : {64, 76, 80}) // the narrowest instantiation that holds the width (SBSIM_NO_TWO_64=1: 76 / 80 alone, the tree before the end of round 4)
+    if (!NR && s >= Ws && sweep_two_supported(s) && !(s == 64 && env_flag("SBSIM_NO_TWO_64"))) NR = s;
   if (!NR || Hs > 128 + 2) return false;
   int ts = 32;
   while (ts < ncls + 1) ts *= 2;

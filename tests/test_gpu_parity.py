@@ -683,6 +683,8 @@ def _oracle_twin(plan, cfg, init_flat):
     ((5, 3), (24, 24), "rows", 4),     # 128x78: two rows per lane, all 64 lanes, no tail row
     ((4, 4), (15, 17), "rows", 4),     # 67x75: two rows per lane, 34 lanes (the sweep ends early)
     ((14, 7), (8, 10), "rows", 4),     # 129x80: two rows per lane, 80 slots + ONE tail row
+    ((8, 5), (12, 10), "rows", 4),     # 107x58: two rows per lane, 64 slots
+    ((14, 7), (8, 7), "rows", 4),      # 129x59: 64 slots + ONE tail row
     # 131..258 rows, <= 96 columns: step_band.hip with three or four wavefronts per building (the library's choice)
     ((9, 4), (16, 17), "rows", 53),    # 156x75 inside the exterior ring: 64 + 64 + 28 rows, 76 slots
     ((10, 4), (18, 20), "rows", 53),   # 193x87: 3 x 64 rows + ONE tail row, 88 slots (16 of them in AGPRs)
