@@ -206,3 +206,21 @@ def test_product_does_not_import_oracle():
       if f.endswith((".py", ".hip", ".h")):
         text = open(os.path.join(dirpath, f)).read()
         assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_plan_info_narrowest_instantiations(monkeypatch):
+  """The planner takes the narrowest instantiation that holds a plan's columns (end of round 4): k_sweep_two on 64
+  slots for 107 x 58 (SBSIM_NO_TWO_64=1: 76), step_band.hip on 68 / 72 slots for 156 x 67 / 255 x 72."""
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  mk = lambda rooms, shape: FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
+  plan = mk((8, 5), (12, 10))
+  rc, a = _plan_info(plan, n_obs=3 * 40 + 19)
+  assert rc == 0 and a["kernel"] == 4 and a["lds_bytes_per_workgroup"] <= 160 * 1024
+  monkeypatch.setenv("SBSIM_NO_TWO_64", "1")
+  rc, b = _plan_info(plan, n_obs=3 * 40 + 19)
+  monkeypatch.delenv("SBSIM_NO_TWO_64")
+  assert rc == 0 and b["kernel"] == 4 and b["sweep_steps"] == a["sweep_steps"] + 12   # 76 - 64 slots
+  rc, c = _plan_info(mk((9, 4), (16, 15)), n_obs=3 * 36 + 19)
+  assert rc == 0 and c["kernel"] == 5 and c["waves_per_building"] == 3 and c["sweep_steps"] == 68
+  rc, d = _plan_info(mk((12, 3), (20, 22)), n_obs=3 * 36 + 19)
+  assert rc == 0 and d["kernel"] == 5 and d["waves_per_building"] == 4 and d["sweep_steps"] in (72, 76)   # 255 rows: + a tail row's 4 steps when it has one
