@@ -39,6 +39,20 @@ from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan  # 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
+KERNEL_SOURCES = ("sbsim_amd/csrc/step_roll.hip", "sbsim_amd/csrc/sweep_common.h", "sbsim_amd/csrc/sb_device.h")
+
+
+def kernel_source_sha256() -> str:
+  """Hash of the files the bench kernel (k_sweep_roll) is compiled from: what ties a committed PMC traffic profile
+  (profiles/traffic_latest.json, stamped by tools/adopt_profiles.py) to the kernel of this run."""
+  import hashlib
+  h = hashlib.sha256()
+  for rel in KERNEL_SOURCES:
+    with open(os.path.join(ROOT, rel), "rb") as fh:
+      h.update(fh.read())
+  return h.hexdigest()
+
+
 def r9_plan() -> FloorPlan:
   return FloorPlan.from_file_input(rectangular_floor_plan((3, 3), (20, 30)), Materials.sb1(), 10.0, 300.0)
 
@@ -73,6 +87,7 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
   step = dt.timedelta(seconds=c.time_step_sec)
   prev = None
   n_steps, t_cpu, sweeps, step_times = 0, 0.0, 0, []
+  cpu_s, load0 = 0.0, os.getloadavg()[0]   # process CPU time inside batch.step (all its OpenMP threads) and the host's load before the sample
   single_times, n_now = [], threads   # after the all-cores sample: two steps of the same rollout on ONE thread
   max_steps = acts.shape[0]
   while n_steps < max_steps:
@@ -89,8 +104,9 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
           comfort_next=si.comfort_next, occupancy=np.full(oplan.Z, si.occupancy), observe=1,
           e_price=si.e_price, e_carbon=si.e_carbon, g_price=si.g_price, g_carbon=si.g_carbon,
           action=native))
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     outs = batch.step(ins, n_threads=n_now)
+    c1 = time.process_time()
     n_steps += 1
     prev, ts = ts, ts + step
     if n_steps <= warmup:
@@ -102,6 +118,7 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
       continue
     step_times.append(time.perf_counter() - t0)
     t_cpu += step_times[-1]
+    cpu_s += c1 - c0
     sweeps += sum(outs[b].n_sweeps for b in range(nb))
     # bounded sample: at least ~2.5 s of wall time (a sub-second sample on a shared host is noise),
     # at most ~25 s
@@ -115,7 +132,15 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
   # median step time: a sub-second sample on a shared 128-thread host is noisy in the mean
   value = nb * zones / float(np.median(step_times))
   grids = np.stack([b.grid() for b in batch.buildings])
+  try:
+    affinity = len(os.sched_getaffinity(0))
+  except (AttributeError, OSError):
+    affinity = None
   return dict(value=value, unit="zone-updates/s", cores=threads, kind="port",
+              # what really ran: CPU seconds the process burnt inside the timed steps / their wall time (= threads that were
+              # actually on a core: a shared host gives fewer than it advertises), the CPUs this process may use, the host's load
+              threads_effective=cpu_s / t_cpu if t_cpu > 0 else None, cpus_allowed=affinity, host_cpus=os.cpu_count(),
+              host_loadavg_1min_before_after=[load0, os.getloadavg()[0]],
               sample=f"{nb} buildings x {n_timed} steps of the bench workload after {warmup} untimed "
                      f"warm-up steps ({sweeps / (nb * n_timed):.2f} sweeps/step), oracle/sb_oracle.c "
                      f"with OpenMP over buildings, {t_cpu:.2f} s wall x {threads} threads; rate from the median step",
@@ -155,31 +180,41 @@ def stub_rank(args) -> None:
   dev = torch.device("cpu")
   pf = sd.preflight(dev, args.gpus)       # before any work: world size, a 256 KiB all_gather, all_reduce(MAX)
   B, K, W = args.buildings, args.steps, args.warmup
-  lo, hi = sd.shard_range(world * B, rank, world)
-  returns = torch.zeros((B,), dtype=torch.float32)
+  mixed = args.config == "mixed"
+  if mixed:   # three classes, each block-partitioned over the ranks on its own: a building's "global index" is class-major
+    per = B // len(MIXED_CLASSES)
+    totals = [world * per] * len(MIXED_CLASSES)
+    spans = sd.class_shard_ranges(totals, rank, world)
+    ids = torch.cat([torch.arange(lo, hi, dtype=torch.float32) + sum(totals[:k]) for k, (lo, hi) in enumerate(spans)])
+    n_total = sum(totals)
+  else:
+    lo, hi = sd.shard_range(world * B, rank, world)
+    ids = torch.arange(lo, hi, dtype=torch.float32)
+    n_total = world * B
+  returns = torch.zeros((ids.numel(),), dtype=torch.float32)
   for _ in range(W):
     time.sleep(1e-3)
   sd.barrier(dev)
   t0 = time.perf_counter()
   for t in range(K):
     time.sleep(1e-3)
-    returns += torch.arange(lo, hi, dtype=torch.float32)
+    returns += ids
   sd.barrier(dev)
   mine = time.perf_counter() - t0
   per_rank = sd.all_ranks(mine / K * 1e3, dev)
   elapsed = sd.max_over_ranks(mine, dev)
   g0 = time.perf_counter()
-  all_returns = sd.gather_returns(returns, world * B)
+  all_returns = sd.gather_returns_by_class(returns, totals) if mixed else sd.gather_returns(returns, n_total)
   gather_ms = (time.perf_counter() - g0) * 1e3
-  ok = bool(torch.equal(all_returns, torch.arange(world * B, dtype=torch.float32) * K))
+  ok = bool(torch.equal(all_returns, torch.arange(n_total, dtype=torch.float32) * K))
   if rank == 0:
-    print(json.dumps({"metric": "stub", "value": world * B * K / elapsed, "unit": "env-steps/s", "n_gpus": world,
+    print(json.dumps({"metric": "stub", "value": n_total * K / elapsed, "unit": "env-steps/s", "n_gpus": world,
                       "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stub",
                       "return_gather_ms": gather_ms, "gathered_returns": int(all_returns.numel()),
                       "gather_in_global_order": ok, "rccl_ranks": pf["ranks"], "preflight": pf,
                       "per_rank_ms_per_step": per_rank,
-                      "config": {"workload": "launcher plumbing test (stub step, gloo)"}}))
+                      "config": {"workload": "launcher plumbing test (stub step, gloo)" + (", three classes sharded per class" if mixed else "")}}))
   if distributed:
     dist.destroy_process_group()
 
@@ -215,14 +250,14 @@ class TwinCheck:
 
   def record(self, step_in, actions: torch.Tensor) -> None:
     """After the device step with `step_in` / `actions`: what the twins need and what the device found."""
-    env, n = self.env, self.n
-    self.steps.append((step_in, actions[:n].detach().cpu().numpy().copy(), env.info[:n, 4].cpu().numpy().copy(),
-                       env.sim.zone_temps()[:n].cpu().numpy().copy()))
+    env, n = self.env, self.n   # (device-side copies: no host synchronisation inside a timed loop)
+    self.steps.append((step_in, actions[:n].detach().clone(), env.info[:n, 4].clone(), env.sim.zone_temps()[:n].clone()))
 
   def verify(self) -> dict:
     lo, hi = self.env.config.action_ranges
     worst, mismatches = 0.0, 0
     for t, (si, acts, nsw, zt) in enumerate(self.steps):
+      acts, nsw, zt = acts.cpu().numpy(), nsw.cpu().numpy(), zt.cpu().numpy()
       for b, tw in enumerate(self.twins):
         native = [np.float32((float(acts[b, 0]) + 1.0) / 2.0 * (lo[1] - lo[0]) + lo[0]),
                   np.float32((float(acts[b, 1]) + 1.0) / 2.0 * (hi[1] - hi[0]) + hi[0])]
@@ -238,39 +273,49 @@ class TwinCheck:
 MIXED_CLASSES = [("R9", (3, 3), (20, 30)), ("SB2-synth", (8, 5), (12, 14)), ("SB1-synth", (14, 9), (8, 7))]
 
 
-def mixed_config(args) -> None:
+def mixed_config(args, ctx=None, emit=True):
   """BASELINE.json configs[2] (SURVEY.md 8d "Config 3"): the batch split evenly over three floor-plan
   classes -- R9 (9 zones), "SB2-synth" (8x5 rooms, 40 zones), "SB1-synth" (14x9 rooms, 126 zones, the
   real SB1's VAV count; SB2 / SB3 do not exist in the reference) -- behind ONE environment
   (`MixedBatchedEnvironment`: one library handle and one HIP stream per class inside, so that the classes'
   launches overlap), stepped through its public `step()` with random setpoint actions.  One JSON line;
   `roofline` sums the algorithmic bytes of the three sweep kernels over their summed durations, each measured
-  with the chip to itself in three rounds after the timed ones."""
-  dev = torch.device("cuda", 0)
-  torch.cuda.set_device(0)
+  with the chip to itself in three rounds after the timed ones.
+  `--gpus N`: every class is block-partitioned over the ranks on its own (each GPU holds the same
+  class mix), `--buildings` per GPU, no per-step collective, one all_gather of the per-building returns at the
+  end (`sbsim_amd.distributed.gather_returns_by_class`: global class-major order)."""
+  rank, dev, distributed, pf = ctx if ctx is not None else start_rank(args)
+  local_rank, world = dev.index, pf["ranks"]
+  torch.cuda.set_device(local_rank)
   B_each, K, W = args.buildings // len(MIXED_CLASSES), args.steps, args.warmup
   N_ALONE = 3
   plans = [FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
            for _, rooms, shape in MIXED_CLASSES]
-  menv = MixedBatchedEnvironment([(p, B_each) for p in plans], device=0, holiday_calendar="us", collect_info=True,
-                                 num_days_in_episode=3)
+  menv = MixedBatchedEnvironment([(p, world * B_each) for p in plans], device=local_rank, rank=rank, world=world,
+                                 holiday_calendar="us", collect_info=True, num_days_in_episode=3)
   menv.reset()
-  rs = np.random.RandomState(7)
+  rs = np.random.RandomState(sd.shard_seed(7, rank))
   t_init = torch.tensor(np.clip(294.0 + rs.randn(B_each), 285.0, 305.0), dtype=torch.float64, device=dev)
+  n_check = args.check_buildings if rank == 0 else 0
   checks = []
   for env, plan in zip(menv.envs, plans):   # every class starts from the same per-building temperatures
     H, Wd = plan.shape
     env.sim.reset(temps=t_init[:, None].expand(B_each, H * Wd).contiguous())
-    checks.append(TwinCheck(env, plan, t_init[:args.check_buildings].cpu().numpy(), args.check_buildings)
-                  if args.check_buildings else None)
+    checks.append(TwinCheck(env, plan, t_init[:n_check].cpu().numpy(), n_check) if n_check else None)
   gen = torch.Generator(device=dev)
-  gen.manual_seed(1234)
+  gen.manual_seed(sd.shard_seed(1234, rank))
   acts = torch.rand((W + K + N_ALONE, menv.batch_size, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+  returns = torch.zeros((menv.batch_size,), dtype=torch.float32, device=dev)
   torch.cuda.synchronize(dev)
+
+  def barrier():
+    sd.barrier(dev)
+    torch.cuda.synchronize(dev)
 
   def round_(t):
     sis = [env.make_step_in(env.current_simulation_timestamp) if c else None for env, c in zip(menv.envs, checks)]
-    menv.step(acts[t])
+    ts = menv.step(acts[t])
+    returns.add_(ts.reward)
     for (lo, hi), c, si in zip(menv.slices, checks, sis):
       if c:
         c.record(si, acts[t, lo:hi])
@@ -300,14 +345,23 @@ def mixed_config(args) -> None:
 
   for t in range(W):
     round_(t)
-  torch.cuda.synchronize(dev)
+  barrier()
   menv.profile = True
   t0 = time.perf_counter()
   for t in range(W, W + K):
     round_(t)
-  torch.cuda.synchronize(dev)
-  elapsed = time.perf_counter() - t0
+  barrier()
+  mine = time.perf_counter() - t0
   menv.profile = False
+  per_rank = sd.all_ranks(mine / K * 1e3, dev)
+  elapsed = sd.max_over_ranks(mine, dev)
+  gather_ms, n_gathered = 0.0, menv.batch_size
+  if distributed:
+    g0 = time.perf_counter()
+    n_gathered = int(sd.gather_returns_by_class(returns, menv.class_totals).numel())
+    torch.cuda.synchronize(dev)
+    gather_ms = (time.perf_counter() - g0) * 1e3
+    assert n_gathered == sum(menv.class_totals)
   for t in range(W + K, W + K + N_ALONE):   # after the timed rounds, in the same regime
     alone(t)
   per_class, alg_bytes, kern_s = {}, 0.0, 0.0
@@ -329,25 +383,35 @@ def mixed_config(args) -> None:
         "launch": li}
     if checks[k]:
       per_class[name]["parity_vs_oracle"] = checks[k].verify()
-  zone_updates = sum(env.sim.B * env.sim.Z for env in menv.envs) * K
-  env_steps = menv.batch_size * K
+  zone_updates = world * sum(env.sim.B * env.sim.Z for env in menv.envs) * K
+  env_steps = world * menv.batch_size * K
   achieved = alg_bytes / kern_s / 1e9
-  print(json.dumps({
-      "metric": "zone-updates/sec over three floor-plan classes (mixed zone counts), 1 MI355X",
-      "value": zone_updates / elapsed, "unit": "zone-updates/s", "n_gpus": 1, "steps": K, "warmup": W,
+  result = {
+      "metric": "zone-updates/sec over three floor-plan classes (mixed zone counts), %d MI355X" % world,
+      "value": zone_updates / elapsed, "unit": "zone-updates/s", "n_gpus": world, "steps": K, "warmup": W,
       "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
       "dtype": "f64", "data": "synthetic", "env_steps_per_s": env_steps / elapsed,
+      "return_gather_ms": gather_ms, "gathered_returns": n_gathered,
+      "rccl_ranks": pf["ranks"], "preflight": pf, "per_rank_ms_per_step": per_rank,
       "timed_through": "MixedBatchedEnvironment.step()",
       "config": {"workload": "BASELINE.json configs[2]: %d buildings x 3 floor-plan classes (R9, SB2-synth 40 zones, "
-                             "SB1-synth 126 zones) behind one MixedBatchedEnvironment (one handle and one HIP stream per "
-                             "class inside), random setpoint actions" % B_each,
+                             "SB1-synth 126 zones) per GPU behind one MixedBatchedEnvironment (one handle and one HIP stream "
+                             "per class inside), random setpoint actions" % B_each,
+                 "parallelism": f"{world} x (the same class mix: every class block-partitioned over the ranks), no per-step collective",
+                 "class_ranges_rank0": [list(r) for r in menv.class_ranges], "class_totals": menv.class_totals,
                  "observation_width": menv.observation_spec().shape[0], "classes": per_class},
       "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                    "note": "sum of the three sweep kernels' algorithmic bytes over the sum of their durations, each "
                            "measured with the chip to itself (in the timed rounds the kernels overlap: wall time per "
-                           "round is ms_per_step)"}}))
+                           "round is ms_per_step)"}}
   menv.close()
+  if emit and rank == 0:
+    print(json.dumps(result))
+  if emit and distributed:
+    import torch.distributed as dist
+    dist.destroy_process_group()
+  return result
 
 
 def start_rank(args):
@@ -368,14 +432,14 @@ def start_rank(args):
   return rank, dev, distributed, pf
 
 
-def policy_config(args) -> None:
+def policy_config(args, ctx=None, emit=True):
   """BASELINE.json configs[4] (SURVEY.md 8d "Config 5"): the configs[1] batch per GPU driven through
   `BatchedEnvironment.step()` by a SAC-shaped actor (2 x 128 MLP, tanh-squashed Gaussian, the policy
   network of the reference's SAC notebook) evaluated on the environment's own GPU -- observations
   never leave HBM, data-parallel actors, no per-step collective.  env-steps/s INCLUDE policy inference
   and the host-side step inputs.  tf-agents is not installable here: the loop makes the same env API
   calls (`reset()`, `step(action)` -> TimeStep) a tf-agents driver would."""
-  rank, dev, distributed, pf = start_rank(args)
+  rank, dev, distributed, pf = ctx if ctx is not None else start_rank(args)
   local_rank, world = dev.index, pf["ranks"]
   if distributed:
     import torch.distributed as dist
@@ -439,11 +503,12 @@ def policy_config(args) -> None:
     n_gathered = int(sd.gather_returns(returns, world * B).numel())
     torch.cuda.synchronize(dev)
     gather_ms = (time.perf_counter() - g0) * 1e3
+  result = None
   if rank == 0:
     li = env.sim.launch_info
     env_steps_per_s = world * B * K / elapsed
     achieved = li["algorithmic_bytes_per_env_step"] * B * K / elapsed / 1e9
-    print(json.dumps({
+    result = {
         "metric": "zone-updates/sec (env-steps/sec x 9 zones) INCLUDING policy inference, batch=64k buildings per GPU",
         "value": env_steps_per_s * Z, "unit": "zone-updates/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -454,16 +519,52 @@ def policy_config(args) -> None:
                                "by a SAC-shaped actor (2 x 128 MLP, tanh-squashed Gaussian) on the environment's GPU",
                    "buildings_per_gpu": B, "grid": [H, Wd], "zones": Z, "policy": "MLP %d-128-128-4, fp32" % O,
                    "mean_return_per_step": float(returns.mean()) / K,
+                   "mean_sweeps_per_env_step_last": float(env.info[:, 4].mean()) if args.check_buildings else None,
                    **({"parity_vs_oracle": check.verify()} if check else {}),
                    "parallelism": f"{world} x (building shard + its own actor), no per-step collective", "launch": li},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?"),
                      "note": "over the whole env step including the policy network (a smooth policy needs fewer "
-                             "Gauss-Seidel sweeps per step than random actions)"}}))
+                             "Gauss-Seidel sweeps per step than random actions)"}}
+    if emit:
+      print(json.dumps(result))
   env.close()
-  if distributed:
+  if emit and distributed:
     dist.destroy_process_group()
+  return result
+
+
+def also_legs(args, dev, pf) -> dict:
+  """The default run's extra legs (after the headline's timed region; nothing inside it changes): a bounded run
+  of BASELINE.json configs[2] (`--config mixed`) and configs[4] (`--config policy`) at their own batch sizes, so
+  that the driver's record carries them too.  Each leg is the same function `--config ...` runs, with a handful
+  of oracle twins per class as its in-run parity check; a leg that fails reports its error instead of taking
+  the headline down."""
+  import copy
+  import traceback
+  out = {}
+  for name, fn, twins in (("mixed", mixed_config, 8), ("policy", policy_config, 32)):
+    a = copy.copy(args)
+    a.steps, a.warmup, a.check_buildings, a.config = 24, 12, twins, name
+    t0 = time.perf_counter()
+    try:
+      r = fn(a, ctx=(0, dev, False, pf), emit=False)
+      leg = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+             "warmup": r["warmup"], "workload": r["config"]["workload"], "roofline_frac": r["roofline"]["frac"]}
+      if name == "mixed":
+        leg["classes"] = {k: {f: v[f] for f in ("kernel", "buildings", "zones", "mean_sweeps_per_env_step", "step_ms_in_round",
+                                                "sweep_kernel_ms_alone", "roofline_frac_alone", "parity_vs_oracle") if f in v}
+                          for k, v in r["config"]["classes"].items()}
+      else:
+        leg["kernel"] = r["roofline"]["kernel"]
+        leg["parity_vs_oracle"] = r["config"].get("parity_vs_oracle")
+        leg["mean_return_per_step"] = r["config"]["mean_return_per_step"]
+    except Exception as exc:   # noqa: BLE001 -- the headline line must still be printed
+      leg = {"error": f"{type(exc).__name__}: {exc}", "trace": traceback.format_exc()[-600:]}
+    leg["leg_wall_s"] = time.perf_counter() - t0
+    out[name] = leg
+  return out
 
 
 def main() -> None:
@@ -485,6 +586,9 @@ def main() -> None:
   ap.add_argument("--through-env-api", action="store_true",
                   help="time BatchedEnvironment.step() itself (the public API) instead of the three phase launches; "
                        "roofline.avg_kernel_ms is then the whole step's GPU time")
+  ap.add_argument("--no-also", action="store_true",
+                  help="skip the default run's extra legs (bounded --config mixed and --config policy runs after the headline, "
+                       "reported under \"also\")")
   ap.add_argument("--stub-step", action="store_true",
                   help="developer / CPU test: launcher, barrier and return-gather plumbing with a stub step (gloo)")
   args = ap.parse_args()
@@ -492,11 +596,11 @@ def main() -> None:
   if args.stub_step:
     return stub_rank(args)
   if args.config == "mixed":
-    if args.gpus != 1:
-      raise SystemExit("bench.py --config mixed is a one-GPU configuration")
-    return mixed_config(args)
+    mixed_config(args)
+    return
   if args.config == "policy":
-    return policy_config(args)
+    policy_config(args)
+    return
 
   rank, dev, distributed, pf = start_rank(args)
   local_rank, world = dev.index, pf["ranks"]
@@ -632,20 +736,24 @@ def main() -> None:
     if os.path.exists(tr):   # PMC passes of this same command (tools/collect_profiles.sh)
       with open(tr) as fh:
         t = json.load(fh)
+      src_now = kernel_source_sha256()
       # the counters were taken on a particular kernel and state layout: a profile of another one is not this run's traffic
       rest = (8 * 4 + 4 * 2) * Z + 16 * 16 + 8 + 4 * env.sim.O + 4
       state_bytes = (li["state_bytes_per_env_step"] - rest) // 2
       same_kernel = _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?") in str(t.get("kernel", ""))
-      if same_kernel and t.get("state_bytes_per_building") == state_bytes and B == 65536:
+      same_source = t.get("kernel_source_sha256") == src_now
+      if same_kernel and same_source and t.get("state_bytes_per_building") == state_bytes and B == 65536:
         result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
         result["roofline"]["traffic_source"] = t.get("source")
         # replayed from the committed PMC profile of this command (a run cannot read its own TCC counters);
-        # the guards above tie it to this kernel, state layout and batch
+        # the guards above tie it to this kernel's SOURCES (a hash of the files it is compiled from), state layout and batch
         result["roofline"]["traffic_measured_in_run"] = False
         result["roofline"]["traffic_profile_commit"] = t.get("commit")
+        result["roofline"]["traffic_profile_kernel_source_sha256"] = src_now
       else:
         result["roofline"]["traffic_measured_in_run"] = False
-        result["roofline"]["traffic_source"] = (f"profiles/traffic_latest.json is for kernel {t.get('kernel')!r}, "
+        result["roofline"]["traffic_source"] = (f"profiles/traffic_latest.json is for kernel {t.get('kernel')!r} built from sources "
+                                                f"{str(t.get('kernel_source_sha256'))[:12]} (this run: {src_now[:12]}), "
                                                 f"{t.get('state_bytes_per_building')} state bytes per building, 65,536 buildings: not this run")
     if world == 1 and not args.no_cpu_baseline:
       nb_s = 2048
@@ -666,8 +774,11 @@ def main() -> None:
       env2.close()
       base["parity_max_abs_dT_K"] = dT
       result["cpu_baseline"] = base
-    print(json.dumps(result))
   env.close()
+  if rank == 0:
+    if world == 1 and not args.no_also and not args.through_env_api and B == 65536:
+      result["also"] = also_legs(args, dev, pf)   # after the headline (and its CPU leg): configs[2] and configs[4], bounded
+    print(json.dumps(result))
   if distributed:
     dist.destroy_process_group()
 

@@ -44,11 +44,13 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 7
+#define SB_ABI_VERSION 8
 #define SB_NUM_ACTIONS 2   /* the SB1 action set (sim_config.gin:239-242): boiler supply_water_setpoint, AHU
                             * supply_air_heating_temperature_setpoint -- the default of sb_params.n_actions */
 #define SB_ACTION_KEEP (-3.0e38f)
-#define SB_MAX_ACTIONS 16  /* settable fields an action vector may drive (sb_params.act_kind) */
+/* (ABI 8: no SB_MAX_ACTIONS any more -- an action vector may drive every settable field of the simulated devices, one
+ * column each: the boiler's setpoint, the air handler's two, one damper command per VAV = 3 + Z columns;
+ * environment/environment.py:631-635 admits every device setpoint that has a normaliser) */
 #define SB_NUM_AUX 7       /* hod cos/sin, dow cos/sin, comfort_now, comfort_soon, num_occupants */
 #define SB_INFO_STRIDE 24  /* floats per building in the optional info output */
 
@@ -100,10 +102,10 @@ typedef struct sb_params {
   /* the action vector: column i drives field act_kind[i] (of zone act_zone[i] for a VAV field) with
    * native value (a + 1) / 2 * (act_hi[i] - act_lo[i]) + act_lo[i] (bounded_action_normalizer.py:73-98),
    * rounded to the proto's float.  Applied in column order after the thermostats (simulator_building.py:204-263). */
-  int32_t n_actions;                 /* 1 .. SB_MAX_ACTIONS */
-  int32_t act_kind[SB_MAX_ACTIONS];  /* sb_action_kind */
-  int32_t act_zone[SB_MAX_ACTIONS];  /* zone index for SB_ACT_VAV_*; ignored otherwise */
-  double act_lo[SB_MAX_ACTIONS], act_hi[SB_MAX_ACTIONS];
+  int32_t n_actions;        /* 1 .. 3 + Z: at most one column per settable field (sb_create checks) */
+  const int32_t *act_kind;  /* [n_actions] sb_action_kind.  Host pointers, copied by sb_create (ABI <= 7: arrays of 16) */
+  const int32_t *act_zone;  /* [n_actions] zone index for SB_ACT_VAV_*; ignored otherwise */
+  const double *act_lo, *act_hi; /* [n_actions] native range of the column's normaliser */
 } sb_params;
 
 /* Observation vector layout (environment.py:543-553,783-813): the device fields in sorted

@@ -11,10 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SBSIM_LIB") or os.path.join(_HERE, "libsbsim_amd.so")
 
 SB_NUM_ACTIONS = 2     # the SB1 action set; sb_params.n_actions is the width of an action row
-SB_MAX_ACTIONS = 16
 SB_ACTION_KEEP = -3.0e38   # sb_step_in.actions_native: this column leaves its field alone
 SB_NUM_AUX = 7
-SB_ABI_VERSION = 7   # include/sbsim_amd.h
+SB_ABI_VERSION = 8   # include/sbsim_amd.h
 # sb_action_kind
 SB_ACT_BOILER_SUPPLY_WATER_SETPOINT, SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT = 0, 1
 SB_ACT_AHU_SUPPLY_AIR_COOLING_SETPOINT, SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND = 2, 3
@@ -47,8 +46,8 @@ PARAM_FIELDS = [
     ("max_prod", C.c_double), ("min_prod", C.c_double), ("max_elec", C.c_double),
     ("max_gas", C.c_double), ("prod_delta", C.c_double), ("prod_stiff", C.c_double),
     ("w_prod", C.c_double), ("w_cost", C.c_double), ("w_carbon", C.c_double),
-    ("n_actions", C.c_int32), ("act_kind", C.c_int32 * SB_MAX_ACTIONS), ("act_zone", C.c_int32 * SB_MAX_ACTIONS),
-    ("act_lo", C.c_double * SB_MAX_ACTIONS), ("act_hi", C.c_double * SB_MAX_ACTIONS),
+    ("n_actions", C.c_int32), ("act_kind", C.POINTER(C.c_int32)), ("act_zone", C.POINTER(C.c_int32)),
+    ("act_lo", C.POINTER(C.c_double)), ("act_hi", C.POINTER(C.c_double)),
 ]
 
 

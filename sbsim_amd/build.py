@@ -19,7 +19,11 @@ HEADERS = [os.path.join(CSRC, "sb_device.h"), os.path.join(CSRC, "sb_host.h"), o
            os.path.join(ROOT, "include", "sbsim_amd.h")]
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(_HERE, "libsbsim_amd.so")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-fPIC"]
+# -amdgpu-atomic-optimizer-strategy=None: the optimizer turns the sweep kernels' one-lane draw (`if (lane == 0) atomicAdd(next_b, 1)`)
+# into a wave reduction that reads the atomic's result AT ONCE -- an s_waitcnt vmcnt(0), i.e. a wait for the next building's rows
+# (all in flight at that point) at the top of every building (step_roll.hip)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-fPIC",
+               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def hipcc() -> str:

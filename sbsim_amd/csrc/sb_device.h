@@ -78,6 +78,8 @@ struct Dev {
   int state_doubles;       // doubles of HBM state per building
   const uint8_t *tcls;     // mode 3: [T][NR] classes of the tail cells (class * 8)
   const uint8_t *tcset;    // mode 3: [T][NR] coefficient sets of the tail cells (set * 8)
+  const double *tmulS;     // mode 3: the tail scan's static multipliers (sweep_common.h, tail_pass_static), tmul_doubles of them
+  int tmul_doubles;
   const double *csetab;    // mode 3: [ncset][4] distinct (bU, bD, bL, bR); the sweep's class bytes index this table
   int ncset;
   int csetab_doubles;      // doubles of csetab (mode 4 with two_sym: [sets][2] for the wavefront's cells, then [sets][4] for the tail cells)
@@ -90,6 +92,7 @@ struct Dev {
   int ZRS;                 // row stride of the zone-sum scratch [Z+1][ZRS] that aliases A (RS | 1)
   int Ws;                  // trimmed width
   int n_ring;              // exterior-space cells outside the trim box (all of class "ambient")
+  double n_ring_f64;       // (double)n_ring: a kernel argument, not a conversion the compiler keeps in a VGPR pair for the kernel's lifetime
   int lw[4], l0[2], rowbase[2], nch[2]; // per wave: rows (mode 5: up to four wavefronts), first lane, first row, 8-step chunks
   int lag;                 // wave 1 runs `lag` chunk slots behind wave 0
   int nslots;              // chunk slots (barriers) per sweep
@@ -135,6 +138,11 @@ struct Dev {
   int n_src, n_hist, hist_normalize; // optional HistogramReducer
   const int *src_dest, *hist_col, *hist_off;
   const double *hist_bins;
+  // the action vector (sb_params.act_*: host arrays, copied): device copies, and per zone the column that carries its damper command
+  const int *act_kind, *act_zone; // [n_actions]
+  const double *act_lo, *act_hi;  // [n_actions]
+  const int *zone_act;            // [Z] action column of the zone's supply_air_damper_percentage_command, or -1
+  int n_damper_actions;           // columns of that kind (0: k_pre never looks at zone_act)
   long long *dbg;          // optional [16] phase time stamps of wave 0's first building (+ [2048] with dbg_timeline)
   int dbg_timeline;        // SBSIM_DEBUG_TIMELINE=1 (developer builds of step_band.hip)
   sb_params p;
@@ -188,6 +196,7 @@ int sweep_roll_lds_slots(int NR);            // slots of A in LDS
 int sweep_roll_a_stride(int NR);             // row stride of A in LDS (doubles)
 int sweep_roll_seam_doubles(int NR, int T);  // LDS doubles of [pad | row 63 | pad][tail rows]
 int sweep_roll_waves();                      // wavefronts (= buildings) per workgroup
+int sweep_roll_tail_mul_doubles(int NR, int T); // LDS doubles of the tail scan's static multipliers
 
 // ---------------------------------------------------------------- wave helpers
 // DPP move of a double; lanes without a source (or outside row_mask) receive 0.
@@ -224,6 +233,18 @@ __device__ __forceinline__ double wave_max(double v) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(t), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(t), 63);
   return __hiloint2double(hi, lo);
+}
+// Wave-wide max of non-negative 32-bit integers (high words of non-negative doubles order like the doubles), same
+// pattern; wave-uniform result.
+__device__ __forceinline__ int wave_max_i32(int v) {
+  int t = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));
+  t = max(t, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));
+  t = max(t, __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, true));
+  t = max(t, __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, true));
+  t = max(t, __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, true));
+  t = max(t, __builtin_amdgcn_update_dpp(t, t, 0x142, 0xa, 0xf, false)); // rows outside the mask keep t
+  t = max(t, __builtin_amdgcn_update_dpp(t, t, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(t, 63);
 }
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
@@ -437,22 +458,25 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   const bool rejected = in.reject_dev && in.reject_dev[b];
   const bool acting = in.has_action && !rejected;
   v.rejected = rejected;
-  double damper_cmd[SB_MAX_ACTIONS]; // agent damper commands of this step, by action column
-  unsigned damper_set = 0;           // bit i: column i carries an accepted damper command (no NaN sentinel: -fno-honor-nans)
+  // The action vector, column by column (bounded_action_normalizer.py:73-98, then the proto's float field).  A damper command
+  // is only VALIDATED here (vav.py:125-129: the setter raises outside [0, 1] -> the step's reward is -inf); the zone loop below
+  // reads its own column again (zone_act) -- no per-building array of commands, whatever the number of VAVs.
   bool boiler_action = false;
-  for (int i = 0; i < p.n_actions; ++i) {
-    damper_cmd[i] = 0.0;
-    if (!acting) continue; // bounded_action_normalizer.py:73-98, then the proto float field
+  auto native_of = [&](int i, bool &present) {
     const double ai = (double)s.actions[(size_t)b * p.n_actions + i];
-    if (in.actions_native && ai <= (double)SB_ACTION_KEEP) continue; // the request does not mention this field
-    const double native = in.actions_native ? ai : (double)(float)((ai + 1.0) / 2.0 * (p.act_hi[i] - p.act_lo[i]) + p.act_lo[i]);
-    switch (p.act_kind[i]) {
+    present = !(in.actions_native && ai <= (double)SB_ACTION_KEEP); // (else: the request does not mention this field)
+    return in.actions_native ? ai : (double)(float)((ai + 1.0) / 2.0 * (a.act_hi[i] - a.act_lo[i]) + a.act_lo[i]);
+  };
+  for (int i = 0; i < p.n_actions && acting; ++i) {
+    bool present;
+    const double native = native_of(i, present);
+    if (!present) continue;
+    switch (a.act_kind[i]) {
       case SB_ACT_BOILER_SUPPLY_WATER_SETPOINT: v.blr_sp = native; boiler_action = true; break;
       case SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT: v.heat_sp = native; break;
       case SB_ACT_AHU_SUPPLY_AIR_COOLING_SETPOINT: v.cool_sp = native; break;
       default: // vav.py:125-129: the setter raises outside [0, 1] -> REJECTED_NOT_ENABLED_OR_AVAILABLE
         if (native < 0.0 || native > 1.0) v.rejected = 1;
-        else { damper_cmd[i] = native; damper_set |= 1u << i; }
     }
   }
   const double recirc = S[11];
@@ -509,8 +533,14 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
     }
     double damper = (mode == 1 || mode == 2) ? 1.0 : 0.1;
     if (rejected) damper = dm8[k];                          // nobody touched the VAV: what it had
-    for (int i = 0; i < p.n_actions; ++i)                   // set_action after update_settings
-      if ((damper_set >> i & 1u) && p.act_zone[i] == z) damper = damper_cmd[i];
+    if (acting && a.n_damper_actions > 0) {                  // set_action after update_settings
+      const int col = a.zone_act[z];
+      if (col >= 0) {
+        bool present;
+        const double native = native_of(col, present);
+        if (present && native >= 0.0 && native <= 1.0) damper = native;
+      }
+    }
     const double valve = valve_open ? 1.0 : 0.0;
     const double reheat = valve * p.vav_max_water_flow;
     const double air = damper * p.vav_max_air_flow;

@@ -87,6 +87,9 @@ struct sb_handle {
   DevBuf<double> abuf; // step_stream.hip: A = ap*Tprev + g of the buildings in flight
   DevBuf<double> redo_scratch; // step_roll.hip: see Dev
   DevBuf<int> redo_ctr, redo_list, zs_off;
+  DevBuf<int> act_kind, act_zone, zone_act; // the action vector's tables (sb_params.act_*) on the device
+  DevBuf<double> act_lo, act_hi;
+  DevBuf<double> tmul; // step_roll.hip: the tail scan's static multipliers
   DevBuf<double> ctab, csetab, temp, zmean, zair, damper, qz, scal, obs_mean, obs_sigma, ring, gtabg, zsum, gsum,
       hist_bins;
   DevBuf<int> czone, zone_off, zone_cells_l, mode, col_zone, zblk_zone, cell_state, nsw, next_b, src_dest,

@@ -36,9 +36,10 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps, int fir
     double s = 0.0, rlo = INFINITY, rhi = -INFINITY;
     if (a.reg) {
       double *T = a.temp + (size_t)b * a.state_doubles;
+      const double *S0 = a.scal + (size_t)b * kNScal;
+      const bool ring_uniform = S0[16] == S0[17]; // (temps_only) the ring holds one value: the ambient temperature of the last step
       for (int g = lane; g < a.N; g += 64) {
-        const double v = temps ? temps[(size_t)b * a.N + g] : initial_temp;
-        s += v;
+        double v = temps ? temps[(size_t)b * a.N + g] : initial_temp;
         const int cs = a.cell_state[g];
         if (cs >= 0) {
           T[cs] = v;
@@ -46,7 +47,10 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps, int fir
           a.ring[(size_t)b * a.n_ring + (-cs - 1)] = v;
           rlo = fmin(rlo, v);
           rhi = fmax(rhi, v);
+        } else { // sb_set_temps leaves exterior space alone: the grid mean counts what the ring holds, not what `temps` says
+          v = ring_uniform ? S0[16] : a.ring[(size_t)b * a.n_ring + (-cs - 1)];
         }
+        s += v;
       }
       rlo = wave_min(rlo);
       rhi = wave_max(rhi);
@@ -79,6 +83,9 @@ __global__ void k_reset(Dev a, double initial_temp, const double *temps, int fir
         a.qz[o] = 0.0;     // building.py:791 input_q <- 0
       }
     }
+    // sb_set_temps: the recirculation temperature of the next step is the mean of the NEW grid (simulator.py:423-426 takes
+    // building.temp.mean() every step; S[11] caches it between steps)
+    if (lane == 0 && temps_only) a.scal[(size_t)b * kNScal + 11] = s / (double)a.N;
     if (lane == 0 && !temps_only) {
       double *S = a.scal + (size_t)b * kNScal;
       S[0] = a.p.ahu_heat_sp; S[1] = a.p.ahu_cool_sp; S[2] = 0.0; S[3] = 0.0; // air_handler.py:131-139
@@ -175,6 +182,7 @@ struct RegPlan {
   int NR = 0, P = 0, RS = 0, Ws = 0, r0 = 0, c0 = 0, n_ring = 0, T = 0, state_doubles = 0, ts = 32;
   std::vector<uint8_t> tcls, tcset;
   std::vector<double> csetab; // mode 3: distinct (bU, bD, bL, bR), the pad set (all zero) last
+  std::vector<double> tmul;   // mode 3: the tail scan's static multipliers (sweep_common.h, tail_pass_static)
   int lw[4] = {0, 0, 0, 0}, l0[2] = {0, 0}, rowbase[2] = {0, 0}, nch[2] = {0, 0};
   int lag = 0, nslots = 0, steps = 0;
   int r_seam = 0, r_A = 0, r_xchg = 0, lds_bytes = 0, wg_per_cu = 0, AS = 0;
@@ -774,7 +782,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
       r.r_seam = 2 * TS;
       r.r_A = r.r_seam + ((sweep_roll_seam_doubles(NR, r.T) + 1) & ~1); // 16-byte aligned rows
       r.wave_doubles = r.r_A + RS * nl_slots; // rows of AS slots, then [RS][nl_slots - AS]
-      r.lds_bytes = (r.r_cmap + (NR / 8) * 64 + r.waves_per_wg * r.wave_doubles) * 8;
+      r.lds_bytes = (r.r_cmap + (NR / 8) * 64 + sweep_roll_tail_mul_doubles(NR, r.T) + r.waves_per_wg * r.wave_doubles) * 8;
       if (const char *pad = getenv("SBSIM_DEBUG_LDS_PAD")) r.lds_bytes += atoi(pad);
       r.wg_per_cu = r.lds_bytes <= kLdsCap ? 1 : 0;
       return;
@@ -836,6 +844,41 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
       r.tcls[(size_t)t * NR + c] = (uint8_t)(8 * cell_class(64 + t, c));
       r.tcset[(size_t)t * NR + c] = (uint8_t)(8 * set_of[cell_class(64 + t, c)]);
     }
+  if (P == 3 && r.T > 0) {
+    // The tail scan (sweep_common.h): along a tail row x_c = bL_c x_{c-1} + q_c; lane l >= L0 composes its two
+    // columns, six DPP levels scan the lanes.  The multiplicative half of every level does not depend on the
+    // temperatures: it is run here, in affine_scan's own order (bit-identical), and the kernel reads what each
+    // level multiplies by: `a` entering levels 1..5, 0 where the level has no source lane for the lane.
+    const int n = NR / 2, L0 = 64 - n;
+    r.tmul.assign((size_t)sweep_roll_tail_mul_doubles(NR, r.T), 0.0);
+    auto src_lane = [](int level, int lane) { // the DPP source of affine_scan's levels: row_shr 1 / 2 / 4 / 8, row_bcast:15 (rows 1, 3), row_bcast:31 (rows 2, 3)
+      const int row = lane >> 4, i = lane & 15;
+      switch (level) {
+        case 0: return i >= 1 ? lane - 1 : -1;
+        case 1: return i >= 2 ? lane - 2 : -1;
+        case 2: return i >= 4 ? lane - 4 : -1;
+        case 3: return i >= 8 ? lane - 8 : -1;
+        case 4: return (row & 1) ? (row << 4) - 1 : -1;
+        default: return row >= 2 ? 31 : -1;
+      }
+    };
+    for (int t = 0; t < r.T; ++t) {
+      auto bL = [&](int c) { const int cl = cell_class(64 + t, c); return cl == pad ? 0.0 : coef(cl, 2); };
+      double a[64], an[64];
+      for (int lane = 0; lane < 64; ++lane) a[lane] = lane >= L0 ? bL(2 * (lane - L0) + 1) * bL(2 * (lane - L0)) : 0.0;
+      for (int d = 0; d < 6; ++d) {
+        for (int lane = 0; lane < 64; ++lane) {
+          const int src = src_lane(d, lane), lp = lane - L0;
+          const double A = src >= 0 ? a[lane] : 0.0;
+          if (lp >= 0 && (d == 1 || d == 2)) r.tmul[(size_t)4 * n * t + 2 * lp + (d - 1)] = A;
+          if (lp >= 0 && (d == 3 || d == 4)) r.tmul[(size_t)4 * n * t + 2 * n + 2 * lp + (d - 3)] = A;
+          if (lp >= 0 && d == 5) r.tmul[(size_t)4 * n * r.T + 2 * lp + t] = A;
+          an[lane] = a[lane] * (src >= 0 ? a[src] : 1.0);
+        }
+        std::memcpy(a, an, sizeof(a));
+      }
+    }
+  }
   for (int w = 0; w < nw; ++w)
     for (int lane = 0; lane < 64; ++lane) {
       const int lp = lane - r.l0[w];
@@ -1047,14 +1090,29 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     return fail(SB_ERR_INVALID, "sb_create: time_step_sec and iteration_limit must be positive");
   if (params->ahu_cool_sp <= params->ahu_heat_sp) // air_handler.py:60-64
     return fail(SB_ERR_INVALID, "cooling_air_temp_setpoint must greater than heating_air_temp_setpoint");
-  if (params->n_actions < 1 || params->n_actions > SB_MAX_ACTIONS)
-    return fail(SB_ERR_INVALID, "sb_create: n_actions must be in 1..SB_MAX_ACTIONS");
-  for (int i = 0; i < params->n_actions; ++i) {
-    const int k = params->act_kind[i];
-    if (k < SB_ACT_BOILER_SUPPLY_WATER_SETPOINT || k > SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND)
-      return fail(SB_ERR_INVALID, "sb_create: unknown action kind");
-    if (k == SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND && (params->act_zone[i] < 0 || params->act_zone[i] >= plan->Z))
-      return fail(SB_ERR_INVALID, "sb_create: VAV action for a zone the floor plan does not have");
+  if (params->n_actions < 1 || params->n_actions > 3 + plan->Z)
+    return fail(SB_ERR_INVALID, "sb_create: n_actions must be in 1 .. 3 + zones (one column per settable field)");
+  if (!params->act_kind || !params->act_zone || !params->act_lo || !params->act_hi)
+    return fail(SB_ERR_INVALID, "sb_create: null action table (sb_params.act_kind / act_zone / act_lo / act_hi)");
+  std::vector<int> zone_act((size_t)std::max(plan->Z, 1), -1);
+  int n_damper_actions = 0;
+  {
+    int seen[3] = {0, 0, 0};
+    for (int i = 0; i < params->n_actions; ++i) {
+      const int k = params->act_kind[i];
+      if (k < SB_ACT_BOILER_SUPPLY_WATER_SETPOINT || k > SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND)
+        return fail(SB_ERR_INVALID, "sb_create: unknown action kind");
+      if (k == SB_ACT_VAV_SUPPLY_AIR_DAMPER_COMMAND) {
+        const int z = params->act_zone[i];
+        if (z < 0 || z >= plan->Z) return fail(SB_ERR_INVALID, "sb_create: VAV action for a zone the floor plan does not have");
+        // environment.py:591-653 keys its action normalisers by (device, setpoint): a field has one column
+        if (zone_act[z] >= 0) return fail(SB_ERR_INVALID, "sb_create: two action columns drive the same VAV damper");
+        zone_act[z] = i;
+        ++n_damper_actions;
+      } else if (seen[k]++) {
+        return fail(SB_ERR_INVALID, "sb_create: two action columns drive the same setpoint");
+      }
+    }
   }
   if (obs->n_obs < 1) return fail(SB_ERR_INVALID, "sb_create: empty observation layout");
   if (!obs->mean || !obs->sigma || (plan->Z > 0 && !obs->col_zone))
@@ -1090,6 +1148,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   d.Np = ((d.N + 1) & ~1) + 2 * kPad;
   d.ncls = plan->n_classes;
   d.p = *params;
+  d.p.act_kind = d.p.act_zone = nullptr; d.p.act_lo = d.p.act_hi = nullptr; // (host pointers: the device reads Dev::act_*)
   d.reg = r.ok ? 1 : 0;
   fill_launch_info(plan, r, q, obs->n_obs, h->cus, n_buildings, &h->info, params->n_actions);
 
@@ -1108,7 +1167,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   for (int g = 0; g < d.N; ++g) h->h_state_index[g] = d.reg ? r.cell_state[g] : kPad + g;
   if (d.reg) {
     d.pitch = d.W; d.NL = d.N; d.ts = r.ts;
-    d.NR = r.NR; d.P = r.P; d.RS = r.RS; d.Ws = r.Ws; d.n_ring = r.n_ring;
+    d.NR = r.NR; d.P = r.P; d.RS = r.RS; d.Ws = r.Ws; d.n_ring = r.n_ring; d.n_ring_f64 = (double)r.n_ring;
     d.T = r.T; d.state_doubles = r.state_doubles; d.AS = r.AS; d.ZRS = r.RS | 1;
     for (int w = 0; w < 2; ++w) { d.l0[w] = r.l0[w]; d.rowbase[w] = r.rowbase[w]; d.nch[w] = r.nch[w]; }
     for (int w = 0; w < 4; ++w) d.lw[w] = r.lw[w];
@@ -1130,6 +1189,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     SB_TRY(upload(h->tcls, r.tcls.data(), r.tcls.size()));
     SB_TRY(upload(h->tcset, r.tcset.data(), r.tcset.size()));
     SB_TRY(upload(h->csetab, r.csetab.data(), r.csetab.size()));
+    SB_TRY(upload(h->tmul, r.tmul.data(), r.tmul.size()));
+    d.tmulS = h->tmul.p; d.tmul_doubles = (int)r.tmul.size();
     d.tcset = h->tcset.p; d.csetab = h->csetab.p; d.ncset = (int)r.csetab.size() / 4;
     d.csetab_doubles = (int)r.csetab.size();
     d.two_sym = r.two_sym; d.two_level = r.two_level; d.tail_set_base = r.tail_set_base;
@@ -1218,6 +1279,13 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.cls = h->cls.p; d.zl16 = h->zl16.p; d.zblk_zone = h->zblk_zone.p; d.sched = h->sched.p;
     d.smask = h->smask.p;
   }
+  SB_TRY(upload(h->act_kind, params->act_kind, (size_t)params->n_actions));
+  SB_TRY(upload(h->act_zone, params->act_zone, (size_t)params->n_actions));
+  SB_TRY(upload(h->act_lo, params->act_lo, (size_t)params->n_actions));
+  SB_TRY(upload(h->act_hi, params->act_hi, (size_t)params->n_actions));
+  SB_TRY(upload(h->zone_act, zone_act.data(), zone_act.size()));
+  d.act_kind = h->act_kind.p; d.act_zone = h->act_zone.p; d.act_lo = h->act_lo.p; d.act_hi = h->act_hi.p;
+  d.zone_act = h->zone_act.p; d.n_damper_actions = n_damper_actions;
   SB_TRY(upload(h->col_zone, obs->col_zone, (size_t)d.Z));
   const size_t n_norm = (size_t)std::max(obs->n_obs, obs->n_src);
   SB_TRY(upload(h->obs_mean, obs->mean, n_norm));

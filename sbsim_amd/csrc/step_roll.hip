@@ -223,6 +223,45 @@ __device__ __forceinline__ void step(double (&e)[NR], double (&bk)[kWin], d2 ud,
   }
 }
 
+// A = ap * Tprev + g, slot by slot (slot j goes to position (j + 1) mod NR of the lane's rotated row: LDS, or a register
+// for the positions beyond lds_slots).  Per cell: one add that turns the class byte (class * 8: the byte offset into ap[]
+// and into g[]) into the table address, one ds_read2_b64, one FMA into a register of its own (accumulated in place in the
+// ds_read2 tuple, the value would have to be copied out for the write), half a ds_write2_b64.
+// There is no pass of its own for this: a slot's A is formed during the RAMP-UP of the building's first sweep (a few slots
+// before the ramp, three per pair of steps) -- slot j is first read two pairs before step j, and until step j every lane's
+// slot j still holds Tprev.  The slots come from HBM in this order (the previous building's hand-over loaded them), so the
+// ramp-up starts on the first ones while the last are still in flight: a pass over all 96 before the first step waited for
+// the LAST load (~2 k cycles per building, tools/prof_sweeps.py).
+constexpr int kA0 = 8; // slots whose A is formed before step 0
+template <int NR, int NAR>
+struct APass {
+  const unsigned long long (&cw)[(NR + 7) / 8]; // class bytes by slot, eight per word
+  unsigned tbase;                               // LDS address of ap[kTS] | g[kTS]
+  double *Aw, *Ax;                              // positions < a_stride / the rest of the lane's rotated row
+  double (&Areg)[NAR];
+  template <int J>
+  __device__ __forceinline__ d2 fetch() const {
+    static_assert(kTS * 8 == 256, "a class byte (class * 8) is the byte offset into ap[] and into g[]");
+    const unsigned h = (J & 7) < 4 ? (unsigned)cw[J >> 3] : (unsigned)(cw[J >> 3] >> 32);
+    unsigned ad; // table base + byte (J & 3) of h: one instruction
+    if constexpr ((J & 3) == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(ad) : "s"(tbase), "v"(h));
+    else if constexpr ((J & 3) == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ad) : "s"(tbase), "v"(h));
+    else if constexpr ((J & 3) == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(ad) : "s"(tbase), "v"(h));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ad) : "s"(tbase), "v"(h));
+    const __attribute__((address_space(3))) double *tp = (const __attribute__((address_space(3))) double *)ad;
+    return d2{tp[0], tp[kTS]}; // (ap, g): ds_read2_b64 offset1:32
+  }
+  template <int J>
+  __device__ __forceinline__ void put(const d2 &pg, const double &ej) const {
+    constexpr int q = (J + 1) % NR, NL = lds_slots(NR), AS = a_stride(NR);
+    double av;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(av) : "v"(pg.x), "v"(ej), "v"(pg.y));
+    if constexpr (q < AS) Aw[q] = av;
+    else if constexpr (q < NL) Ax[q - AS] = av;
+    else Areg[q - NL] = av;
+  }
+};
+
 // Pairs S, S + 2, .. < S1 (S odd).  While pair S runs, the LDS reads of pair S + 2 * kDepth are
 // issued in two halves; in the main loop (WRAP) the last kDepth pairs read ahead for the next
 // period's first pairs (whose seam values the caller reads after the tail scan).
@@ -230,13 +269,12 @@ __device__ __forceinline__ void step(double (&e)[NR], double (&bk)[kWin], d2 ud,
 #define SB_DEPTH 1
 #endif
 constexpr int kDepth = SB_DEPTH;          // pairs between the LDS reads of a step and its arithmetic
-constexpr int kBufs = kDepth + 1;         // 48 pairs per period: kBufs must divide 48
-static_assert(48 % kBufs == 0, "pair buffers rotate through a whole period");
+constexpr int kBufs = kDepth + 1;         // NR / 2 pairs per period: kBufs must divide that (checked per instantiation in k_sweep_roll)
 constexpr int pair_buf(int S) { return ((S - 1) / 2) % kBufs; }
 
-template <int NR, int S, int S1, bool WRAP, bool EXACT, int NAR>
-__device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], const double (&Areg)[NAR],
-                                           PairBuf (&pb)[kBufs], Ctx<NR> &x, Acc &acc) {
+template <int NR, int S, int S1, bool WRAP, bool EXACT, bool APASS, int NAR>
+__device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], double (&Areg)[NAR],
+                                           PairBuf (&pb)[kBufs], Ctx<NR> &x, Acc &acc, const APass<NR, NAR> &ap) {
   if constexpr (S < S1) {
     constexpr bool wrapped = WRAP && S + 2 * kDepth >= S1;
     constexpr int N = wrapped ? S + 2 * kDepth - NR : S + 2 * kDepth;
@@ -246,6 +284,13 @@ __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], 
     __builtin_amdgcn_sched_barrier(0);
 #endif
     load_first<NR, N, !wrapped>(nxt, x, Areg);
+    // the ramp-up forms A of three more slots per pair (APass): the table reads here, the values after the pair's steps
+    constexpr int j0 = kA0 + 3 * ((S - 1) / 2);
+    static_assert(!APASS || (S % 2 == 1 && j0 >= S + 2 * kDepth + 2), "a slot's A is written before the pair that reads it ahead");
+    d2 pa0 = d2{0.0, 0.0}, pa1 = d2{0.0, 0.0}, pa2 = d2{0.0, 0.0};
+    if constexpr (APASS && j0 < NR) pa0 = ap.template fetch<j0 < NR ? j0 : 0>();
+    if constexpr (APASS && j0 + 1 < NR) pa1 = ap.template fetch<j0 + 1 < NR ? j0 + 1 : 0>();
+    if constexpr (APASS && j0 + 2 < NR) pa2 = ap.template fetch<j0 + 2 < NR ? j0 + 2 : 0>();
     __builtin_amdgcn_sched_barrier(0);
     step<NR, S, EXACT>(e, bk, cur.ud0, cur.lr0, cur.A.x, cur.sm.x, acc);
     __builtin_amdgcn_sched_barrier(0);
@@ -253,7 +298,11 @@ __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], 
     __builtin_amdgcn_sched_barrier(0);
     step<NR, S + 1, EXACT>(e, bk, cur.ud1, cur.lr1, cur.A.y, cur.sm.y, acc);
     __builtin_amdgcn_sched_barrier(0);
-    roll_pairs<NR, S + 2, S1, WRAP, EXACT>(e, bk, Areg, pb, x, acc);
+    if constexpr (APASS && j0 < NR) ap.template put<j0 < NR ? j0 : 0>(pa0, e[j0 < NR ? j0 : 0]);
+    if constexpr (APASS && j0 + 1 < NR) ap.template put<j0 + 1 < NR ? j0 + 1 : 0>(pa1, e[j0 + 1 < NR ? j0 + 1 : 0]);
+    if constexpr (APASS && j0 + 2 < NR) ap.template put<j0 + 2 < NR ? j0 + 2 : 0>(pa2, e[j0 + 2 < NR ? j0 + 2 : 0]);
+    if constexpr (APASS) __builtin_amdgcn_sched_barrier(0);
+    roll_pairs<NR, S + 2, S1, WRAP, EXACT, APASS>(e, bk, Areg, pb, x, acc, ap);
   }
 }
 
@@ -265,7 +314,7 @@ __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], 
 // wait for the row loads of the next building issued before it, i.e. for HBM (that paced the loop at 125
 // cycles per pair of slots where its instructions issue in 35).
 #ifndef SB_ZPRE
-#define SB_ZPRE 16
+#define SB_ZPRE 8
 #endif
 constexpr int kZPre = SB_ZPRE; // zone-offset words read before the loop
 // HBM state layout: [NR / 2][64 lanes][2] -- a lane's two neighbouring slots are 16 bytes, so the
@@ -312,14 +361,17 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); // one wavefront per SIMD, each with its own buildings
   const int gw = (int)blockIdx.x * kWaves + wave;
   constexpr int kASlots = (NR + 7) / 8, kZSlots = (NR + 3) / 4, kCW = NR / 8;
+  static_assert((NR / 2) % kBufs == 0, "pair buffers rotate through a whole period: pair_buf() must not alias across the wrap");
   constexpr int kNL = lds_slots(NR), kAS = a_stride(NR), kNAR = NR - kNL > 0 ? NR - kNL : 2;
 
   // shared by the workgroup's wavefronts (read-only after this block):
   double *tabc = lds;                      // [kTS][4]: bU bD bL bR per coefficient set
   unsigned long long *ctab8 = (unsigned long long *)(lds + a.r_cmap); // [kCW][64]: the steps' coefficient sets, a byte each
   // the wavefront's own region:
-  double *wl = lds + a.r_cmap + kCW * 64 + (size_t)wave * a.lds_wave_doubles;
-  double *tapg = wl;                       // [kTS][2]: (ap, g) by class; g of this building -- one ds_read_b128 per cell of the A pass
+  double *tmul = lds + a.r_cmap + kCW * 64; // the tail scan's static multipliers (sweep_common.h, tail_pass_static)
+  double *wl = tmul + a.tmul_doubles + (size_t)wave * a.lds_wave_doubles;
+  double *tapg = wl;                       // [2][kTS]: ap by class, then g by class (g of this building); a class byte of the A pass (class * 8) IS the
+                                           // byte offset into either: one add (SDWA byte select) forms the address, one ds_read2_b64 fetches both
   double *tE0 = wl + a.r_seam + 2;         // the first tail row by column ([2 guards | NR | 2 guards]): lane 63's lower neighbours
   double *A = wl + a.r_A;                  // [64][kAS]; after the sweeps: zone sums [Z+1][ZRS]
   // every byte of LDS starts finite: reads next to the arrays' ends are multiplied by 0
@@ -327,7 +379,8 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
   __syncthreads();
   for (int i = threadIdx.x; i < 4 * kTS; i += blockDim.x) tabc[i] = i < 4 * a.ncset ? a.csetab[i] : 0.0;
   for (int i = threadIdx.x; i < kCW * 64; i += blockDim.x) ctab8[i] = a.cmapS[i];
-  if (lane < kTS) tapg[2 * lane] = lane <= a.ncls ? a.ctab[lane * 8 + 4] : 0.0; // row `ncls` is the pad class
+  for (int i = threadIdx.x; i < a.tmul_doubles; i += blockDim.x) tmul[i] = a.tmulS[i];
+  if (lane < kTS) tapg[lane] = lane <= a.ncls ? a.ctab[lane * 8 + 4] : 0.0; // row `ncls` is the pad class
   __syncthreads(); // the only barriers: from here on the wavefronts go their own ways
 
   const sb_params &p = a.p;
@@ -347,6 +400,9 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
   // (two 16-bit halves) and of their classes (two bytes)
   const bool tactive = tail_col<NR>(lane, 0) >= 0; // the lane owns two tail columns
   const int tc0 = tactive ? tail_col<NR>(lane, 0) : 0;
+  // where the lane's cells of the first tail row go: column tc0; idle lanes write their zeros to the zero guards.
+  // (an offset, not a pointer: per-lane pointers that live as long as the kernel end up in scratch)
+  const int tcw = tactive ? tc0 : -2;
   int tset[kTailMax], tcls8[kTailMax];
 #pragma unroll
   for (int t = 0; t < kTailMax; ++t) {
@@ -379,7 +435,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     nx_tnow = a.bld[(bb)].t_now;                                                                \
     nx_lo = a.scal[(size_t)(bb) * kNScal + 16];                                                 \
     nx_hi = a.scal[(size_t)(bb) * kNScal + 17];                                                 \
-    nx_g = a.gtabg[(size_t)(bb) * kTS + (lane & (kTS - 1))];                                    \
+    nx_g = a.gtabg[(size_t)(bb) * kTS + (opaque(lane) & (kTS - 1))]; /* (formed here: hoisted out of the building loop the per-lane address lives in scratch, and a scratch reload waits for every load in flight) */ \
     const double *tt_ = a.temp + (size_t)(bb) * a.state_doubles + NR * 64;                      \
     _Pragma("unroll") for (int t = 0; t < kTailMax; ++t)                                        \
       _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
@@ -398,91 +454,86 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     }
     SB_LOAD_AUX(b_first);
   }
+  // class bytes by slot (static per lane): read from L2 for the NEXT building right after a building's hand-over (the zone
+  // reduce and the set-up hide the latency), used by APass during the ramp-up
+  unsigned long long amapw[kASlots];
+#define SB_LOAD_AMAP(g0, g1)                                                                    \
+  do {                                                                                          \
+    const int o_ = opaque(0);                                                                   \
+    _Pragma("unroll") for (int g = (g0); g < (g1); ++g) amapw[g] = amap[o_ + g * 64];           \
+  } while (0)
+  constexpr int kAHalf = kASlots / 2; // words asked for before the next building's rows; the others after them
+  SB_LOAD_AMAP(0, kASlots);
   // Buildings need different numbers of sweeps: after its first building a workgroup draws the
   // next one from a device counter (zeroed before every launch).
   int iter = 0;
   for (int s = gw, sn = 0, b = b_first, bn = 0; s < nB; s = sn, b = bn, ++iter) {
     // the draw of the NEXT building: issued here, read before the hand-over (an atomic's round trip
     // to L2 is 1-2 us: the sweeps hide it)
+    // (nothing may USE the result here -- not even an addition: the wait for it is a wait for every load in flight, i.e. for
+    // the next building's rows; and the compiler's atomic optimizer, which turns the one-lane atomic into a wave reduction
+    // that reads the result at once, is off for this library: sbsim_amd/build.py)
     int nb = 0;
-    if (lane == 0) nb = a.sweep_wgs + atomicAdd(a.next_b, 1); // (the redo launch: its own counter and wavefront count)
+    if (lane == 0) nb = atomicAdd(a.next_b, 1); // (the redo launch: its own counter and wavefront count)
     SB_STAMP(0);
-    unsigned long long amapw[kASlots]; // issued here, used by the A pass: the setup hides the latency
-    {
-      const int o = opaque(0);
-#pragma unroll
-      for (int g = 0; g < kASlots; ++g) amapw[g] = amap[o + g * 64];
-      x.wn = x.cw[0]; // the first class word of the ramp-up
-    }
+    x.wn = x.cw[0]; // the first class word of the ramp-up
     __builtin_amdgcn_sched_barrier(0);
     const double t_now = nx_tnow;
     // exterior-space cells outside the trim box all become t_now in the first sweep
     // (simulator.py:256-258); their largest |delta| follows from their extreme values
     const double ring_d = a.n_ring > 0 ? fmax(fabs(t_now - nx_lo), fabs(t_now - nx_hi)) : 0.0;
-    if (lane < kTS) tapg[2 * lane + 1] = nx_g;
+    if (lane < kTS) tapg[kTS + opaque(lane)] = nx_g; // (the address formed here: see SB_LOAD_AUX)
     double tv[kTailMax][2]; // the lane's tail cells: current values
 #pragma unroll
     for (int t = 0; t < kTailMax; ++t)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) tv[t][k] = nx_tail[t][k];
-    if (tactive) *(d2 *)(tE0 + tc0) = d2{tv[0][0], tv[0][1]};
+      for (int k = 0; k < 2; ++k) tv[t][k] = tactive ? nx_tail[t][k] : 0.0; // (idle lanes compute zeros in the tail pass)
+    *(d2 *)(tE0 + opaque(tcw)) = d2{tv[0][0], tv[0][1]};
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(1);
     double At[kTailMax][2] = {{0.0, 0.0}, {0.0, 0.0}}; // A of the lane's tail cells
+    if constexpr (!EXACT) {
+      // unconditional (a row beyond T and the lanes that own no tail column hold the pad class: ap = 1, g = 0, on cells that
+      // are 0): four table reads in flight, then four FMAs -- a branch per cell is four LDS round trips one after the other
+      const double *pg[kTailMax][2];
 #pragma unroll
-    for (int t = 0; t < kTailMax; ++t)
+      for (int t = 0; t < kTailMax; ++t)
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if (t < a.T && tactive) {
-          const int c8 = (tcls8[t] >> (8 * k)) & 0xff;
-          const d2 pg = *(const d2 *)((const char *)tapg + 2 * c8);
-          At[t][k] = fma(pg.x, tv[t][k], pg.y);
-        }
+        for (int k = 0; k < 2; ++k) pg[t][k] = (const double *)((const char *)tapg + ((opaque(tcls8[t]) >> (8 * k)) & 0xff)); // (opaque: the addresses are formed here, not kept for the kernel's lifetime)
+      double tap[kTailMax][2], tg[kTailMax][2];
+#pragma unroll
+      for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { tap[t][k] = pg[t][k][0]; tg[t][k] = pg[t][k][kTS]; }
+#pragma unroll
+      for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) At[t][k] = fma(tap[t][k], tv[t][k], tg[t][k]);
+    } else { // (the float64 instantiation has no registers for the four reads in flight: scratch)
+#pragma unroll
+      for (int t = 0; t < kTailMax; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (t < a.T && tactive) {
+            const int c8 = (opaque(tcls8[t]) >> (8 * k)) & 0xff;
+            const double *pg = (const double *)((const char *)tapg + c8);
+            At[t][k] = fma(pg[0], tv[t][k], pg[kTS]);
+          }
+    }
 
-    // A = ap*Tprev + g for every cell of the lane's row (E = Tprev before the first sweep); slot j
-    // goes to position (j + 1) mod NR of the lane's row
+    // A = ap*Tprev + g (E = Tprev before the first sweep): the first kA0 slots here, the others during the ramp-up (APass)
     double Areg[kNAR];
     Areg[0] = 0.0;
+    const APass<NR, kNAR> ap{amapw, (unsigned)(size_t)(__attribute__((address_space(3))) double *)tapg, A + (size_t)R * kAS,
+                             A + 64 * kAS + (size_t)R * (kNL - kAS), Areg};
     {
-      const unsigned long long(&cwa)[kASlots] = amapw;
-      double *Aw = A + (size_t)R * kAS, *Ax = A + 64 * kAS + (size_t)R * (kNL - kAS);
-      auto at = [&](int q) { return q < kAS ? Aw + q : Ax + (q - kAS); }; // position q of the lane's rotated row
-      // groups of 8, software-pipelined: the table reads of group g+1 are issued before the A
-      // values of group g are written (the compiler cannot prove that A and the tables do not alias).
-      // One ds_read_b128 per cell ((ap, g) of its class), one ds_write_b64.
-      constexpr int kGroups = (NR + 7) / 8;
-      d2 pg[2][8];
-      auto fetch = [&](int g, d2 (&pp)[8]) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int j = min(8 * g + k, NR - 1);
-          const unsigned c16 = (unsigned)((cwa[j >> 3] >> (8 * (j & 7))) & 0xffull) * 2u;
-          pp[k] = *(const d2 *)((const char *)tapg + c16);
-        }
-      };
-      fetch(0, pg[0]);
-      double carry = 0.0; // A of an odd slot, waiting for its even partner
-#pragma unroll
-      for (int g = 0; g < kGroups; ++g) {
-        if (g + 1 < kGroups) fetch(g + 1, pg[(g + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (8 * g + k < NR) {
-            const int j = 8 * g + k;
-            const double av = fma(pg[g & 1][k].x, e[j], pg[g & 1][k].y);
-            const int q = (j + 1) % NR; // position in the rotated row
-#ifdef SB_A_WRITE_B128 // one 16-byte write per pair: the compiler assembles the pair with two v_mov -- three instructions and 13 LDS cycles against two and 12
-            if (j % 2 == 1 && j + 1 < NR && q + 1 < kNL) carry = av;
-            else if (j % 2 == 0 && j > 0 && q < kNL && q - 1 >= 0 && (q - 1) % 2 == 0) *(d2 *)at(q - 1) = d2{carry, av};
-            else
-#endif
-            if (q < kNL) *at(q) = av;
-            else Areg[q - kNL] = av;
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      static_assert(kA0 == 8 && kA0 + 3 * ((kWin - 1) / 2) >= NR, "the ramp-up's pairs reach the last slot");
+      const d2 g0 = ap.template fetch<0>(), g1 = ap.template fetch<1>(), g2 = ap.template fetch<2>(), g3 = ap.template fetch<3>(),
+               g4 = ap.template fetch<4>(), g5 = ap.template fetch<5>(), g6 = ap.template fetch<6>(), g7 = ap.template fetch<7>();
+      __builtin_amdgcn_sched_barrier(0);
+      ap.template put<0>(g0, e[0]); ap.template put<1>(g1, e[1]); ap.template put<2>(g2, e[2]); ap.template put<3>(g3, e[3]);
+      ap.template put<4>(g4, e[4]); ap.template put<5>(g5, e[5]); ap.template put<6>(g6, e[6]); ap.template put<7>(g7, e[7]);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -510,17 +561,21 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
         step<NR, 0, EXACT>(e, bk, ud, lr, x.Arow[1], 0.0, acc);
       }
       __builtin_amdgcn_sched_barrier(0);
-      roll_pairs<NR, 1, kWin, false, EXACT>(e, bk, Areg, pb, x, acc); // ramp-up; reads ahead for the first pairs of the period
+      roll_pairs<NR, 1, kWin, false, EXACT, true>(e, bk, Areg, pb, x, acc, ap); // ramp-up (+ A of the slots from kA0 on); reads ahead for the first pairs of the period
+      SB_STAMP(15);
 #pragma nounroll
       for (;;) { // simulator.py:348-368
         __builtin_amdgcn_sched_barrier(0);
 #ifdef SB_PHASE_STAMPS
-#define SB_STAMP2(i) do { if (a.dbg && gw == 0 && iter == 10 && n_sweeps == 1 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#ifndef SB_STAMP_SWEEP
+#define SB_STAMP_SWEEP 1 // which sweep of the building the period's stamps are taken in (0: the first one, right after the ramp-up)
+#endif
+#define SB_STAMP2(i) do { if (a.dbg && gw == 0 && iter == 10 && n_sweeps == SB_STAMP_SWEEP && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define SB_STAMP2(i) do { } while (0)
 #endif
         SB_STAMP2(10);
-        roll_pairs<NR, kWin, NR + kWin, true, EXACT>(e, bk, Areg, pb, x, acc);
+        roll_pairs<NR, kWin, NR + kWin, true, EXACT, false>(e, bk, Areg, pb, x, acc, ap);
         SB_STAMP2(11);
         // row 63's last column (lane 63's result of the period's last step) enters its shift register;
         // then both are reversed: lane l holds columns 2 (l - L0), 2 (l - L0) + 1, the tail scan's layout
@@ -537,21 +592,27 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
                                 __builtin_amdgcn_ds_bpermute(rev, __double2loint(acc.sro)));
         }
         SB_STAMP2(12);
-        const double dt_ = tail_pass<NR>(a.T, tactive, tE0 + tc0, U0, U1, tv, tset, At);
+        const double dt_ = tail_pass_static<NR>(a.T, tmul + opaque(tc0), tE0 + opaque(tcw), U0, U1, tv, tset, At); // tmul + 2 l'
+
         SB_STAMP2(13);
-        double md = wave_max(EXACT ? fmax(acc.cur, dt_) : dt_);
-        if (n_sweeps == 0) md = fmax(md, ring_d);
-        SB_STAMP2(14);
-        ++n_sweeps;
-        converged = md <= p.conv_threshold;
-        if constexpr (!EXACT) { // the wavefront's rows: lane 63 has collected every column's maximum (high words)
+        if constexpr (EXACT) {
+          double md = wave_max(fmax(acc.cur, dt_));
+          if (n_sweeps == 0) md = fmax(md, ring_d);
+          ++n_sweeps;
+          converged = md <= p.conv_threshold;
+        } else {
+          // the wavefront's rows: lane 63 has collected every column's maximum (high words); the tail cells' and the
+          // ring's join them as high words too (non-negative doubles order like their high words read as integers)
           asm("v_max_f32 %0, %0, %1" : "+v"(acc.fin) : "v"(acc.tr)); // the period's last step
-          const int m_hi = __builtin_amdgcn_readlane(acc.fin, 63), thr_hi = __double2hiint(p.conv_threshold);
+          int m_hi = max(__builtin_amdgcn_readlane(acc.fin, 63), wave_max_i32(__double2hiint(dt_)));
+          if (n_sweeps == 0) m_hi = max(m_hi, __double2hiint(ring_d));
+          const int thr_hi = __double2hiint(p.conv_threshold);
+          ++n_sweeps;
           acc.fin = 0;
           acc.tr = lanes_upto<62>() ? acc.tr : 0; // lane 63's was this sweep's last column: the next step's collect must not see it again
           const bool undecided = m_hi == thr_hi || (a.dbg_redo_mod > 0 && b % a.dbg_redo_mod == 0); // (a test hook)
-          if (converged && undecided) { redo = 1; break; } // 32 bits cannot tell: the exact kernel takes the building
-          converged = converged && m_hi < thr_hi;
+          if (m_hi <= thr_hi && undecided) { redo = 1; break; } // 32 bits cannot tell: the exact kernel takes the building
+          converged = m_hi < thr_hi;
         }
 #ifdef SB_EXP_DESYNC // timing experiments: sweep counts 1..9 by building number (mean 5), whatever the numbers are
         if (n_sweeps >= 1 + (int)(((unsigned)b * 2654435761u >> 13) % 9u)) break;
@@ -568,8 +629,16 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(3);
-    sn = __builtin_amdgcn_readfirstlane(nb);
+    sn = a.sweep_wgs + __builtin_amdgcn_readfirstlane(nb);
     bn = sn < nB ? building(sn) : 0;
+    // the next building's small inputs and the class bytes: asked for BEFORE its rows (the hand-over below), because
+    // memory operations return in order -- behind the rows, the set-up's first use of any of them waited for the last row
+    // (the class bytes of the first half of the slots only: the ramp-up reaches the other half ~3 k cycles in, when the
+    // rows have long arrived, and every value asked for here lives through the hand-over -- k_sweep_roll<96> has 28
+    // registers for that, not 40)
+    if (sn < nB) SB_LOAD_AUX(bn);
+    SB_LOAD_AMAP(0, kAHalf);
+    __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(4);
 
     // grid back to HBM.  Zone sums (A is dead now): every lane adds its cells into its own
@@ -600,7 +669,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(5);
-    if (sn < nB) SB_LOAD_AUX(bn);
+    SB_LOAD_AMAP(kAHalf, kASlots);
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(6);
     __builtin_amdgcn_wave_barrier();
@@ -627,7 +696,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
       }
       const double gsum = wave_sum(gacc);
       if (lane == 0 && !redo) {
-        a.gsum[b] = gsum + (double)a.n_ring * t_now;
+        a.gsum[b] = gsum + a.n_ring_f64 * t_now;
         a.nsw[b] = n_sweeps | (converged << 16);
       }
       if (lane == 0 && redo) a.redo_list[atomicAdd(a.redo_ctr, 1)] = b;
@@ -639,6 +708,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
   }
 #undef SB_STAMP
 #undef SB_LOAD_AUX
+#undef SB_LOAD_AMAP
 }
 
 } // namespace
@@ -648,6 +718,7 @@ int sweep_roll_lds_slots(int NR) { return lds_slots(NR); }
 int sweep_roll_a_stride(int NR) { return a_stride(NR); }
 int sweep_roll_seam_doubles(int NR, int T) { (void)T; return tail_row(NR); } // the first tail row, by column
 int sweep_roll_waves() { return kWaves; }
+int sweep_roll_tail_mul_doubles(int NR, int T) { return tail_mul_doubles(NR, T); } // the tail scan's static multipliers (shared by the workgroup)
 
 int sweep_roll_redo_workgroups() { return 8; } // the exact kernel's launch on the redo list (a handful of buildings per step at most)
 

@@ -104,5 +104,72 @@ __device__ __forceinline__ double tail_pass(int T, bool active, double *tE0c, do
   return dmax;
 }
 
+// ---------------------------------------------------------------- tail rows, static scan (step_roll.hip)
+// The multiplicative halves of the scan's composed maps -- the `a` of affine_scan at every level -- are
+// products of bL along the row: static per floor plan.  The planner runs that half on the host (the same
+// multiplications in the same order: bit-identical to affine_scan) and ships, per tail row and lane, the
+// value of `a` ENTERING levels 1..5 (level 0's is lr1.x * lr0.x, formed here from the coefficients the pass
+// reads anyway); 0 where a level has no source lane for the lane.  A level is then two DPP moves and one
+// FMA (affine_scan: four moves, four more that set up their `old` operands, an FMA and a multiplication).
+// A lane without a source reads 0 (bound_ctrl) or, in the rows a broadcast level's row_mask leaves out,
+// keeps the previous level's shifted value -- finite, times 0.
+// LDS layout of the table (shared by the workgroup), n = NR / 2 lanes own tail columns, l' = lane - (64 - n):
+//   [t < T][d2 (A1, A2)][n] [d2 (A3, A4)][n]   then   [d2 (A5 of row 0, A5 of row 1)][n]
+constexpr int tail_mul_doubles(int NR, int T) { return T > 0 ? (4 * T + 2) * (NR / 2) : 0; }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void scan_level(double &q, double A, double &qs) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(qs), __double2loint(q), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(qs), __double2hiint(q), CTRL, ROW_MASK, 0xf, true);
+  qs = __hiloint2double(hi, lo);
+  q = fma(A, qs, q);
+}
+
+// tm: the lane's entry of the table's first array (table + 2 l').  Lanes that own no tail column (pad coefficient
+// set, A = 0, cells 0) compute zeros; their tE0c points at the zero guards in front of the row.
+// (Tried: the second row's LDS reads issued before the first row's scan, so that their latency hides behind it --
+// 26 more registers live across the scan, and k_sweep_roll<96> has none to spare: scratch.)
+template <int NR>
+__device__ __forceinline__ double tail_pass_static(int T, const double *tm, double *tE0c, double U0, double U1,
+                                                   double (&tv)[kTailMax][2], const int (&tset)[kTailMax],
+                                                   const double (&At)[kTailMax][2]) {
+  static_assert(NR % 2 == 0 && NR <= 128, "two columns per lane");
+  constexpr int n = NR / 2;
+  double dmax = 0.0;
+#pragma unroll
+  for (int t = 0; t < kTailMax; ++t) {
+    if (t < T) {
+      const lds_d2 s0 = (lds_d2)(unsigned)(tset[t] & 0xffff), s1 = (lds_d2)((unsigned)tset[t] >> 16);
+      const d2 ud0 = s0[0], lr0 = s0[1], ud1 = s1[0], lr1 = s1[1];
+      const d2 A12 = *(const d2 *)(tm + 4 * n * t), A34 = *(const d2 *)(tm + 4 * n * t + 2 * n);
+      const double old0 = tv[t][0], old1 = tv[t][1];
+      const double R1 = wave_shift1<0x130, false>(old0, 0.0); // the next lane's first column (not yet updated)
+      double q0 = At[t][0], q1 = At[t][1];
+      if (t + 1 < T) { // the row below (not yet updated); association order as in tail_pass
+        q0 = fma(ud0.y, tv[t + 1 < kTailMax ? t + 1 : t][0], q0);
+        q1 = fma(ud1.y, tv[t + 1 < kTailMax ? t + 1 : t][1], q1);
+      }
+      q0 = fma(ud0.x, U0, fma(lr0.y, old1, q0));
+      q1 = fma(ud1.x, U1, fma(lr1.y, R1, q1));
+      double Q = fma(lr1.x, q0, q1), qs = 0.0;
+      scan_level<0x111, 0xf>(Q, lr1.x * lr0.x, qs);
+      scan_level<0x112, 0xf>(Q, A12.x, qs);
+      scan_level<0x114, 0xf>(Q, A12.y, qs);
+      scan_level<0x118, 0xf>(Q, A34.x, qs);
+      scan_level<0x142, 0xa>(Q, A34.y, qs);
+      scan_level<0x143, 0xc>(Q, tm[4 * n * T + t], qs);
+      const double xl = wave_shift1<0x138, false>(Q, 0.0);
+      const double x0 = fma(lr0.x, xl, q0);
+      dmax = fmax(dmax, fmax(fabs(x0 - old0), fabs(Q - old1)));
+      tv[t][0] = x0;
+      tv[t][1] = Q;
+      if (t == 0) *(d2 *)tE0c = d2{x0, Q};
+      U0 = x0;
+      U1 = Q;
+    }
+  }
+  return dmax;
+}
+
 } // namespace sweep
 } // namespace sb

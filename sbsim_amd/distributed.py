@@ -7,6 +7,8 @@ tests).  Nothing here touches HIP, so it is covered by world_size-2 gloo tests."
 from __future__ import annotations
 
 import os
+import socket
+import zlib
 from typing import List, Tuple
 
 import torch
@@ -39,6 +41,13 @@ def shard_range(n_buildings_total: int, rank: int, world_size: int) -> Tuple[int
   base, extra = divmod(n_buildings_total, world_size)
   lo = rank * base + min(rank, extra)
   return lo, lo + base + (1 if rank < extra else 0)
+
+
+def class_shard_ranges(class_totals, rank: int, world_size: int) -> List[Tuple[int, int]]:
+  """Mixed floor-plan classes: every class is block-partitioned on its own, so each rank
+  holds the same class mix (load balance: the classes need very different numbers of sweeps).  Returns the
+  rank's [lo, hi) inside every class's own global index space."""
+  return [shard_range(int(n), rank, world_size) for n in class_totals]
 
 
 def shard_seed(base_seed: int, rank: int) -> int:
@@ -91,6 +100,37 @@ def gather_returns(local_returns: torch.Tensor, n_buildings_total: int) -> torch
   return out.to(local_returns.device) if staged else out
 
 
+def gather_returns_by_class(local_returns: torch.Tensor, class_totals) -> torch.Tensor:
+  """The end-of-rollout gather for a batch mixed over floor-plan classes.  ``local_returns``: the rank's
+  buildings in class order (its shard of class 0, then its shard of class 1, ...: the layout of
+  ``MixedBatchedEnvironment``).  Returns [sum(class_totals)] on every rank in GLOBAL order: class-major, the
+  buildings of a class in their global order (rank 0's shard of the class first).  One all_gather, as for
+  one class."""
+  class_totals = [int(n) for n in class_totals]
+  total = sum(class_totals)
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    assert local_returns.numel() == total
+    return local_returns.clone()
+  world, rank = dist.get_world_size(), dist.get_rank()
+  spans = [class_shard_ranges(class_totals, r, world) for r in range(world)]   # [rank][class] -> (lo, hi)
+  sizes = [sum(hi - lo for lo, hi in sp) for sp in spans]
+  assert local_returns.numel() == sizes[rank], (local_returns.numel(), sizes[rank])
+  staged = _host_staged(local_returns)
+  src = local_returns.cpu() if staged else local_returns
+  padded = torch.zeros((max(sizes),), dtype=src.dtype, device=src.device)
+  padded[: sizes[rank]] = src
+  parts: List[torch.Tensor] = [torch.empty_like(padded) for _ in range(world)]
+  dist.all_gather(parts, padded)
+  out = []
+  for k in range(len(class_totals)):
+    for r in range(world):
+      off = sum(hi - lo for lo, hi in spans[r][:k])
+      lo, hi = spans[r][k]
+      out.append(parts[r][off: off + hi - lo])
+  full = torch.cat(out)
+  return full.to(local_returns.device) if staged else full
+
+
 def barrier(device: torch.device | None = None) -> None:
   """dist.barrier() that names the rank's device under RCCL (without device_ids the first barrier of a
   process binds NCCL/RCCL to "the current device" with a warning, and to the wrong one if set_device was
@@ -98,7 +138,7 @@ def barrier(device: torch.device | None = None) -> None:
   if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
     return
   if dist.get_backend() == "nccl" and device is not None and device.type == "cuda":
-    dist.barrier(device_ids=[device.index])
+    dist.barrier(device_ids=[device.index if device.index is not None else torch.cuda.current_device()])
   else:
     dist.barrier()
 
@@ -117,7 +157,8 @@ def all_ranks(value: float, device: torch.device) -> List[float]:
 def preflight(device: torch.device, n_expected: int, payload_bytes: int = 256 * 1024) -> dict:
   """Checks the multi-process set-up before any environment is built, so that the first RCCL run fails
   early and legibly instead of hanging in a collective: the world size is what the caller expects, every
-  rank sits on its own device (unless SBSIM_BENCH_SHARE_GPU=1), a 256 KiB all_gather returns every rank's
+  rank of a NODE sits on its own device (unless SBSIM_BENCH_SHARE_GPU=1; ranks on different nodes may well
+  both use cuda:0 -- devices are compared per host), a 256 KiB all_gather returns every rank's
   pattern in rank order and an all_reduce(MAX) returns the largest rank.  Returns what it saw (rank 0 prints
   it in the bench line); raises SystemExit with the reason otherwise.  Backend-agnostic: "nccl" (= RCCL) on
   GPUs, "gloo" in the CPU tests."""
@@ -131,18 +172,21 @@ def preflight(device: torch.device, n_expected: int, payload_bytes: int = 256 * 
     raise SystemExit(f"preflight: {n_expected} ranks expected, the process group has {world}")
   on_host = backend == "gloo" or device.type != "cuda"
   cdev = torch.device("cpu") if on_host else device
+  local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))   # ranks on THIS node (torchrun sets it)
   if device.type == "cuda":
     n_dev = torch.cuda.device_count()
-    if not share_gpu() and n_dev < world:
-      raise SystemExit(f"preflight: {world} ranks on this node but only {n_dev} visible GPU(s) "
+    if not share_gpu() and n_dev < local_world:
+      raise SystemExit(f"preflight: {local_world} ranks on this node but only {n_dev} visible GPU(s) "
                        "(one process per GPU; SBSIM_BENCH_SHARE_GPU=1 shares devices over gloo for tests)")
-  # every rank's device, in rank order
-  mine = torch.tensor([device.index if device.type == "cuda" else -1], dtype=torch.int64, device=cdev)
+  # every rank's (host, device), in rank order
+  dev_index = (device.index if device.index is not None else torch.cuda.current_device()) if device.type == "cuda" else -1
+  host = zlib.crc32(socket.gethostname().encode()) & 0x7FFFFFFF
+  mine = torch.tensor([host, dev_index], dtype=torch.int64, device=cdev)
   seen = [torch.empty_like(mine) for _ in range(world)]
   dist.all_gather(seen, mine)
-  devices = [int(t.item()) for t in seen]
-  if device.type == "cuda" and not share_gpu() and len(set(devices)) != world:
-    raise SystemExit(f"preflight: two ranks share a device (rank -> device: {devices}); "
+  hosts, devices = [int(t[0].item()) for t in seen], [int(t[1].item()) for t in seen]
+  if device.type == "cuda" and not share_gpu() and len(set(zip(hosts, devices))) != world:
+    raise SystemExit(f"preflight: two ranks of one node share a device (rank -> device: {devices}); "
                      "each rank must call torch.cuda.set_device(LOCAL_RANK)")
   # a payload-sized all_gather: rank r sends r + 1 everywhere
   n = max(1, payload_bytes // 4)
@@ -159,7 +203,7 @@ def preflight(device: torch.device, n_expected: int, payload_bytes: int = 256 * 
   if device.type == "cuda":
     torch.cuda.synchronize(device)
   names = devices if device.type != "cuda" else [f"cuda:{d}" for d in devices]
-  return {"ranks": world, "backend": "rccl (torch 'nccl')" if backend == "nccl" else backend, "devices": names,
+  return {"ranks": world, "nodes": len(set(hosts)), "backend": "rccl (torch 'nccl')" if backend == "nccl" else backend, "devices": names,
           "all_gather_bytes_per_rank": n * 4, "ok": True}
 
 

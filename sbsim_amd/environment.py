@@ -168,15 +168,21 @@ class SimConfig:
     p.max_elec, p.max_gas = self.max_electricity_rate, self.max_natural_gas_rate
     p.prod_delta, p.prod_stiff = self.productivity_midpoint_delta, self.productivity_decay_stiffness
     p.w_prod, p.w_cost, p.w_carbon = self.productivity_weight, self.energy_cost_weight, self.carbon_emission_weight
-    if len(self.action_names) != len(self.action_ranges) or not 1 <= len(self.action_names) <= _ffi.SB_MAX_ACTIONS:
-      raise ValueError("one native range per action, 1..%d actions" % _ffi.SB_MAX_ACTIONS)
-    p.n_actions = len(self.action_names)
-    for i, (name, (lo, hi)) in enumerate(zip(self.action_names, self.action_ranges)):
+    n = len(self.action_names)
+    if n != len(self.action_ranges) or n < 1:
+      raise ValueError("one native range per action, at least one action")
+    for name in self.action_names:
       if name not in ACTION_KINDS:   # simulator_building.py:236-251: REJECTED_NOT_ENABLED_OR_AVAILABLE at run time
         raise ValueError(f"{name!r} is not a settable field of the simulated devices")
-      p.act_kind[i] = ACTION_KINDS[name]
-      p.act_zone[i] = self.action_zones[i] if i < len(self.action_zones) else 0
-      p.act_lo[i], p.act_hi[i] = lo, hi
+    p.n_actions = n
+    # host arrays the struct points at (sb_create copies them; they live as long as the Params object)
+    kinds = (C.c_int32 * n)(*[ACTION_KINDS[name] for name in self.action_names])
+    zones = (C.c_int32 * n)(*[self.action_zones[i] if i < len(self.action_zones) else 0 for i in range(n)])
+    los = (C.c_double * n)(*[float(lo) for lo, _ in self.action_ranges])
+    his = (C.c_double * n)(*[float(hi) for _, hi in self.action_ranges])
+    p.act_kind, p.act_zone = C.cast(kinds, C.POINTER(C.c_int32)), C.cast(zones, C.POINTER(C.c_int32))
+    p.act_lo, p.act_hi = C.cast(los, C.POINTER(C.c_double)), C.cast(his, C.POINTER(C.c_double))
+    p._keep_alive = (kinds, zones, los, his)
     return p
 
 
@@ -696,16 +702,31 @@ class MixedBatchedEnvironment:
   mixed observation is ``[B_total, max width]``; a building's row holds its class's fields first (the layout
   of ``BatchedEnvironment.field_names`` of its class, ``self.envs[k].field_names``) and zeros after
   ``self.observation_widths[k]``; ``self.class_of_building`` ([B_total] int32 in HBM) and ``self.slices``
-  say which class a building belongs to.  Every keyword argument goes to each class's ``BatchedEnvironment``."""
+  say which class a building belongs to.  Every keyword argument goes to each class's ``BatchedEnvironment``.
 
-  def __init__(self, classes: Sequence[Tuple[FloorPlan, int]], device: int = 0, **env_kwargs):
+  Several GPUs (``rank``, ``world``): the counts in ``classes`` are the GLOBAL ones and every class
+  is block-partitioned over the ranks on its own (``sbsim_amd.distributed.class_shard_ranges``), so each rank
+  holds the same class mix -- the classes need very different numbers of sweeps per step, a rank with only the
+  large class would set the pace.  ``self.class_totals`` / ``self.class_ranges`` say which global buildings of
+  each class this rank holds; ``distributed.gather_returns_by_class`` puts per-building results back into
+  global (class-major) order."""
+
+  def __init__(self, classes: Sequence[Tuple[FloorPlan, int]], device: int = 0, rank: int = 0, world: int = 1,
+               **env_kwargs):
     if not classes:
       raise ValueError("MixedBatchedEnvironment needs at least one (floor plan, number of buildings) class")
+    from . import distributed as _sd
     self.device = int(device)
     self.tdev = torch.device("cuda", self.device)
     self.envs: List[BatchedEnvironment] = []
     self.streams: List[torch.cuda.Stream] = []
     self.slices: List[Tuple[int, int]] = []
+    self.rank, self.world = int(rank), int(world)
+    self.class_totals = [int(n) for _, n in classes]
+    self.class_ranges = _sd.class_shard_ranges(self.class_totals, self.rank, self.world)
+    if any(hi <= lo_ for lo_, hi in self.class_ranges):
+      raise ValueError(f"rank {rank} of {world} would hold no building of some class: {self.class_ranges}")
+    classes = [(plan, hi - lo_) for (plan, _), (lo_, hi) in zip(classes, self.class_ranges)]
     lo = 0
     for plan, n in classes:
       stream = torch.cuda.Stream(device=self.tdev)

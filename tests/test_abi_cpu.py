@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
   assert set(names) == set(_ffi.EXPORTS), (names, _ffi.EXPORTS)
   for n in names:
     assert hasattr(lib, n), n
-  assert _ffi.load().sb_abi_version() == _ffi.SB_ABI_VERSION == 7
+  assert _ffi.load().sb_abi_version() == _ffi.SB_ABI_VERSION == 8
 
 
 def test_struct_layouts_match_header():

@@ -253,3 +253,96 @@ def test_hip_simulator_building_on_a_four_wavefront_plan(monkeypatch):
   assert np.abs(b.env.sim.temps().cpu().numpy() - ref.env.sim.temps().cpu().numpy()).max() < 1e-9
   b.close()
   ref.close()
+
+
+@pytest.mark.gpu
+def test_action_vector_as_wide_as_the_building_has_setpoints():
+  """ABI 8: one action column per settable field (environment/environment.py:591-653 admits every device setpoint with a
+  normaliser): the boiler's, the air handler's two and one damper command per VAV of a 126-zone plan -- a 129-column
+  vector (the 16-column limit of ABI <= 7 did not hold an SB1 agent that drives its dampers, vav.py:66-70).  Against
+  oracle twins (their `damper_cmd` path, sb_oracle.c: vav.py:125-129): some columns left out of a request
+  (SB_ACTION_KEEP), some commands outside [0, 1] (that action is rejected, the others apply, the reward is -inf)."""
+  torch = pytest.importorskip("torch")
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+  from oracle import oracle as orc   # checker only
+  from sbsim_amd import _ffi
+  from sbsim_amd.environment import ACTION_REJECTION_REWARD, BatchedSimulator, SimConfig
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  from tests.test_gpu_parity import T_TOL, _step_in
+  plan = FloorPlan.from_file_input(rectangular_floor_plan((14, 9), (8, 7)), Materials.sb1(), 10.0, 300.0)
+  Z = len(plan.zone_cell_lists())
+  assert Z == 126
+  cfg = SimConfig.sb1()
+  cfg.action_names = ("supply_water_setpoint", "supply_air_heating_temperature_setpoint",
+                      "supply_air_cooling_temperature_setpoint") + ("supply_air_damper_percentage_command",) * Z
+  # the dampers are listed in reverse zone order: a column is not its zone's index
+  cfg.action_zones = (0, 0, 0) + tuple(range(Z - 1, -1, -1))
+  cfg.action_ranges = ((310.0, 355.0), (285.0, 295.0), (296.0, 305.0)) + ((-0.001, 1.001),) * Z   # a normaliser that can overshoot [0, 1] (one damper in 500)
+  g = load("h2_sb1_r9_random.npz")
+  B, T = 6, 8
+  sim = BatchedSimulator(plan, cfg, B, float(g["h_conv"]))
+  assert sim.n_actions == 3 + Z
+  rs = np.random.RandomState(5)
+  H, W = plan.shape
+  init = np.clip(294.0 + rs.randn(B, 1) + np.zeros((B, H * W)), 285.0, 305.0)
+  sim.reset(temps=torch.tensor(init, dtype=torch.float64, device="cuda"))
+  oplan = orc.OraclePlan(plan.conductivity, plan.density, plan.heat_capacity, plan.exterior_space,
+                         plan.zone_cell_lists(), plan.diffusers, plan.cv_size_cm, plan.floor_height_cm)
+  c = cfg
+  oprm = orc.OracleParams(
+      dt=c.time_step_sec, conv_threshold=c.convergence_threshold, iter_limit=c.iteration_limit,
+      vav_max_air_flow=c.vav_max_air_flow_rate, vav_max_water_flow=c.vav_reheat_max_water_flow_rate,
+      ahu_recirc=c.ahu_recirculation, ahu_heat_sp=c.ahu_heating_air_temp_setpoint,
+      ahu_cool_sp=c.ahu_cooling_air_temp_setpoint, ahu_dp=c.ahu_fan_differential_pressure,
+      ahu_eff=c.ahu_fan_efficiency, blr_setpoint=c.boiler_reheat_water_setpoint,
+      blr_head=c.boiler_water_pump_differential_head, blr_pump_eff=c.boiler_water_pump_efficiency,
+      comfort_lo=c.comfort_temp_window[0], comfort_hi=c.comfort_temp_window[1],
+      eco_lo=c.eco_temp_window[0], eco_hi=c.eco_temp_window[1],
+      blr_heating_rate=c.boiler_heating_rate, blr_cooling_rate=c.boiler_cooling_rate, ahu_has_weather=1)
+  twins = [orc.OracleBuilding(oplan, oprm, 0.0, reset_temps=init[b]) for b in range(B)]
+  obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  n_rejected = 0
+  for t in range(T):
+    norm = rs.uniform(-1, 1, size=(B, 3 + Z)).astype(np.float32)
+    native = np.empty((B, 3 + Z), dtype=np.float32)
+    for i, (lo, hi) in enumerate(cfg.action_ranges):   # bounded_action_normalizer.py:93-98, then the proto's float
+      native[:, i] = ((norm[:, i].astype(np.float64) + 1.0) / 2.0 * (hi - lo) + lo).astype(np.float32)
+    keep = rs.rand(B, 3 + Z) < 0.3                      # the request does not mention these fields
+    keep[:, :2] = False                                 # (the twins' interface always carries the two SB1 setpoints)
+    if t % 2 == 0:                                      # every other step in native units with left-out columns
+      act = native.copy()
+      act[keep] = _ffi.SB_ACTION_KEEP
+    else:
+      act, keep = norm, np.zeros_like(keep)
+    si = _step_in(g, t + 100)
+    si.actions_native = int(t % 2 == 0)
+    sim.step(torch.tensor(act, device="cuda"), si, obs, rew, info)
+    i_ = info.cpu().numpy().astype(np.float64)
+    zt, r = sim.zone_temps().cpu().numpy(), rew.cpu().numpy()
+    dm = sim._get(sim._lib.sb_get_zone_power, (B, Z), torch.float64).cpu().numpy()
+    for b in range(B):
+      cmd = np.full(Z, np.nan)
+      for col in range(3, 3 + Z):
+        if not keep[b, col]:
+          cmd[cfg.action_zones[col]] = float(native[b, col])
+      tt = t + 100
+      o = twins[b].step(
+          now_ts=300.0 * t, t_amb_now=float(g["t_amb_now"][tt]), h_conv=float(g["h_conv"]),
+          t_amb_next=float(g["t_amb_next"][tt]), comfort_now=bool(g["comfort_now"][tt]),
+          comfort_prev=g["comfort_prev"][tt] == 1, comfort_next=bool(g["comfort_next"][tt]),
+          occupancy=float(g["occupancy"][tt]), e_price=float(g["e_price"][tt]), e_carbon=float(g["e_carbon"][tt]),
+          g_price=float(g["g_price"][tt]), g_carbon=float(g["g_carbon"][tt]),
+          action=[native[b, 0], native[b, 1]], cool_sp=None if keep[b, 2] else float(native[b, 2]), damper_cmd=cmd)
+      assert i_[b, 4] == o["n_sweeps"], (t, b, i_[b, 4], o["n_sweeps"])
+      assert np.abs(zt[b] - o["zone_temp_post"]).max() < T_TOL, (t, b)
+      assert np.allclose(dm[b], o["q_zone"], rtol=1e-12, atol=1e-9), (t, b)     # every zone's VAV power: every damper landed
+      if o["action_accepted"]:
+        assert abs(float(r[b]) - o["reward"]) < 1e-6, (t, b)
+      else:
+        n_rejected += 1
+        assert r[b] == ACTION_REJECTION_REWARD and abs(i_[b, 7] - o["reward"]) < 1e-6, (t, b)
+  assert 0 < n_rejected < B * T          # the overshooting normaliser rejected some steps, not all
+  sim.close()

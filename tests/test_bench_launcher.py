@@ -74,3 +74,24 @@ def test_preflight_refuses_a_world_size_it_was_not_told():
   assert sd.preflight(torch.device("cpu"), 1)["ranks"] == 1
   with pytest.raises(SystemExit, match="2 ranks expected"):
     sd.preflight(torch.device("cpu"), 2)
+
+
+def test_gpus_8_rehearsal_on_gloo():
+  """The driver's 8-GPU command shape on CPU: eight ranks, the preflight, barrier-bracketed timing, the gather
+  of 8 x B returns in global order (the first time more than two ranks meet in this code)."""
+  r = _run(["--gpus", "8", "--stub-step", "--steps", "2", "--warmup", "1", "--buildings", "11"], timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  d = _json_line(r.stdout)
+  assert d["n_gpus"] == 8 and d["gathered_returns"] == 88 and d["gather_in_global_order"] is True
+  assert d["rccl_ranks"] == 8 and d["preflight"]["ok"] is True and d["preflight"]["nodes"] == 1
+  assert len(d["per_rank_ms_per_step"]) == 8 and len(d["preflight"]["devices"]) == 8
+
+
+def test_mixed_config_two_ranks_every_class_on_every_rank():
+  """--config mixed --gpus 2: each class is block-partitioned over the ranks on its own and the
+  end-of-rollout gather returns the buildings in global class-major order."""
+  r = _run(["--config", "mixed", "--gpus", "2", "--stub-step", "--steps", "2", "--warmup", "0", "--buildings", "30"])
+  assert r.returncode == 0, r.stderr[-2000:]
+  d = _json_line(r.stdout)
+  assert d["n_gpus"] == 2 and d["gathered_returns"] == 60 and d["gather_in_global_order"] is True
+  assert "three classes" in d["config"]["workload"]

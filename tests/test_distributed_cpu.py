@@ -64,3 +64,50 @@ def test_single_process_paths():
   x = torch.arange(5, dtype=torch.float32)
   assert torch.equal(sd.gather_returns(x, 5), x)
   assert sd.max_over_ranks(2.5, torch.device("cpu")) == 2.5
+
+
+def test_class_shards_give_every_rank_the_same_mix():
+  totals = [21845, 21845, 21846]
+  for world in (1, 2, 8):
+    spans = [sd.class_shard_ranges(totals, r, world) for r in range(world)]
+    for k, n in enumerate(totals):
+      assert spans[0][k][0] == 0 and spans[-1][k][1] == n
+      sizes = [sp[k][1] - sp[k][0] for sp in spans]
+      assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n
+      for a, b in zip(spans, spans[1:]):
+        assert a[k][1] == b[k][0]
+
+
+def _worker8(rank: int, world: int, port: int, n_total: int, totals):
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  assert sd.init_process_group("gloo")
+  pf = sd.preflight(torch.device("cpu"), world)
+  assert pf["ranks"] == world and pf["ok"] and pf["nodes"] == 1
+  lo, hi = sd.shard_range(n_total, rank, world)
+  full = sd.gather_returns(torch.arange(lo, hi, dtype=torch.float32), n_total)
+  assert torch.equal(full, torch.arange(n_total, dtype=torch.float32)), (rank, full)
+  # three classes, each sharded on its own; the rank's vector is in class order, the gathered one class-major
+  spans = sd.class_shard_ranges(totals, rank, world)
+  local = torch.cat([torch.arange(a, b, dtype=torch.float32) + 1000.0 * k for k, (a, b) in enumerate(spans)])
+  got = sd.gather_returns_by_class(local, totals)
+  want = torch.cat([torch.arange(0, n, dtype=torch.float32) + 1000.0 * k for k, n in enumerate(totals)])
+  assert torch.equal(got, want), (rank, got, want)
+  assert sd.all_ranks(float(rank), torch.device("cpu")) == [float(r) for r in range(world)]
+  assert sd.max_over_ranks(1.0 + rank, torch.device("cpu")) == float(world)
+  sd.barrier(torch.device("cpu"))
+  dist.destroy_process_group()
+
+
+def test_world_size_8_gloo_shards_gathers_and_preflight():
+  """Eight ranks (the node the scaling bench runs on): preflight, shard ranges, the gather in global order for
+  one class (ragged: 8 does not divide 75) and for three classes sharded per class."""
+  port = _free_port()
+  mp.spawn(_worker8, args=(8, port, 75, [19, 8, 30]), nprocs=8, join=True)
+
+
+def test_gather_by_class_single_process():
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+    os.environ.pop(k, None)
+  x = torch.arange(7, dtype=torch.float32)
+  assert torch.equal(sd.gather_returns_by_class(x, [3, 4]), x)

@@ -226,6 +226,69 @@ def test_divergent_buildings_against_oracle(mode, monkeypatch):
     assert np.abs(grid[b] - twins[b].grid()).max() < T_TOL, b
 
 
+@pytest.mark.parametrize("path", ["reg", "lds"])
+def test_set_temps_with_a_grid_whose_sum_changes(path, monkeypatch):
+  """sb_set_temps is a general `building.temp <- temps` (building.py:891-893), not only the seeded
+  convection's within-room permutation: a grid with ANOTHER sum must move the next step's recirculation temperature
+  (simulator.py:423-426 takes building.temp.mean() every step; the library caches it in scal[11]).  Two steps, a
+  non-permutation edit of every building's interior, two more steps -- against oracle twins that get the same edit."""
+  _need_gpu()
+  if path == "lds":
+    monkeypatch.setenv("SBSIM_FORCE_LDS_PATH", "1")
+  g = load("h2_sb1_r9_random.npz")
+  p = load("plan_r9_sb1.npz")
+  B = 5
+  rs = np.random.RandomState(11)
+  init = np.clip(294.0 + rs.randn(B, 1, 1) + 0.3 * rs.randn(B, 68, 98), 285.0, 305.0)
+  acts = rs.uniform(-1, 1, size=(4, B, 2)).astype(np.float32)
+  sim = BatchedSimulator(_plan(p), SimConfig.sb1(), B, float(g["h_conv"]))
+  sim.reset(temps=torch.tensor(init.reshape(B, -1), dtype=torch.float64, device="cuda"))
+  plan, prm = oracle_plan(p), oracle_params(g["params_json"])
+  twins = [orc.OracleBuilding(plan, prm, 0.0, reset_temps=init[b].reshape(-1)) for b in range(B)]
+  obs = torch.zeros((B, sim.O), dtype=torch.float32, device="cuda")
+  rew = torch.zeros((B,), dtype=torch.float32, device="cuda")
+  info = torch.zeros((B, _ffi.SB_INFO_STRIDE), dtype=torch.float32, device="cuda")
+  rng_w, rng_a = (310.0, 355.0), (285.0, 300.0)
+
+  def both(t):
+    sim.step(torch.tensor(acts[t], device="cuda"), _step_in(g, t + 100), obs, rew, info)
+    i = info.cpu().numpy().astype(np.float64)
+    zt = sim.zone_temps().cpu().numpy()
+    for b in range(B):
+      a, tt = acts[t, b], t + 100
+      native = [np.float32((float(a[0]) + 1.0) / 2.0 * (rng_w[1] - rng_w[0]) + rng_w[0]),
+                np.float32((float(a[1]) + 1.0) / 2.0 * (rng_a[1] - rng_a[0]) + rng_a[0])]
+      o = twins[b].step(
+          now_ts=300.0 * t, t_amb_now=float(g["t_amb_now"][tt]), h_conv=float(g["h_conv"]),
+          t_amb_next=float(g["t_amb_next"][tt]), comfort_now=bool(g["comfort_now"][tt]),
+          comfort_prev=g["comfort_prev"][tt] == 1, comfort_next=bool(g["comfort_next"][tt]),
+          occupancy=float(g["occupancy"][tt]), e_price=float(g["e_price"][tt]), e_carbon=float(g["e_carbon"][tt]),
+          g_price=float(g["g_price"][tt]), g_carbon=float(g["g_carbon"][tt]), action=native, observe=True)
+      assert i[b, 4] == o["n_sweeps"], (t, b, i[b, 4], o["n_sweeps"])
+      assert np.abs(zt[b] - o["zone_temp_post"]).max() < T_TOL, (t, b)
+      assert abs(i[b, 6] - o["t_supply_air"]) < 1e-4, (t, b, i[b, 6], o["t_supply_air"])   # (an fp32 output)
+      ref = np.array([o["blower_rate"], o["ac_rate"], o["gas_rate"], o["pump_rate"]], np.float64)
+      assert np.allclose(i[b, :4], ref, rtol=2e-6, atol=1e-6), (t, b)
+
+  both(0)
+  both(1)
+  grid = sim.temps().cpu().numpy().reshape(B, 68, 98)
+  inside = ~np.asarray(p["exterior_space"], dtype=bool)
+  edit = grid.copy()
+  edit[:, inside] += 1.5 + 0.5 * rs.rand(B, int(inside.sum()))      # every interior cell warmer: the grid's sum changes
+  edit[:, 10:30, 10:40] -= 2.0 * inside[10:30, 10:40]                # ... and one patch colder
+  sim.set_temps(torch.tensor(edit, dtype=torch.float64, device="cuda"))
+  for b in range(B):
+    twins[b].temp[:] = edit[b].reshape(-1)      # the oracle reads its grid (and every mean of it) afresh each step
+  assert abs(float(sim.scalars().cpu().numpy()[0, 11]) - edit[0].mean()) < 1e-9   # the recirculation temperature follows
+  both(2)
+  both(3)
+  final = sim.temps().cpu().numpy()
+  for b in range(B):
+    assert np.abs(final[b].reshape(-1) - twins[b].temp).max() < T_TOL, b
+  sim.close()
+
+
 @pytest.mark.parametrize("limit", [1, 2, 5])
 def test_iteration_limit_ends_the_step(limit):
   """simulator.py:348-368 with a limit that bites (the golden rollouts always converge): the

@@ -13,7 +13,7 @@ bases=""
 for src in ${srcs//,/ }; do
   base=$(basename $src .hip)
   bases="$bases $base"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fPIC "$@" \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fPIC -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" \
     -I $root/include -I $root/sbsim_amd/csrc -c $root/sbsim_amd/csrc/$src -o $obj/${base}_$name.o &
 done
 wait
