@@ -187,6 +187,7 @@ struct RegPlan {
   int lag = 0, nslots = 0, steps = 0;
   int r_seam = 0, r_A = 0, r_xchg = 0, lds_bytes = 0, wg_per_cu = 0, AS = 0;
   int r_cmap = 0, wave_doubles = 0, waves_per_wg = 1; // mode 3: four buildings per workgroup share the class words
+  int ZRS = 0; // modes 1..3: row stride of the zone-sum scratch
   std::vector<unsigned long long> cmapS, amapS, zmapS;
   std::vector<int> cell_state;
   // mode 4 (plan_two)
@@ -735,11 +736,15 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   const int nl_slots = P == 3 ? sweep_roll_lds_slots(NR) : sweep_reg_lds_slots(NR, P);
   r.ts = TS;
   const int RS = P == 3 ? 64 : Hs;
-  const int ZRS = RS | 1; // odd stride: the zone reduce reads 16 zone rows at once
-  if ((size_t)(Z + 1) * ZRS > (size_t)RS * nl_slots || (size_t)(Z + 1) * ZRS * 8 > 65535) {
-    r.why = "too many zones for the zone-sum scratch"; // it aliases A: (Z+1) x ZRS doubles
+  // the zone-sum scratch aliases A.  Modes 1, 2: [Z + 1][ZRS = rows | 1] (odd stride: the zone reduce reads 16 zone rows at once),
+  // 16-bit byte offsets.  Mode 3 (step_roll.hip): [64 rows][ZRS = (Z + 1) | 1], a slot's offset inside its lane's row is zone * 8:
+  // one byte (Z <= 31: every zone has a cell class of its own and the class table holds 32)
+  const int ZRS = P == 3 ? ((Z + 1) | 1) : (RS | 1);
+  if (P == 3 ? (Z > 31 || ZRS > nl_slots) : ((size_t)(Z + 1) * ZRS > (size_t)RS * nl_slots || (size_t)(Z + 1) * ZRS * 8 > 65535)) {
+    r.why = "too many zones for the zone-sum scratch"; // it aliases A
     return;
   }
+  r.ZRS = ZRS;
   r.NR = NR; r.P = P; r.RS = RS; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
   r.T = P == 3 ? std::max(0, Hs - 64) : 0;
   r.state_doubles = NR * RS + r.T * NR;
@@ -832,7 +837,7 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   auto cell_class = [&](int R, int col) { // trimmed coordinates
     return (R >= 0 && R < Hs && col >= 0 && col < Ws) ? cls_at(x0 + R, y0 + col) : pad;
   };
-  const int aslots = (NR + 7) / 8, zslots = (NR + 3) / 4;
+  const int aslots = (NR + 7) / 8, zslots = P == 3 ? NR / 8 : (NR + 3) / 4;
   const int nw = P == 2 ? 2 : 1;
   r.cmapS.assign(P == 3 ? (size_t)(NR / 8) * 64 : (size_t)nw * (maxch + 3) * 64, 0);
   r.amapS.assign((size_t)nw * aslots * 64, 0);
@@ -917,6 +922,22 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
         }
         r.amapS[((size_t)w * aslots + g) * 64 + lane] = word;
       }
+      if (P == 3) { // step_roll.hip: a byte per slot = zone * 8 (the byte offset inside the lane's row of the scratch), eight slots per word
+        for (int g = 0; g < zslots; ++g) {
+          unsigned long long word = 0;
+          for (int k = 0; k < 8; ++k) {
+            const int j = 8 * g + k;
+            const int col = ((j - lp) % NR + NR) % NR;
+            int z = Z; // dump column
+            if (valid && R < Hs && col < Ws) { // (below 64 rows the lanes beyond the plan own pad rows)
+              const int zz = zone_of[(x0 + R) * W + (y0 + col)];
+              if (zz >= 0) z = zz;
+            }
+            word |= (unsigned long long)(z * 8) << (8 * k);
+          }
+          r.zmapS[(size_t)g * 64 + lane] = word;
+        }
+      } else
       for (int g = 0; g < zslots; ++g) {
         unsigned long long word = 0;
         for (int k = 0; k < 4; ++k) {
@@ -1168,7 +1189,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
   if (d.reg) {
     d.pitch = d.W; d.NL = d.N; d.ts = r.ts;
     d.NR = r.NR; d.P = r.P; d.RS = r.RS; d.Ws = r.Ws; d.n_ring = r.n_ring; d.n_ring_f64 = (double)r.n_ring;
-    d.T = r.T; d.state_doubles = r.state_doubles; d.AS = r.AS; d.ZRS = r.RS | 1;
+    d.T = r.T; d.state_doubles = r.state_doubles; d.AS = r.AS; d.ZRS = r.ZRS ? r.ZRS : (r.RS | 1);
     for (int w = 0; w < 2; ++w) { d.l0[w] = r.l0[w]; d.rowbase[w] = r.rowbase[w]; d.nch[w] = r.nch[w]; }
     for (int w = 0; w < 4; ++w) d.lw[w] = r.lw[w];
     d.lag = r.lag; d.nslots = r.nslots; d.nsteps = r.steps;

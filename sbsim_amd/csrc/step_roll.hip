@@ -309,41 +309,36 @@ __device__ __forceinline__ void roll_pairs(double (&e)[NR], double (&bk)[kWin], 
 // The end of a building's step, slot by slot: undo the started sweep (lanes <= J restore slot J
 // from the window's copies), store the slot, add it to its zone sum (LDS), load the same slot of
 // the next building.  The loop runs at the pace of the memory pipe; the restores cost nothing there.
-// zw: the zone-sum offsets, four slots per word -- read before the loop (into the registers A's slots
-// leave free after the sweeps): memory operations return in order, so a word read inside the loop would
-// wait for the row loads of the next building issued before it, i.e. for HBM (that paced the loop at 125
-// cycles per pair of slots where its instructions issue in 35).
-#ifndef SB_ZPRE
-#define SB_ZPRE 8
-#endif
-constexpr int kZPre = SB_ZPRE; // zone-offset words read before the loop
+// Zone sums: the scratch (it aliases A) is [row = lane][ZRS] -- a lane's sums of the zones its row crosses, zone-minor, ZRS odd
+// (a half-wavefront's ds_add_f64 to one zone covers all banks) -- so a slot's destination is the lane's row + zone * 8: ONE BYTE
+// per slot (zone <= 31 on this kernel: at most 32 cell classes), eight slots per 64-bit word, NR / 8 words per lane, all read
+// before the loop.  (Until round 4: [zone][row] with 16-bit offsets, NR / 4 words -- 48 registers, a third of them read inside the
+// loop behind the next building's row loads.  Memory operations return in order, so a word read inside the loop waits for the
+// rows issued before it, i.e. for HBM.)
 // HBM state layout: [NR / 2][64 lanes][2] -- a lane's two neighbouring slots are 16 bytes, so the
 // loop moves a building with NR / 2 stores and NR / 2 loads of 16 bytes per lane (a wavefront has
 // at most 63 memory operations in flight: the count of operations, not their size, paces the loop).
 template <int NR, int J>
-__device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kWin], unsigned long long (&zw)[(NR + 3) / 4],
-                                          const unsigned long long *zmap, double *tp, const double *np_, double *zs) {
-  static_assert(NR % 2 == 0, "slot pairs");
+__device__ __forceinline__ void hand_over(double (&e)[NR], const double (&bk)[kWin], const unsigned long long (&zw)[NR / 8],
+                                          double *tp, const double *np_, double *zrow) {
+  static_assert(NR % 8 == 0, "whole zone words");
   if constexpr (J < NR) {
-    // the last words: read in the loop's first iterations (into the registers the restored copies leave free);
-    // their wait, at slot 4 * kZPre, is for the first rows of the next building -- which the A pass needs anyway
-    if constexpr (J % 4 == 0 && J >= 8 && kZPre + (J - 8) / 4 < (NR + 3) / 4) zw[kZPre + (J - 8) / 4] = zmap[(kZPre + (J - 8) / 4) * 64];
     if constexpr (J < kWin) e[J] = lanes_upto<J>() ? bk[J] : e[J];
     if constexpr (J + 1 < kWin) e[J + 1] = lanes_upto<J + 1>() ? bk[J + 1] : e[J + 1];
-    const unsigned long long w = zw[J / 4];
-    const unsigned off0 = (unsigned)((w >> (16 * (J & 3))) & 0xffffull), off1 = (unsigned)((w >> (16 * ((J + 1) & 3))) & 0xffffull);
+    const unsigned w = (J & 7) < 4 ? (unsigned)zw[J / 8] : (unsigned)(zw[J / 8] >> 32);
+    const unsigned off0 = (w >> (8 * (J & 3))) & 0xffu, off1 = (w >> (8 * ((J + 1) & 3))) & 0xffu;
 #ifndef SB_EXP_NOMEM // timing experiment: the hand-over without its HBM traffic
     __builtin_nontemporal_store(d2{e[J], e[J + 1]}, (d2 *)(tp + J * 64)); // the state streams: read once, written once per launch
 #endif
-    __hip_atomic_fetch_add((double *)((char *)zs + off0), e[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add((double *)((char *)zs + off1), e[J + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add((double *)((char *)zrow + off0), e[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add((double *)((char *)zrow + off1), e[J + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef SB_EXP_NOMEM
     const d2 nv = __builtin_nontemporal_load((const d2 *)(np_ + J * 64));
     e[J] = nv.x;
     e[J + 1] = nv.y;
 #endif
     if constexpr ((J & 7) == 6) __builtin_amdgcn_sched_barrier(0);
-    hand_over<NR, J + 2>(e, bk, zw, zmap, tp, np_, zs);
+    hand_over<NR, J + 2>(e, bk, zw, tp, np_, zrow);
   }
 }
 
@@ -360,7 +355,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); // one wavefront per SIMD, each with its own buildings
   const int gw = (int)blockIdx.x * kWaves + wave;
-  constexpr int kASlots = (NR + 7) / 8, kZSlots = (NR + 3) / 4, kCW = NR / 8;
+  constexpr int kASlots = (NR + 7) / 8, kZSlots = NR / 8, kCW = NR / 8;
   static_assert((NR / 2) % kBufs == 0, "pair buffers rotate through a whole period: pair_buf() must not alias across the wrap");
   constexpr int kNL = lds_slots(NR), kAS = a_stride(NR), kNAR = NR - kNL > 0 ? NR - kNL : 2;
 
@@ -373,7 +368,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
   double *tapg = wl;                       // [2][kTS]: ap by class, then g by class (g of this building); a class byte of the A pass (class * 8) IS the
                                            // byte offset into either: one add (SDWA byte select) forms the address, one ds_read2_b64 fetches both
   double *tE0 = wl + a.r_seam + 2;         // the first tail row by column ([2 guards | NR | 2 guards]): lane 63's lower neighbours
-  double *A = wl + a.r_A;                  // [64][kAS]; after the sweeps: zone sums [Z+1][ZRS]
+  double *A = wl + a.r_A;                  // [64][kAS]; after the sweeps: zone sums [64 rows][ZRS]
   // every byte of LDS starts finite: reads next to the arrays' ends are multiplied by 0
   for (int i = threadIdx.x; i < a.lds_reg_bytes / 8; i += blockDim.x) lds[i] = 0.0;
   __syncthreads();
@@ -641,31 +636,31 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(4);
 
-    // grid back to HBM.  Zone sums (A is dead now): every lane adds its cells into its own
-    // column of zs[zone][row]; row Z collects every cell outside a zone, so that the sum of all
-    // rows is the grid sum.
+    // grid back to HBM.  Zone sums (A is dead now): every lane adds its cells into its own row of zs[row][zone]; column Z
+    // collects every cell outside a zone, so that the sum of all entries is the grid sum.
     double *zs = A;
     const int ZRS = a.ZRS;
     {
-      unsigned long long zw[kZSlots]; // zone-sum offsets, four slots per word
+      unsigned long long zw[kZSlots]; // zone bytes, eight slots per word
       const unsigned long long *zm = zmap + opaque(0);
 #pragma unroll
-      for (int g = 0; g < (kZPre < kZSlots ? kZPre : kZSlots); ++g) zw[g] = zm[g * 64];
+      for (int g = 0; g < kZSlots; ++g) zw[g] = zm[g * 64];
       __builtin_amdgcn_sched_barrier(0);
       // a building on its way to the redo list keeps its state: its rows go to the wavefront's scratch
       double *tp = redo ? a.redo_scratch + (size_t)gw * a.state_doubles : a.temp + (size_t)b * a.state_doubles;
       double *Ttail = tp + NR * 64; // [T][NR]
-      for (int z = 0; z <= a.Z; ++z) zs[(size_t)z * ZRS + R] = 0.0;
+      double *zrow = zs + (size_t)opaque(R) * ZRS; // the lane's row of the scratch
+      for (int z = 0; z <= a.Z; ++z) zrow[z] = 0.0;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int t = 0; t < kTailMax; ++t) // the tail rows hold no zone cells (sb_create checks): all into row Z
+      for (int t = 0; t < kTailMax; ++t) // the tail rows hold no zone cells (sb_create checks): all into column Z
         if (t < a.T && tactive) {
           *(d2 *)(Ttail + t * NR + tc0) = d2{tv[t][0], tv[t][1]};
-          zs[(size_t)a.Z * ZRS + lane] += tv[t][0] + tv[t][1]; // the lane's own column of the scratch
+          zrow[a.Z] += tv[t][0] + tv[t][1];
         }
       const double *np_ = a.temp + (size_t)(sn < nB ? bn : b) * a.state_doubles;
       static_assert(RS == 64, "hand_over: slot stride");
-      hand_over<NR, 0>(e, bk, zw, zm, tp + 2 * R, np_ + 2 * R, zs);
+      hand_over<NR, 0>(e, bk, zw, tp + 2 * R, np_ + 2 * R, zrow);
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_STAMP(5);
@@ -681,10 +676,10 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
       double gacc = 0.0;
       for (int zb = 0; zb <= a.Z; zb += 16) {
         const int zz = zb + (lane & 15), g = lane >> 4;
-        const double *zr = zs + (size_t)(zz <= a.Z ? zz : a.Z) * ZRS + g;
+        const double *zr = zs + (size_t)g * ZRS + (zz <= a.Z ? zz : a.Z);
         double part[RS / 4];
 #pragma unroll
-        for (int k = 0; k < RS / 4; ++k) part[k] = zr[4 * k]; // sixteen independent reads, then one wait
+        for (int k = 0; k < RS / 4; ++k) part[k] = zr[(size_t)4 * k * ZRS]; // sixteen independent reads, then one wait
         double v = 0.0;
 #pragma unroll
         for (int k = 0; k < RS / 4; ++k) v += part[k];
