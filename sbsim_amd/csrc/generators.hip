@@ -124,8 +124,10 @@ constexpr int kConvMaxRoom = 2047; // a cell's index in its room fits 11 bits ne
 
 // The shuffle's random numbers: a counter-based mixer -- MurmurHash3's 32-bit finaliser over (stream, cell,
 // word number) -- an eighth of Philox4x32-10's instructions (which was a quarter of this kernel's).  stream:
-// (seed, global building, call number) folded once per building; word k of the cell with index g0 in the
-// CALLER's grid: fmix32((stream ^ g0 * 0x9E3779B1) + k * 0x6C8E9CF5).  Word 0 -> inclusion (u = (x >> 8) / 2^24,
+// (seed, global building, call number) folded once per building into TWO 32-bit words (s0, s1) by two independent
+// chains (round 5, ADVICE r4: one word gave 65,536 buildings 0.5 colliding pairs per call -- whole buildings making
+// identical draws; 64 bits: 1e-10); a cell's key (index g0 in the CALLER's grid) = fmix32(s0 ^ g0 * 0x9E3779B1) + s1,
+// word k of the cell = fmix32(key + k * 0x6C8E9CF5).  Word 0 -> inclusion (u = (x >> 8) / 2^24,
 // included unless u > p), word 1 -> the swap's time stamp (its top 20 bits; ties by the cell's rank in the
 // room), words 2.. -> partner candidates until one is accepted.  Known answers: tests/test_convection.py;
 // restated in oracle/convection_oracle.py.  (Occupancy and the whole-room permutation keep Philox.)
@@ -133,13 +135,21 @@ __host__ __device__ inline uint32_t fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return h;
 }
-__host__ __device__ inline uint32_t conv_stream(uint64_t seed, uint64_t gb, uint32_t call) {
+struct ConvStream { uint32_t s0, s1; };
+__host__ __device__ inline ConvStream conv_stream(uint64_t seed, uint64_t gb, uint32_t call) {
   uint32_t h = fmix32((uint32_t)seed ^ 0x9E3779B9u);
   h = fmix32(h ^ (uint32_t)(seed >> 32));
   h = fmix32(h ^ (uint32_t)gb);
   h = fmix32(h ^ (uint32_t)(gb >> 32));
-  return fmix32(h ^ call);
+  h = fmix32(h ^ call);
+  uint32_t g = fmix32(call ^ 0x7F4A7C15u); // the second chain: other constants, the inputs in another order
+  g = fmix32(g + (uint32_t)(gb >> 32));
+  g = fmix32(g + (uint32_t)gb);
+  g = fmix32(g + (uint32_t)(seed >> 32));
+  g = fmix32(g + (uint32_t)seed);
+  return ConvStream{h, g};
 }
+__host__ __device__ inline uint32_t conv_key(ConvStream st, uint32_t g0) { return fmix32(st.s0 ^ (g0 * 0x9E3779B1u)) + st.s1; }
 __host__ __device__ inline uint32_t conv_word(uint32_t cell_key, uint32_t k) { return fmix32(cell_key + k * 0x6C8E9CF5u); }
 
 // A cell's own swap in LDS, 8 bytes: its time stamp ((top 20 bits of word 1) << 11 | the cell's rank in the
@@ -184,14 +194,14 @@ k_convect(ConvArgs o) {
     // waits for LDS only), so a building's memory latency hides behind its predecessor's pointer chase
     auto draw = [&](int b, double (&val)[Q], int (&oth)[Q]) {
       const double *st = o.temp + (size_t)b * o.stride;
-      const uint32_t stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call);
+      const ConvStream stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
           const int i = tid + q * kConvThreads;
           oth[q] = i;
           if (i < n) {
             val[q] = st[c_b[q] & 0x1fffffu];
-            const uint32_t key = stream ^ ((c_a[q] & 0xfffffu) * 0x9E3779B1u);
+            const uint32_t key = conv_key(stream, c_a[q] & 0xfffffu);
             const double u = (double)(conv_word(key, 0) >> 8) * (1.0 / 16777216.0);
             int other = i;
             if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table: the partner by rejection --
@@ -232,14 +242,14 @@ k_convect(ConvArgs o) {
     if ((int)blockIdx.x < o.B) draw(blockIdx.x, val, oth);
     for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
       double *st = o.temp + (size_t)b * o.stride;
-      const uint32_t stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call);
+      const ConvStream stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call);
       // the records and the list links (LDS atomics)
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
         if (i < n) {
           const int other = oth[q];
-          const uint32_t key = stream ^ ((c_a[q] & 0xfffffu) * 0x9E3779B1u);
+          const uint32_t key = conv_key(stream, c_a[q] & 0xfffffu);
           uint2 r;
           r.x = other != i ? (((conv_word(key, 1) >> 12) << 11) | (c_b[q] >> 21)) + 1u : 0u; // the time stamp; pad: the cell's rank
           const uint32_t nxt = other != i ? atomicExch(&head[other], (uint32_t)i) : kConvEnd;

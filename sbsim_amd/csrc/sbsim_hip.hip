@@ -714,7 +714,10 @@ void plan_reg(const sb_plan_desc *plan, int lds_per_cu, RegPlan &r) {
   // period is no longer than that: the roll kernel without tail rows, the lanes beyond the plan own pad rows
   // (measured, 65,536 buildings: 47 x 98 / 6 zones 6.8 -> 1.9 ms per step, 62 x 97 4.8 -> 2.5, 49 x 50 8.9 -> 7.6;
   // 25 x 38 and 17 x 25 stay: 3.3 against 4.4, 2.6 against 4.9)
-  if (P == 1 && NR && !env_flag("SBSIM_NO_ROLL_SMALL") && pick_slots(3) && NR + Hs - 1 >= pick_slots(3)) { P = 3; NR = pick_slots(3); }
+  // (only when the roll kernel's own limits hold -- its zone-sum scratch takes <= 31 zones; its LDS layout always fits: checked
+  // HERE, before the switch, so that a plan it cannot take stays on k_sweep_reg<NR,1> instead of falling through to the
+  // LDS-grid kernel)
+  if (P == 1 && NR && !env_flag("SBSIM_NO_ROLL_SMALL") && pick_slots(3) && Z <= 31 && NR + Hs - 1 >= pick_slots(3)) { P = 3; NR = pick_slots(3); }
   if (!P && Hs <= 64 + 2 && pick_slots(3)) {
     bool zone_free = true;
     for (int x = x0 + 64; x <= x1; ++x)

@@ -671,11 +671,11 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
     SB_STAMP(7);
 
     { // hand the zone sums, the grid sum and the sweep count to k_post
-      // 16 zones x 4 row groups per pass: lane (zone = lane & 15, group = lane >> 4) adds every
-      // fourth row of its zone, two xor-shuffles combine the groups
+      // 16 zones x 4 row groups per pass: lane (zone = lane >> 2, group = lane & 3) adds every fourth row of its zone; the
+      // four groups of a zone sit in one quad of lanes, so two DPP quad permutes combine them (no LDS round trip)
       double gacc = 0.0;
       for (int zb = 0; zb <= a.Z; zb += 16) {
-        const int zz = zb + (lane & 15), g = lane >> 4;
+        const int zz = zb + (lane >> 2), g = lane & 3;
         const double *zr = zs + (size_t)g * ZRS + (zz <= a.Z ? zz : a.Z);
         double part[RS / 4];
 #pragma unroll
@@ -684,10 +684,10 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
 #pragma unroll
         for (int k = 0; k < RS / 4; ++k) v += part[k];
         if (zz > a.Z) v = 0.0;
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lane < 16 && zz < a.Z && !redo) a.zsum[(size_t)b * a.Z + zz] = v;
-        if (lane < 16 && zz <= a.Z) gacc += v;
+        v += dpp_or_zero<0xB1, 0xf>(v); // quad_perm [1, 0, 3, 2]: the neighbour in the pair
+        v += dpp_or_zero<0x4E, 0xf>(v); // quad_perm [2, 3, 0, 1]: the other pair of the quad
+        if (g == 0 && zz < a.Z && !redo) a.zsum[(size_t)b * a.Z + zz] = v;
+        if (g == 0 && zz <= a.Z) gacc += v;
       }
       const double gsum = wave_sum(gacc);
       if (lane == 0 && !redo) {

@@ -25,7 +25,8 @@ def _stats(grids, H, W):
   return hist / inner.sum(), fixed, msd
 
 
-KAT_WORDS = [3190747415, 3427320923, 4229512302]   # conv_word(conv_stream(4242, 1000, 0), 777, 0..2)
+KAT_STREAM = (1574376046, 3772118591)               # conv_stream(4242, 1000, 0): two 32-bit words since round 5
+KAT_WORDS = [3743786416, 1994968540, 174502889]     # conv_word(conv_stream(4242, 1000, 0), 777, 0..2)
 
 
 def test_mixer_known_answers():
@@ -37,7 +38,13 @@ def test_mixer_known_answers():
   s = conv_stream(4242, 1000, 0)
   assert s == conv_stream(4242, 1000, 0) and s != conv_stream(4242, 1001, 0) and s != conv_stream(4242, 1000, 1)
   assert conv_stream(0x1_0000_0000 + 4242, 1000, 0) != s                                # the seed's high word counts
-  assert [conv_word(s, 777, k) for k in range(3)] == KAT_WORDS
+  assert s == KAT_STREAM and [conv_word(s, 777, k) for k in range(3)] == KAT_WORDS
+  # a 32-bit stream gives a 65,536-building batch ~0.5 colliding pairs per call (whole buildings making identical
+  # draws); with both words no two buildings of the batch share a stream -- here for three calls, and with a shard offset
+  for call, first in ((0, 0), (1, 0), (287, 65536 * 7)):
+    st = [conv_stream(1234, first + b, call) for b in range(65536)]
+    assert len(set(st)) == 65536, (call, first)
+  assert len({a for a, _ in [conv_stream(1234, b, 0) for b in range(65536)]}) <= 65536   # (the first word alone may collide)
   # uniformity of the top bits over cells and words (a smoke test, not a battery): 4,096 draws into 16 bins
   draws = np.array([conv_word(s, g, k) >> 28 for g in range(1024) for k in range(4)])
   assert np.abs(np.bincount(draws, minlength=16) - 256).max() < 70

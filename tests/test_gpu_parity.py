@@ -1078,6 +1078,16 @@ def test_bench_two_ranks_sharing_one_gpu(monkeypatch):
   assert len(d["per_rank_ms_per_step"]) == 2 and len(d["per_rank_sweep_kernel_ms"]) == 2
   p = _run_bench(["--config", "policy", "--gpus", "2", "--buildings", "4096", "--steps", "2", "--warmup", "1"])
   assert p["n_gpus"] == 2 and p["gathered_returns"] == 8192
+  # configs[2] on two ranks: every class block-partitioned over the ranks on its own, so each rank holds the
+  # same class mix; the gather puts the returns back into global class-major order
+  m = _run_bench(["--config", "mixed", "--gpus", "2", "--buildings", "3072", "--steps", "2", "--warmup", "1", "--check-buildings", "4"])
+  assert m["n_gpus"] == 2 and m["gathered_returns"] == 2 * 3 * 1024 and m["rccl_ranks"] == 2
+  assert m["config"]["class_totals"] == [2048, 2048, 2048] and m["config"]["class_ranges_rank0"] == [[0, 1024]] * 3
+  assert len(m["per_rank_ms_per_step"]) == 2
+  for name, c in m["config"]["classes"].items():
+    assert c["buildings"] == 1024, name
+    par = c["parity_vs_oracle"]
+    assert par["sweep_count_mismatches"] == 0 and par["max_abs_dT_zone_K"] < T_TOL, (name, par)
 
 
 def test_bench_through_the_public_env_api_costs_the_same():
@@ -1085,17 +1095,21 @@ def test_bench_through_the_public_env_api_costs_the_same():
   sweep kernel; `--through-env-api` times BatchedEnvironment.step() itself (host-side step inputs, sb_step,
   TimeStep): within 3 % of the phases path."""
   _need_gpu()
-  common = ["--gpus", "1", "--steps", "20", "--warmup", "30", "--no-cpu-baseline"]
+  import json
+  common = ["--gpus", "1", "--steps", "20", "--warmup", "30", "--no-cpu-baseline", "--no-also"]
   seen = []
-  for attempt in range(3):   # a timing comparison on a shared host: the best of up to three pairs of runs
+  for attempt in range(3):   # three interleaved pairs of runs, always: the verdict is on their medians, not on the luckiest pair
     a = _run_bench(common)
     b = _run_bench(common + ["--through-env-api"])
     assert b["timed_through"] == "BatchedEnvironment.step()" and a["timed_through"].startswith("BatchedSimulator.step")
     assert abs(b["config"]["mean_sweeps_per_env_step"] - a["config"]["mean_sweeps_per_env_step"]) < 1e-9
     seen.append((a["ms_per_step"], b["ms_per_step"]))
-    if b["ms_per_step"] < 1.03 * a["ms_per_step"]:
-      break
-  assert min(y for _, y in seen) < 1.03 * min(x for x, _ in seen), seen
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+  with open(os.path.join(root, "gpurun_out", "env_api_pairs.json"), "w") as fh:   # (copied into profiles/ by the round's collection)
+    json.dump({"command": "bench.py " + " ".join(common) + " [--through-env-api]", "ms_per_step_pairs_phases_vs_env_api": seen}, fh)
+  med = lambda v: sorted(v)[len(v) // 2]
+  assert med([y for _, y in seen]) < 1.03 * med([x for x, _ in seen]), seen
 
 
 def test_bench_two_gpus_when_the_box_has_them():
