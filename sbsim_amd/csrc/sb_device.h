@@ -310,27 +310,9 @@ __device__ __forceinline__ void put_obs_n(const Dev &a, float *row, int n, const
     if (k < n) put_obs_at(a, row, sg[k], mu[k], dest[k], native[k]);
 }
 
-// One building's observation row, written by one thread.  S: the building's scalar state
-// (kNScalOut doubles).  Device columns in sorted (device, field) order (air_handler.py:66-95 /
-// boiler.py:69-79).
-__device__ inline void write_obs(const Dev &a, int b, float *obs, const float *aux, double t_amb_obs,
-                                 const double *S, const float *num_occupants = nullptr, double occ_norm = 0.0) {
-  float *row = obs + (size_t)b * a.O;
-  for (int k = 0; k < a.n_hist; ++k)
-    for (int j = a.hist_off[k]; j < a.hist_off[k + 1]; ++j) row[a.hist_col[k] + j - a.hist_off[k]] = 0.0f;
-  for (int z0 = 0; z0 < a.Z; z0 += 4) { // four zones = twelve values at a time
-    int src[12];
-    double val[12];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int z = z0 + k < a.Z ? z0 + k : z0, c0 = a.col_zone[z];
-      src[3 * k] = c0; src[3 * k + 1] = c0 + 1; src[3 * k + 2] = c0 + 2;
-      val[3 * k] = a.damper[(size_t)b * a.Z + z];   // supply_air_damper_percentage_command
-      val[3 * k + 1] = a.p.vav_max_air_flow;        // supply_air_flowrate_setpoint
-      val[3 * k + 2] = a.zair[(size_t)b * a.Z + z]; // zone_air_temperature_sensor
-    }
-    put_obs_n<12>(a, row, 3 * (a.Z - z0 < 4 ? a.Z - z0 : 4), src, val);
-  }
+// The air handler's and the boiler's fields, the histograms' normalisation, the auxiliary features (write_obs's second half).
+__device__ inline void write_obs_plant(const Dev &a, float *row, const float *aux, double t_amb_obs, const double *S,
+                                       const float *num_occupants, double occ_norm, int b) {
   const int n_ahu = a.p.ahu_has_weather ? 9 : 8;
   const double flow = S[2];
   int src[12];
@@ -375,6 +357,30 @@ __device__ inline void write_obs(const Dev &a, int b, float *obs, const float *a
     row[a.col_aux + SB_NUM_AUX - 1] = (float)(((double)(int)num_occupants[b] - occ_norm) / (occ_norm + 1.0));
 }
 
+// One building's observation row, written by one thread.  S: the building's scalar state
+// (kNScalOut doubles).  Device columns in sorted (device, field) order (air_handler.py:66-95 /
+// boiler.py:69-79).
+__device__ inline void write_obs(const Dev &a, int b, float *obs, const float *aux, double t_amb_obs,
+                                 const double *S, const float *num_occupants = nullptr, double occ_norm = 0.0) {
+  float *row = obs + (size_t)b * a.O;
+  for (int k = 0; k < a.n_hist; ++k)
+    for (int j = a.hist_off[k]; j < a.hist_off[k + 1]; ++j) row[a.hist_col[k] + j - a.hist_off[k]] = 0.0f;
+  for (int z0 = 0; z0 < a.Z; z0 += 4) { // four zones = twelve values at a time
+    int src[12];
+    double val[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int z = z0 + k < a.Z ? z0 + k : z0, c0 = a.col_zone[z];
+      src[3 * k] = c0; src[3 * k + 1] = c0 + 1; src[3 * k + 2] = c0 + 2;
+      val[3 * k] = a.damper[(size_t)b * a.Z + z];   // supply_air_damper_percentage_command
+      val[3 * k + 1] = a.p.vav_max_air_flow;        // supply_air_flowrate_setpoint
+      val[3 * k + 2] = a.zair[(size_t)b * a.Z + z]; // zone_air_temperature_sensor
+    }
+    put_obs_n<12>(a, row, 3 * (a.Z - z0 < 4 ? a.Z - z0 : 4), src, val);
+  }
+  write_obs_plant(a, row, aux, t_amb_obs, S, num_occupants, occ_norm, b);
+}
+
 // ---------------------------------------------------------------- the step around the sweep
 // Values of one building's step handed from k_pre to the sweep kernel (t_now) and k_post.
 struct Bld {
@@ -408,11 +414,6 @@ __device__ inline void observe_boiler(const Dev &a, double *S) {
   }
 }
 
-// k_pre, one thread per building.  request_action: setup_step_sim (thermostats on the stored
-// zone means), then the agent's setpoints; execute_step_sim: the AHU supply temperature, the
-// per-building table g[class] = gc*T_amb + sc*q_zone (q of the PREVIOUS step feeds this sweep),
-// VAV outputs from the PRE-update zone temperatures (simulator.py:433-448), demand accumulation
-// in the reference's zone order, boiler tank lag (boiler.py:158-217).
 // np.interp(x, xp, fp) for one x (numpy's arr_interp: value at a knot is the knot's, otherwise
 // slope * (x - xp[j]) + fp[j] with the slope of the bracketing interval), then
 // conversion_utils.fahrenheit_to_kelvin (conversion_utils.py:155-171).
@@ -435,7 +436,30 @@ __device__ inline double replay_weather_kelvin(const double *xp, const double *f
   return __dadd_rn(__dmul_rn(f - 32.0, 5.0) / 9.0, 273.15);
 }
 
-__device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
+// Lane k of the calling lane's 16-lane DPP row broadcast to the row (row_newbcast:k).
+template <int K>
+__device__ __forceinline__ double row_bcast(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + K, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// fn(k, lane k's values ...) for k = 0 .. n-1 in order: the row's sequential accumulations (the reference adds zone by zone)
+template <int K = 0, typename F>
+__device__ __forceinline__ void row_each(int n, double x0, double x1, double x2, double x3, F &&fn) {
+  if constexpr (K < 16) {
+    if (K < n) fn(row_bcast<K>(x0), row_bcast<K>(x1), row_bcast<K>(x2), row_bcast<K>(x3));
+    row_each<K + 1>(n, x0, x1, x2, x3, fn);
+  }
+}
+
+// k_pre: one 16-lane row of a wavefront per building, lanes = zones (16 at a time), the per-building demand sums added in
+// the reference's zone order through row broadcasts.  request_action: setup_step_sim (thermostats on the stored
+// zone means), then the agent's setpoints; execute_step_sim: the AHU supply temperature, the
+// per-building table g[class] = gc*T_amb + sc*q_zone (q of the PREVIOUS step feeds this sweep),
+// VAV outputs from the PRE-update zone temperatures (simulator.py:433-448), demand accumulation
+// in the reference's zone order, boiler tank lag (boiler.py:158-217).
+// i: the lane's index in its row; every lane of the row runs the per-building (uniform) part -- same addresses, one transaction.
+__device__ inline void pre_building(const Dev &a, const StepArgs &s, int b, int i) {
   const sb_params &p = a.p;
   const sb_step_in &in = s.in;
   const double *S = a.scal + (size_t)b * kNScal;
@@ -454,24 +478,26 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
     v.t_next = in.t_amb_dev ? in.t_amb_dev[2 * b + 1] : in.t_amb_next;
   }
   v.heat_sp = S[0]; v.cool_sp = S[1]; v.blr_sp = S[4];
+  const double recirc = S[11], S8 = S[8], S9 = S[9], S10 = S[10], S18 = S[18];
+  double age = S[19];
   // a building that rejected the request (environment.py:1266-1309) runs neither setup_step_sim nor set_action
   const bool rejected = in.reject_dev && in.reject_dev[b];
   const bool acting = in.has_action && !rejected;
   v.rejected = rejected;
   // The action vector, column by column (bounded_action_normalizer.py:73-98, then the proto's float field).  A damper command
-  // is only VALIDATED here (vav.py:125-129: the setter raises outside [0, 1] -> the step's reward is -inf); the zone loop below
-  // reads its own column again (zone_act) -- no per-building array of commands, whatever the number of VAVs.
+  // is only VALIDATED here (vav.py:125-129: the setter raises outside [0, 1] -> the step's reward is -inf); a zone's lane
+  // reads its own column again below (zone_act) -- no per-building array of commands, whatever the number of VAVs.
   bool boiler_action = false;
-  auto native_of = [&](int i, bool &present) {
-    const double ai = (double)s.actions[(size_t)b * p.n_actions + i];
+  auto native_of = [&](int col, bool &present) {
+    const double ai = (double)s.actions[(size_t)b * p.n_actions + col];
     present = !(in.actions_native && ai <= (double)SB_ACTION_KEEP); // (else: the request does not mention this field)
-    return in.actions_native ? ai : (double)(float)((ai + 1.0) / 2.0 * (a.act_hi[i] - a.act_lo[i]) + a.act_lo[i]);
+    return in.actions_native ? ai : (double)(float)((ai + 1.0) / 2.0 * (a.act_hi[col] - a.act_lo[col]) + a.act_lo[col]);
   };
-  for (int i = 0; i < p.n_actions && acting; ++i) {
+  for (int c = 0; c < p.n_actions && acting; ++c) {
     bool present;
-    const double native = native_of(i, present);
+    const double native = native_of(c, present);
     if (!present) continue;
-    switch (a.act_kind[i]) {
+    switch (a.act_kind[c]) {
       case SB_ACT_BOILER_SUPPLY_WATER_SETPOINT: v.blr_sp = native; boiler_action = true; break;
       case SB_ACT_AHU_SUPPLY_AIR_HEATING_SETPOINT: v.heat_sp = native; break;
       case SB_ACT_AHU_SUPPLY_AIR_COOLING_SETPOINT: v.cool_sp = native; break;
@@ -479,62 +505,46 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
         if (native < 0.0 || native > 1.0) v.rejected = 1;
     }
   }
-  const double recirc = S[11];
   const double mixed = p.ahu_recirc * recirc + (1 - p.ahu_recirc) * v.t_now;
   v.t_sa = ahu_supply(mixed, v.heat_sp, v.cool_sp);
+  // g[class]: a lane per class, 16 at a time.  q is the PREVIOUS step's: every read of qz here is issued before the zone
+  // loop below stores this step's (one instruction stream: a wavefront's memory operations on an address stay in order)
   double *gt = a.gtabg + (size_t)b * a.ts;
-  // (in chunks of eight, loads before stores: a store to gt may alias the next class's loads for all the compiler knows,
-  // and one class per round trip to L2 -- class -> its zone -> that zone's q -- was most of this kernel's time)
-  for (int c0 = 0; c0 < a.ts; c0 += 8) {
-    double gg[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int c = c0 + k;
-      gg[k] = 0.0;
-      if (c < a.ncls) {
-        const int zc = a.czone[c];
-        const double q = zc >= 0 ? a.qz[zb + zc] : 0.0;
-        gg[k] = fma(a.ctab[c * 8 + 6], q, a.ctab[c * 8 + 5] * v.t_now);
-      }
+  for (int c = i; c < a.ts; c += 16) {
+    double gg = 0.0;
+    if (c < a.ncls) {
+      const int zc = a.czone[c];
+      const double q = zc >= 0 ? a.qz[zb + zc] : 0.0;
+      gg = fma(a.ctab[c * 8 + 6], q, a.ctab[c * 8 + 5] * v.t_now);
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (c0 + k < a.ts) gt[c0 + k] = gg[k];
+    gt[c] = gg;
   }
   const double hsp = in.comfort_now ? p.comfort_lo : p.eco_lo;
   const double csp = in.comfort_now ? p.comfort_hi : p.eco_hi;
   // Thermostat._previous_timestamp (thermostat.py:88): the host's value, or the building's own when
   // buildings can skip thermostat updates (scal[18]: -1 none, else is_comfort_mode of the last update)
-  const int comfort_prev = in.reject_dev ? (int)S[18] : in.comfort_prev;
+  const int comfort_prev = in.reject_dev ? (int)S18 : in.comfort_prev;
   double ahu_flow = 0.0, blr_flow = 0.0, num = 0.0, den = 0.0;
   int ahu_count = 0, blr_count = 0;
-  for (int z0 = 0; z0 < a.Z; z0 += 8) { // eight zones' inputs first (see gt above), then their arithmetic in zone order
-   double tz8[8], dm8[8];
-   int mr8[8];
-#pragma unroll
-   for (int k = 0; k < 8; ++k) {
-     const size_t i = zb + (size_t)(z0 + k < a.Z ? z0 + k : z0);
-     tz8[k] = a.zmean[i]; mr8[k] = a.mode[i]; dm8[k] = rejected ? a.damper[i] : 0.0;
-   }
-#pragma unroll
-   for (int k = 0; k < 8; ++k) {
-    const int z = z0 + k;
-    if (z >= a.Z) break;
-    const double tz = tz8[k];           // pre-update zone mean (vav.zone_air_temperature)
-    const int mraw = mr8[k];
-    int mode = mraw & kModeMask;        // thermostat.py:114-148
+  for (int z0 = 0; z0 < a.Z; z0 += 16) { // sixteen zones at a time, a lane each; then their demand in zone order
+    const int z = z0 + i;
+    const bool on = z < a.Z;
+    const size_t zi = zb + (size_t)(on ? z : z0);
+    const double tz = a.zmean[zi];           // pre-update zone mean (vav.zone_air_temperature)
+    const int mraw = a.mode[zi];
+    int mode = mraw & kModeMask;            // thermostat.py:114-148
     bool valve_open = (mraw & kValveBit) != 0;
     if (!rejected) {
       if (in.comfort_now) mode = default_control(mode, tz, hsp, csp);
       else if (comfort_prev == 1) mode = 3;
       else if (!(mode == 3 && tz > hsp)) mode = default_control(mode, tz, hsp, csp);
-      valve_open = mode == 1;           // vav.py:229-243: update_settings writes damper and valve
-      a.mode[zb + z] = mode | (valve_open ? kValveBit : 0);
+      valve_open = mode == 1;               // vav.py:229-243: update_settings writes damper and valve
+      if (on) a.mode[zi] = mode | (valve_open ? kValveBit : 0);
     }
     double damper = (mode == 1 || mode == 2) ? 1.0 : 0.1;
-    if (rejected) damper = dm8[k];                          // nobody touched the VAV: what it had
-    if (acting && a.n_damper_actions > 0) {                  // set_action after update_settings
-      const int col = a.zone_act[z];
+    if (rejected) damper = a.damper[zi];                      // nobody touched the VAV: what it had
+    if (acting && a.n_damper_actions > 0) {                   // set_action after update_settings
+      const int col = a.zone_act[on ? z : z0];
       if (col >= 0) {
         bool present;
         const double native = native_of(col, present);
@@ -547,29 +557,31 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
     const double heat_diff = kCAir * air - kCWater * reheat;     // vav.py:181-195
     const double water_heat = v.blr_sp * kCWater * reheat;
     const double tzs = (v.t_sa * heat_diff + water_heat) / air / kCAir;
-    a.qz[zb + z] = air * kCAir * (tzs - tz);                     // vav.py:211-217
-    a.zair[zb + z] = tz;
-    a.damper[zb + z] = damper;
-    // air_handler.py:254-268, boiler.py:219-231, simulator.py:373-381
-    if (air > 0) {
-      ahu_flow += air;
-      if (ahu_flow > p.ahu_max_flow) ahu_flow = p.ahu_max_flow;
-      ++ahu_count;
+    if (on) {
+      a.qz[zi] = air * kCAir * (tzs - tz);                       // vav.py:211-217
+      a.zair[zi] = tz;
+      a.damper[zi] = damper;
     }
-    if (reheat > 0) { blr_flow += reheat; ++blr_count; }
-    num += valve * tzs;
-    den += valve;
-   }
+    // air_handler.py:254-268, boiler.py:219-231, simulator.py:373-381: zone after zone
+    row_each(a.Z - z0, air, reheat, valve, tzs, [&](double air_k, double reheat_k, double valve_k, double tzs_k) {
+      if (air_k > 0) {
+        ahu_flow += air_k;
+        if (ahu_flow > p.ahu_max_flow) ahu_flow = p.ahu_max_flow;
+        ++ahu_count;
+      }
+      if (reheat_k > 0) { blr_flow += reheat_k; ++blr_count; }
+      num += valve_k * tzs_k;
+      den += valve_k;
+    });
   }
   v.ahu_flow = ahu_flow; v.blr_flow = blr_flow; v.ahu_count = ahu_count; v.blr_count = blr_count;
   v.blr_return = num / (den + 1e-6);
   // _get_observation: the boiler tank lag advances (boiler.py:158-217)
-  v.tank = S[8]; v.tank_change = S[9]; v.duration = S[10];
+  v.tank = S8; v.tank_change = S9; v.duration = S10;
   // boiler.py:158-168 at this step's observation (Environment: one per step): with an action time stamp
   // (smart_device.py:193; a rejected request leaves the old one) the duration is observation_ts -
   // action_ts; without one the first observation becomes it and the duration keeps its value.
   // scal[19]: (last observation - action time stamp) / dt, kAgeNone = no action time stamp yet.
-  double age = S[19];
   if (in.has_action) {
     const bool none = age_is_none(age);
     if (boiler_action) age = 1.0;
@@ -578,7 +590,7 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
     if (boiler_action || !none) v.duration = age * p.dt;
   }
   v.action_age = age;
-  v.comfort_seen = rejected ? (int)S[18] : in.comfort_now;
+  v.comfort_seen = rejected ? (int)S18 : in.comfort_now;
   if (p.blr_cooling_rate > 0.0 && p.blr_heating_rate > 0.0) {
     const double begin = v.tank;
     if (v.blr_sp > begin) v.tank = fmin(begin + p.blr_heating_rate * v.duration / 60.0, v.blr_sp);
@@ -588,9 +600,13 @@ __device__ inline void pre_building(const Dev &a, const StepArgs &s, int b) {
   } else {
     v.tank = v.blr_sp;
   }
-  a.bld[b] = v;
+  if (i == 0) a.bld[b] = v;
 }
 
+// (k_post stays one THREAD per building.  Measured, round 5: as one 16-lane row per building -- the shape of k_pre, a zone per
+// lane, the reference's zone-by-zone sums through row broadcasts -- it takes 64 us against 37 (65,536 buildings): its 165
+// registers leave three wavefronts per SIMD, i.e. 12,288 buildings in flight where the thread-per-building kernel keeps all
+// 65,536 in flight at once, and its time is the chain of dependent reads of one building, not the instructions.)
 // k_post, one thread per building.  reward_info (simulator.py:457-576) + regret reward on fp32
 // proto fields, scalar state, observation row, from the sweep kernel's zone sums / grid sum.
 __device__ inline void post_building(const Dev &a, const StepArgs &s, int b) {

@@ -150,28 +150,30 @@ __global__ void k_copy_scalars(Dev a, double *out) {
     out[i] = a.scal[(i / kNScalOut) * kNScal + (i % kNScalOut)];
 }
 
-// Per-building algebra before / after the sweep kernel: one thread per building (sb_device.h).
+// Per-building algebra before / after the sweep kernel (sb_device.h).  k_pre: one 16-lane row of a wavefront per building,
+// lanes = zones -- four buildings per wavefront, sixteen per workgroup; the building's demand sums in the reference's zone
+// order through DPP row broadcasts.  k_post: one thread per building (the row shape was measured slower: sb_device.h).
 // only >= 0: that building alone (the known-answer taps).
-__global__ void __launch_bounds__(64) k_pre(Dev a, StepArgs s, int only) {
+constexpr int kRowsPerBlock = 16; // buildings per workgroup of 256 threads
+__global__ void __launch_bounds__(16 * kRowsPerBlock) k_pre(Dev a, StepArgs s, int only) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { // the sweep kernel's draw counter; mode 3: the redo list's counters
     *a.next_b = 0;
     if (a.redo_ctr) a.redo_ctr[0] = a.redo_ctr[1] = 0;
   }
+  const int i = threadIdx.x & 15, r = threadIdx.x >> 4;
   if (only >= 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) pre_building(a, s, only);
+    if (blockIdx.x == 0 && r == 0) pre_building(a, s, only, i);
     return;
   }
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
-    pre_building(a, s, b);
+  for (int b = blockIdx.x * kRowsPerBlock + r; b < a.B; b += gridDim.x * kRowsPerBlock) pre_building(a, s, b, i);
 }
 
-__global__ void __launch_bounds__(64) k_post(Dev a, StepArgs s, int only) {
+__global__ void __launch_bounds__(64) k_post(Dev a, StepArgs s, int only) { // one thread per building: see sb_device.h
   if (only >= 0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) post_building(a, s, only);
     return;
   }
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x)
-    post_building(a, s, b);
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x) post_building(a, s, b);
 }
 
 // ---------------------------------------------------------------- register-path planning
@@ -1455,9 +1457,9 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   StepArgs s;
   s.actions = actions_dev; s.obs = obs_dev; s.reward = reward_dev; s.info = info_dev; s.in = *in;
   const Dev &d = h->d;
-  const int blocks = std::max(1, std::min((d.B + 63) / 64, h->cus * 16)); // one thread per building
+  const int blocks = std::max(1, std::min((d.B + kRowsPerBlock - 1) / kRowsPerBlock, h->cus * 32)); // a 16-lane row per building
   if (phases & SB_PHASE_PRE) {
-    hipLaunchKernelGGL(k_pre, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s, -1);
+    hipLaunchKernelGGL(k_pre, dim3(blocks), dim3(16 * kRowsPerBlock), 0, (hipStream_t)stream, d, s, -1);
     SB_HIP(hipGetLastError());
   }
   if (phases & SB_PHASE_SWEEP) {
@@ -1479,7 +1481,7 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
       const int rc = sb_launch_convection(h, (hipStream_t)stream); // k_post do not change (values move inside rooms)
       if (rc != SB_OK) return rc;
     }
-    hipLaunchKernelGGL(k_post, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d, s, -1);
+    hipLaunchKernelGGL(k_post, dim3(std::max(1, std::min((d.B + 63) / 64, h->cus * 16))), dim3(64), 0, (hipStream_t)stream, d, s, -1);
     ++h->steps_since_reset;
     SB_HIP(hipGetLastError());
   }
@@ -1550,7 +1552,7 @@ int sb_tap_pre(sb_handle *h, int32_t building, const double *zone_temps, const i
   }
   StepArgs s{};
   s.actions = act.p; s.in = *in;
-  hipLaunchKernelGGL(k_pre, dim3(1), dim3(64), 0, nullptr, d, s, building); // this building alone
+  hipLaunchKernelGGL(k_pre, dim3(1), dim3(16 * kRowsPerBlock), 0, nullptr, d, s, building); // this building alone
   SB_HIP(hipGetLastError());
   SB_HIP(hipDeviceSynchronize());
   if (bld) {
