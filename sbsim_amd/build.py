@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["sbsim_hip.hip", "step_reg.hip", "step_roll.hip", "step_two.hip", "step_two_64.hip", "step_two_76.hip", "step_two_80.hip", "step_band.hip", "step_band_68.hip", "step_band_72.hip", "step_band_76.hip", "step_band_80.hip", "step_band_84.hip", "step_band_88.hip", "step_band_92.hip", "step_band_96.hip", "step_stream.hip", "step_lds.hip",    # one translation unit per step kernel
+SOURCES = ["sbsim_hip.hip", "step_reg.hip", "step_roll.hip", "step_two.hip", "step_two_64.hip", "step_two_76.hip", "step_two_80.hip", "step_band.hip", "step_band_68.hip", "step_band_72.hip", "step_band_76.hip", "step_band_80.hip", "step_band_84.hip", "step_band_88.hip", "step_band_92.hip", "step_band_96.hip", "step_stream.hip", "step_stream_ms.hip", "step_lds.hip",    # one translation unit per step kernel
            "generators.hip",                                 # occupancy / convection generators
            "floorplan.cpp", "episode.cpp"]                   # host-only: floor-plan preprocessing, episode shards
 HEADERS = [os.path.join(CSRC, "sb_device.h"), os.path.join(CSRC, "sb_host.h"), os.path.join(CSRC, "sweep_common.h"), os.path.join(CSRC, "step_two_impl.h"), os.path.join(CSRC, "step_two_cfg.h"), os.path.join(CSRC, "step_band_impl.h"), os.path.join(CSRC, "step_band_cfg.h"),

@@ -2,16 +2,18 @@
 //
 // One environment step (include/sbsim_amd.h, sb_step) is three launches on the caller's stream:
 //   k_pre   (sbsim_hip.hip)  thermostats, setpoints, VAV / air handler / boiler demand, the
-//                            per-building g table; one thread per building
-//   sweep   step_reg.hip  k_sweep_reg  the Gauss-Seidel sweeps with the temperature grid in the
-//                            VGPRs of one or two wavefronts (lane = row, cyclic-skewed slots)
-//           step_roll.hip k_sweep_roll the same for 65..66-row plans (R9): one wavefront + tail rows,
-//                            consecutive sweeps overlapped
-//           step_lds.hip  k_sweep_lds  the same with the grid in LDS (any floor-plan shape)
-//   k_post  (sbsim_hip.hip)  reward_info, regret reward, observation row, scalar state
+//                            per-building g table; one 16-lane DPP row of a wavefront per building, lanes = zones
+//   sweep   step_roll.hip k_sweep_roll   <= 66 rows (R9): one wavefront + tail rows, the grid in registers, sweeps overlapped
+//           step_two.hip  k_sweep_two    67..130 rows: two rows per lane
+//           step_band.hip k_sweep_band   131..258 rows: two to four wavefronts per building
+//           step_reg.hip  k_sweep_reg    small plans (one / two wavefronts, no overlap)
+//           step_lds.hip  k_sweep_lds    the grid in LDS (any floor-plan shape that fits a CU)
+//           step_stream.hip k_sweep_stream  the grid in global memory (everything else)
+//   k_post  (sbsim_hip.hip)  reward_info, regret reward, observation row, scalar state; one thread per building
 // The sweep kernel is > 95 % of the time and is kept free of everything else: its unrolled
-// code already fills the instruction cache, and the per-building algebra (a few hundred
-// flops on 9..126 zones) would run on a few lanes of one wavefront while the grid waits.
+// code already fills the instruction cache, and a lone wavefront per SIMD pays one issue slot per instruction
+// whatever the number of lanes that work -- the per-building algebra (~650 instructions with lanes = zones) would cost the
+// sweep kernel what the two small launches cost now.
 // The per-building algebra is the code in this header (pre_building, post_building).
 //
 // Reference behaviour (all under /root/reference/smart_control):
@@ -91,6 +93,7 @@ struct Dev {
   int AS;                  // row stride of A in LDS (odd when it fits: bank-conflict free)
   int ZRS;                 // row stride of the zone-sum scratch [Z+1][ZRS] that aliases A (RS | 1)
   int Ws;                  // trimmed width
+  int stream_ms;           // mode 6: 1 = step_stream_ms.hip (several sweeps per pass over the grid), 0 = step_stream.hip
   int n_ring;              // exterior-space cells outside the trim box (all of class "ambient")
   double n_ring_f64;       // (double)n_ring: a kernel argument, not a conversion the compiler keeps in a VGPR pair for the kernel's lifetime
   int lw[4], l0[2], rowbase[2], nch[2]; // per wave: rows (mode 5: up to four wavefronts), first lane, first row, 8-step chunks
@@ -190,6 +193,12 @@ int launch_sweep_stream(const Dev &d, double *abuf, int waves, hipStream_t strea
 int prepare_sweep_stream(const Dev &d, int waves);
 int sweep_stream_set_table();
 int sweep_stream_zone_columns();
+// step_stream_ms.hip: mode 6 with several sweeps per pass (two grids in global memory take turns)
+int launch_sweep_stream_ms(const Dev &d, double *abuf, double *ebuf, int waves, hipStream_t stream);
+int prepare_sweep_stream_ms(const Dev &d, int waves);
+int sweep_stream_ms_sweeps();                      // sweeps per pass, at most
+int sweep_stream_ms_seam_doubles(int NS, int W);   // LDS doubles of the seam rows
+int sweep_stream_ms_xchg_doubles(int W);           // ... of the progress words, max|delta| parts and publish scratch
 int prepare_sweep_roll(const Dev &d);
 bool sweep_roll_supported(int NR);
 int sweep_roll_lds_slots(int NR);            // slots of A in LDS

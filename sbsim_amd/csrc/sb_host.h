@@ -85,6 +85,7 @@ struct sb_handle {
   sb_launch_info info{};
   DevBuf<uint8_t> cls, tcls, tcset;
   DevBuf<double> abuf; // step_stream.hip: A = ap*Tprev + g of the buildings in flight
+  DevBuf<double> ebuf; // step_stream_ms.hip: the scratch grid a pass writes when it reads the building's state (per resident workgroup)
   DevBuf<double> redo_scratch; // step_roll.hip: see Dev
   DevBuf<int> redo_ctr, redo_list, zs_off;
   DevBuf<int> act_kind, act_zone, zone_act; // the action vector's tables (sb_params.act_*) on the device

@@ -190,6 +190,7 @@ struct RegPlan {
   int r_seam = 0, r_A = 0, r_xchg = 0, lds_bytes = 0, wg_per_cu = 0, AS = 0;
   int r_cmap = 0, wave_doubles = 0, waves_per_wg = 1; // mode 3: four buildings per workgroup share the class words
   int ZRS = 0; // modes 1..3: row stride of the zone-sum scratch
+  int stream_ms = 0; // mode 6: several sweeps per pass (step_stream_ms.hip)
   std::vector<unsigned long long> cmapS, amapS, zmapS;
   std::vector<int> cell_state;
   // mode 4 (plan_two)
@@ -608,13 +609,22 @@ bool plan_stream(const sb_plan_desc *plan, RegPlan &r, std::string &why) {
   if (Z > 65534) { why = "too many zones"; r.csetab.clear(); return false; }
   const int ZC = sweep_stream_zone_columns();
   int off = 4 * sweep_stream_set_table() + 2 * ts;
-  r.r_seam = off; off += 2 * NWV * (NS + 8);
-  r.r_xchg = off; off += 32 + 64 * NWV; // progress, max|delta| parts, the publish scratch
+  // step_stream_ms.hip (several sweeps per pass over the grid: a seam row per sweep) -- OPT-IN, SBSIM_STREAM_MS=1: correct
+  // (bit-identical iterates, tests/test_gpu_parity.py) but not faster yet (256 registers leave two
+  // wavefronts per SIMD, and a step of four sweep slots takes 3.3x a step of step_stream.hip's one).  Needs its LDS to fit
+  // and the last wavefront to own the spare rows its bands need (the band of sweep j sits j rows further up).
+  {
+    const int ms_off = off + sweep_stream_ms_seam_doubles(NS, NWV) + sweep_stream_ms_xchg_doubles(NWV) + (Z + 1) * ZC;
+    r.stream_ms = env_flag("SBSIM_STREAM_MS") && ms_off * 8 <= kLdsCap && 64 * NWV - Hs >= sweep_stream_ms_sweeps() - 1 &&
+                  NWV <= 8; // (its 256 registers: two wavefronts per SIMD, workgroups of at most 8)
+  }
+  r.r_seam = off; off += r.stream_ms ? sweep_stream_ms_seam_doubles(NS, NWV) : 2 * NWV * (NS + 8);
+  r.r_xchg = off; off += r.stream_ms ? sweep_stream_ms_xchg_doubles(NWV) : 32 + 64 * NWV; // progress, max|delta| parts, the publish scratch
   r.r_A = off; off += (Z + 1) * ZC;
   r.lds_bytes = off * 8;
   if (r.lds_bytes > kLdsCap) { why = "the seam rows (rows / 64 x columns x 16 bytes) and the zone sums do not fit in 160 KiB of LDS"; r.csetab.clear(); return false; }
   // workgroups per CU: LDS, threads (2,048 per CU) and registers (<= 128 per lane: four wavefronts per SIMD)
-  r.wg_per_cu = std::max(1, std::min({kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule), 32 / NWV, 16 / NWV}));
+  r.wg_per_cu = std::max(1, std::min({kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule), 32 / NWV, (r.stream_ms ? 8 : 16) / NWV}));
   r.NR = NS; r.P = 6; r.RS = RS; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
   r.T = 0; r.ts = ts; r.AS = 0;
   r.state_doubles = NS * RS;
@@ -1228,6 +1238,8 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     }
     SB_TRY(alloc_zero(h->temp, (size_t)d.B * d.state_doubles));
     if (d.P == 6) SB_TRY(alloc_zero(h->abuf, (size_t)h->info.workgroups * d.state_doubles)); // A = ap*Tprev + g, one grid per resident workgroup
+    d.stream_ms = d.P == 6 ? r.stream_ms : 0;
+    if (d.stream_ms) SB_TRY(alloc_zero(h->ebuf, (size_t)h->info.workgroups * d.state_doubles)); // the pass's other grid
     d.two_abuf = nullptr;
     if (d.P == 4) { // step_two.hip: the slots of A that stream from L2, one strip per resident workgroup
       SB_TRY(alloc_zero(h->abuf, (size_t)h->info.workgroups * (size_t)std::max(1, d.NR - sweep_two_lds_slots(d.NR, d.two_level)) * 128));
@@ -1381,7 +1393,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     if (alloc_zero(h->dbg, 16 + (d.dbg_timeline ? 2048 : 0)) == SB_OK) d.dbg = h->dbg.p;
   }
 
-  const int e = d.reg ? (d.P == 6 ? prepare_sweep_stream(d, h->info.waves_per_workgroup) : d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
+  const int e = d.reg ? (d.P == 6 ? (d.stream_ms ? prepare_sweep_stream_ms(d, h->info.waves_per_workgroup) : prepare_sweep_stream(d, h->info.waves_per_workgroup)) : d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
                       : prepare_sweep_lds((size_t)h->info.lds_bytes_per_workgroup);
   if (e != (int)hipSuccess) {
     delete h;
@@ -1466,7 +1478,8 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
     if (!(phases & SB_PHASE_PRE)) // k_pre zeroes the sweep kernel's draw counter; without it in this call:
       SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream));
     if (!(phases & SB_PHASE_PRE) && d.redo_ctr) SB_HIP(hipMemsetAsync(d.redo_ctr, 0, 2 * sizeof(int), (hipStream_t)stream));
-    const int e = d.reg ? (d.P == 6   ? launch_sweep_stream(d, h->abuf.p, h->info.waves_per_workgroup, (hipStream_t)stream)
+    const int e = d.reg ? (d.P == 6   ? (d.stream_ms ? launch_sweep_stream_ms(d, h->abuf.p, h->ebuf.p, h->info.waves_per_workgroup, (hipStream_t)stream)
+                                                     : launch_sweep_stream(d, h->abuf.p, h->info.waves_per_workgroup, (hipStream_t)stream))
                        : d.P == 5 ? launch_sweep_band(d, (hipStream_t)stream)
                        : d.P == 4 ? launch_sweep_two(d, (hipStream_t)stream)
                        : d.P == 3 ? launch_sweep_roll(d, (hipStream_t)stream)

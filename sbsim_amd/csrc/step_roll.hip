@@ -30,7 +30,24 @@
 //   * window steps route |delta| to the accumulator of the lane's own sweep by its SIGN: a lane
 //     mask that one DPP shift per step maintains is OR-ed into the high word, one running max
 //     (sweep k) and one running min (sweep k+1) -- no lane compare, no select
+//     (the float64 instantiation; the library's kernel carries the high word of |delta| in a TRAVELLING maximum: struct Acc)
 // Plain step: 14.5 issue slots (was 16), window step 19.5 (was 22), 12 LDS cycles (was 20).
+//
+// Around the sweeps (round 5; the order of a building's memory operations decides what its wavefront waits for):
+//   * nothing at the top of a building reads a memory result: the draw of the next building (an atomic) is READ after the
+//     sweeps, and the compiler's atomic optimizer -- which turns the one-lane atomic into a wave reduction that reads the
+//     result at once, i.e. waits for every load in flight = the next building's rows -- is off (sbsim_amd/build.py);
+//   * the next building's small inputs and class bytes are asked for BEFORE its rows (memory operations return in order);
+//   * A = ap*Tprev + g has no pass of its own: a slot's A is formed during the ramp-up of the first sweep, a few slots ahead
+//     of the step that reads it (struct APass), so the ramp-up starts on the first rows while the last are in flight;
+//   * the tail rows' scan multiplies by STATIC factors (the multiplicative halves of its composed maps are products of bL:
+//     the planner runs that half once, sweep_common.h tail_pass_static): a level is two DPP moves and one FMA;
+//   * the stopping decision of the library's kernel is taken on high words throughout (rows, tail cells, ring): one 32-bit
+//     wave maximum; what 32 bits cannot decide goes to the float64 instantiation through the redo list, as before;
+//   * zone sums: a row-major scratch [lane][zone] with ONE BYTE per slot (hand_over);
+//   * no kernel-lifetime per-lane pointers or converted constants (each one the register allocator parks in scratch costs a
+//     scratch reload = a wait for every load in flight): per-lane addresses are formed where they are used (opaque()).
+// Policy loop (two sweeps per step): 3.73e8 -> 4.45e8 zone-updates/s; the driver's window: frac 0.199 -> 0.208.
 #include "sweep_common.h"
 
 namespace sb {
@@ -609,6 +626,7 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
           if (m_hi <= thr_hi && undecided) { redo = 1; break; } // 32 bits cannot tell: the exact kernel takes the building
           converged = m_hi < thr_hi;
         }
+        SB_STAMP2(14);
 #ifdef SB_EXP_DESYNC // timing experiments: sweep counts 1..9 by building number (mean 5), whatever the numbers are
         if (n_sweeps >= 1 + (int)(((unsigned)b * 2654435761u >> 13) % 9u)) break;
 #else

@@ -53,4 +53,10 @@ for name, rooms, shape, B, force in CASES:
   print(f"{name}: B={B}, kernel {li['kernel']} ({li['waves_per_building']} wavefronts per building, {li['workgroups']} workgroups, "
         f"{li['lds_bytes_per_workgroup']} B LDS), sweep kernel {ms:.2f} ms/step, mean sweeps {np.mean(sweeps):.2f}, "
         f"{B * cells * np.mean(sweeps) / (ms * 1e-3):.3e} cell-sweeps/s, {B * cells * np.mean(sweeps) * 28 / (ms * 1e-3) / 1e12:.2f} TB/s at 28 B per cell-sweep")
+  if os.environ.get("SBSIM_PHASE_TIMING") and li["kernel"] == 6:
+    import ctypes
+    from sbsim_amd import _ffi
+    buf = (ctypes.c_longlong * 16)()
+    if _ffi.load().sb_debug_phase_cycles(env.sim._h, buf) == 0 and buf[0]:
+      print(f"    step_stream_ms.hip: {buf[1] / buf[0]:.2f} passes, {buf[2] / buf[0]:.2f} sweep slots, {buf[3] / buf[0]:.2f} sweeps per building-step")
   env.close()

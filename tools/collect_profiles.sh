@@ -6,7 +6,7 @@ STEPS=${STEPS:-20}; WARM=${WARM:-5}   # the driver's bench command
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/profiles_$tag
 mkdir -p $out
-cmd="python $PWD/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline"
+cmd="python $PWD/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-also"   # (the headline leg alone: the default run's "also" legs launch other kernels)
 echo "$cmd" > $out/command.txt
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$tag -o bench -- $cmd > $out/bench_under_rocprof.json 2> /tmp/prof_stats_$tag.err)
 find /tmp/prof_stats_$tag -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
@@ -89,5 +89,5 @@ bash $PWD/tools/pmc_sweep.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY S
 # (the stamps are compiled in with -DSB_PHASE_STAMPS only: tools/build_variant.sh stamps step_roll.hip,step_two_76.hip,step_two_80.hip,step_band_76.hip,...,step_band_96.hip -DSB_PHASE_STAMPS)
 [ -f $PWD/tools/libexp_stamps.so ] && SBSIM_LIB=$PWD/tools/libexp_stamps.so SBSIM_PHASE_TIMING=1 LIMS=1,2,4 timeout 600 python $PWD/tools/prof_sweeps.py 2>&1 | grep -v amdgpu.ids > $out/phase_cycles.txt
 # the same bench after 100 warm-up steps: the steady state beside the driver's transient window
-timeout 600 python $PWD/bench.py --steps 20 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_steady.json
+timeout 600 python $PWD/bench.py --steps 20 --warmup 100 --no-cpu-baseline --no-also 2>/dev/null | tail -1 > $out/bench_steady.json
 ls -la $out

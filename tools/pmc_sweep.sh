@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 i=0
 for ctrs in "$@"; do
   i=$((i+1)); out=/tmp/pmc_sweep_$i; rm -rf $out
-  (cd /tmp && timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $out.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-also --steps 20 --warmup 5 > $out.log 2>&1)
   python - "$out" <<'PY'
 import sys, glob, csv, collections
 acc = collections.defaultdict(float)
