@@ -10,7 +10,7 @@ the other in uniformly random order (:137-145).  Here the swaps are really appli
 the other (the device follows every value through the sequence instead); the draws are the
 device's: a counter-based mixer -- MurmurHash3's 32-bit finaliser -- over (stream, cell, word number):
 stream = (s0, s1) = conv_stream(seed, global building, call number), word k of the cell with grid index g0 =
-fmix32(fmix32(s0 ^ g0 * 0x9E3779B1) + s1 + k * 0x6C8E9CF5); word 0 -> inclusion (u = (x >> 8) / 2**24, included
+fmix32((s0 ^ g0 * 0x9E3779B1) + s1 + k * 0x6C8E9CF5); word 0 -> inclusion (u = (x >> 8) / 2**24, included
 unless u > p), word 1 -> order (swaps by increasing ((x >> 12) << 11 | the cell's rank in the room)),
 word 2 -> the partner ((x * count) >> 32 among the valid offsets in (dx, dy) raster order); wide windows:
 words 2, 3, .. -> candidates until one is accepted.  The reference draws from Python's
@@ -34,24 +34,28 @@ def fmix32(h: int) -> int:
   return h
 
 
-def conv_stream(seed: int, gb: int, call: int):
-  """(seed, global building, call) -> the building's stream (s0, s1): two independent chains, 64 bits -- with one word
-  65,536 buildings had 0.5 colliding pairs per call (generators.hip)."""
+def conv_salt(seed: int, call: int):
+  """What the two stream words take from (seed, call number): the same for every building of a call."""
   h = fmix32((seed & M32) ^ 0x9E3779B9)
   h = fmix32(h ^ ((seed >> 32) & M32))
-  h = fmix32(h ^ (gb & M32))
-  h = fmix32(h ^ ((gb >> 32) & M32))
   h = fmix32(h ^ (call & M32))
   g = fmix32((call & M32) ^ 0x7F4A7C15)
-  g = fmix32(g + ((gb >> 32) & M32))
-  g = fmix32(g + (gb & M32))
-  g = fmix32(g + ((seed >> 32) & M32))
-  g = fmix32(g + (seed & M32))
+  g = fmix32((g + ((seed >> 32) & M32)) & M32)
+  g = fmix32((g + (seed & M32)) & M32)
   return (h, g)
 
 
+def conv_stream(seed: int, gb: int, call: int):
+  """(seed, global building, call) -> the building's stream (s0, s1), 64 bits -- with one word 65,536 buildings had 0.5
+  colliding pairs per call.  One round per word over the building's number modulo 2**32 and a (seed, call) salt: each
+  word is a bijection of the building's number (generators.hip)."""
+  a, b = conv_salt(seed, call)
+  gb &= M32
+  return (fmix32(gb ^ a), fmix32((gb * 0x9E3779B1 + b) & M32))
+
+
 def conv_word(stream, g0: int, k: int) -> int:
-  key = (fmix32(stream[0] ^ ((g0 * 0x9E3779B1) & M32)) + stream[1]) & M32
+  key = ((stream[0] ^ ((g0 * 0x9E3779B1) & M32)) + stream[1]) & M32
   return fmix32((key + k * 0x6C8E9CF5) & M32)
 
 

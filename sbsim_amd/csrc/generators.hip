@@ -125,8 +125,9 @@ constexpr int kConvMaxRoom = 2047; // a cell's index in its room fits 11 bits ne
 // The shuffle's random numbers: a counter-based mixer -- MurmurHash3's 32-bit finaliser over (stream, cell,
 // word number) -- an eighth of Philox4x32-10's instructions (which was a quarter of this kernel's).  stream:
 // (seed, global building, call number) folded once per building into TWO 32-bit words (s0, s1) by two independent
-// chains (round 5, ADVICE r4: one word gave 65,536 buildings 0.5 colliding pairs per call -- whole buildings making
-// identical draws; 64 bits: 1e-10); a cell's key (index g0 in the CALLER's grid) = fmix32(s0 ^ g0 * 0x9E3779B1) + s1,
+// functions (round 5, ADVICE r4: one word gave 65,536 buildings 0.5 colliding pairs per call -- whole buildings making
+// identical draws; now each word is a bijection of the building's number); a cell's key (index g0 in the CALLER's grid) = (s0 ^ g0 * 0x9E3779B1) + s1 (an xor and an
+// add: two buildings' keys agree on every cell only when both words do; a mixer round here cost k_convect 13 %),
 // word k of the cell = fmix32(key + k * 0x6C8E9CF5).  Word 0 -> inclusion (u = (x >> 8) / 2^24,
 // included unless u > p), word 1 -> the swap's time stamp (its top 20 bits; ties by the cell's rank in the
 // room), words 2.. -> partner candidates until one is accepted.  Known answers: tests/test_convection.py;
@@ -136,20 +137,27 @@ __host__ __device__ inline uint32_t fmix32(uint32_t h) {
   return h;
 }
 struct ConvStream { uint32_t s0, s1; };
-__host__ __device__ inline ConvStream conv_stream(uint64_t seed, uint64_t gb, uint32_t call) {
+// What the two words take from (seed, call): the same for every building of a launch -- the compiler hoists both out of
+// the building loop (two scalar registers).
+struct ConvSalt { uint32_t a, b; };
+__host__ __device__ inline ConvSalt conv_salt(uint64_t seed, uint32_t call) {
   uint32_t h = fmix32((uint32_t)seed ^ 0x9E3779B9u);
   h = fmix32(h ^ (uint32_t)(seed >> 32));
-  h = fmix32(h ^ (uint32_t)gb);
-  h = fmix32(h ^ (uint32_t)(gb >> 32));
   h = fmix32(h ^ call);
-  uint32_t g = fmix32(call ^ 0x7F4A7C15u); // the second chain: other constants, the inputs in another order
-  g = fmix32(g + (uint32_t)(gb >> 32));
-  g = fmix32(g + (uint32_t)gb);
+  uint32_t g = fmix32(call ^ 0x7F4A7C15u);
   g = fmix32(g + (uint32_t)(seed >> 32));
   g = fmix32(g + (uint32_t)seed);
-  return ConvStream{h, g};
+  return ConvSalt{h, g};
 }
-__host__ __device__ inline uint32_t conv_key(ConvStream st, uint32_t g0) { return fmix32(st.s0 ^ (g0 * 0x9E3779B1u)) + st.s1; }
+// Per building ONE round per word, side by side, over the building's number modulo 2^32 (sb_convection_attach refuses a
+// batch that reaches beyond): each word is a bijection of it, so no two buildings of a launch share even one.  Every
+// wavefront walks this scalar chain twice per room and building right after a barrier: at five rounds per word it was 13 %
+// of k_convect's time, at five and one 3 %.
+__host__ __device__ inline ConvStream conv_stream(ConvSalt salt, uint32_t gb) {
+  return ConvStream{fmix32(gb ^ salt.a), fmix32(gb * 0x9E3779B1u + salt.b)};
+}
+__host__ __device__ inline ConvStream conv_stream(uint64_t seed, uint64_t gb, uint32_t call) { return conv_stream(conv_salt(seed, call), (uint32_t)gb); }
+__host__ __device__ inline uint32_t conv_key(ConvStream st, uint32_t g0) { return (st.s0 ^ (g0 * 0x9E3779B1u)) + st.s1; }
 __host__ __device__ inline uint32_t conv_word(uint32_t cell_key, uint32_t k) { return fmix32(cell_key + k * 0x6C8E9CF5u); }
 
 // A cell's own swap in LDS, 8 bytes: its time stamp ((top 20 bits of word 1) << 11 | the cell's rank in the
@@ -242,7 +250,7 @@ k_convect(ConvArgs o) {
     if ((int)blockIdx.x < o.B) draw(blockIdx.x, val, oth);
     for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
       double *st = o.temp + (size_t)b * o.stride;
-      const ConvStream stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call);
+      const ConvStream stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call); // (scalar: cheaper formed again than carried from the draw)
       // the records and the list links (LDS atomics)
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
@@ -473,6 +481,8 @@ int sb_convection_attach(sb_handle *h, double p, int32_t distance, uint64_t seed
   }
   if (max_room > kConvMaxRoom)
     return fail(SB_ERR_UNSUPPORTED, "sb_convection_attach: a room has more than 2047 cells");
+  if (first_building < 0 || (unsigned long long)first_building + (unsigned long long)d.B > (1ull << 32))
+    return fail(SB_ERR_INVALID, "sb_convection_attach: the shuffle's streams number buildings modulo 2^32 -- first_building + B reaches beyond");
   if (!wide) // every cell's partner list: the targets of its valid offsets, in table order, as list indices
     for (int z = 0; z < d.Z; ++z) {
       const int c0 = h->h_zone_off[z], n = h->h_zone_off[z + 1] - c0;

@@ -34,7 +34,10 @@ constexpr int kSets = 32;   // entries of the coefficient-set table (at LDS addr
 constexpr int kPF = 8;      // steps between sweep 0's global loads and their use
 constexpr int kQF = 4;      // ... the later sweeps' (A, class word): L1 / L2 hits
 constexpr int kZC = 17;     // columns of the zone-sum scratch per zone (16 lane columns + 1: odd stride)
-constexpr int kS = 4;       // sweeps per pass, at most
+#ifndef SB_STREAM_S
+#define SB_STREAM_S 4
+#endif
+constexpr int kS = SB_STREAM_S; // sweeps per pass, at most
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef const d2 __attribute__((address_space(3))) *lds_d2;
