@@ -239,7 +239,11 @@ k_convect(ConvArgs o) {
               // partner list (the valid offsets in (dx, dy) raster order, as list indices; built by sb_convection_attach)
               const int cnt = (int)(c_a[q] >> 20);
               const int pick = (int)(((unsigned long long)conv_word(key, 2) * (unsigned long long)cnt) >> 32);
+#if defined(SB_CONV_ABL) && (SB_CONV_ABL & 2) // ... without the partner table's gather
+              other = (i + 1 + pick) % n;
+#else
               other = (int)o.partner[(size_t)(c0 + i) * (size_t)o.pw + (size_t)pick];
+#endif
             }
             oth[q] = other;
           }
@@ -248,10 +252,26 @@ k_convect(ConvArgs o) {
     double val[Q], val_n[Q];
     int oth[Q], oth_n[Q];
     if ((int)blockIdx.x < o.B) draw(blockIdx.x, val, oth);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(val[q]), "+v"(oth[q])); // waited for here, not at the loop's top (see the hand-over below)
     for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
       double *st = o.temp + (size_t)b * o.stride;
       const ConvStream stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call); // (scalar: cheaper formed again than carried from the draw)
-      // the records and the list links (LDS atomics)
+      // the records and the list links (LDS atomics): the lane's Q exchanges first, their results read after the time
+      // stamps are formed (an exchange whose result is used under its own branch is waited for there: Q round trips in a row)
+      uint32_t nxt[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int i = tid + q * kConvThreads;
+        nxt[q] = kConvEnd;
+#if defined(SB_CONV_ABL) && (SB_CONV_ABL & 4) // ... without the list exchanges
+        if (i < n && oth[q] != i) nxt[q] = (uint32_t)oth[q];
+#else
+        if (i < n && oth[q] != i) nxt[q] = atomicExch(&head[oth[q]], (uint32_t)i);
+#endif
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(nxt[q])); // (keeps the compiler from sinking the result's first use into the branch)
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
@@ -260,8 +280,7 @@ k_convect(ConvArgs o) {
           const uint32_t key = conv_key(stream, c_a[q] & 0xfffffu);
           uint2 r;
           r.x = other != i ? (((conv_word(key, 1) >> 12) << 11) | (c_b[q] >> 21)) + 1u : 0u; // the time stamp; pad: the cell's rank
-          const uint32_t nxt = other != i ? atomicExch(&head[other], (uint32_t)i) : kConvEnd;
-          r.y = (uint32_t)other | (nxt << 16);
+          r.y = (uint32_t)other | (nxt[q] << 16);
           rec[i] = r;
         }
       }
@@ -274,6 +293,9 @@ k_convect(ConvArgs o) {
         if (i < n) { // follow the value through the swaps that touch the cell it sits in
           int pos = i, to = -1;
           uint32_t t = 0, best = 0xffffffffu;
+#if defined(SB_CONV_ABL) && (SB_CONV_ABL & 1) // developer experiment (tools/build_variant.sh): the kernel without the pointer chase
+          if (o.B > 0) { vout[pos] = val[q]; continue; }
+#endif
           uint2 R = rec[pos];
           uint32_t j = head[pos];
           if (R.x > t) { best = R.x; to = (int)(R.y & 0xffffu); }
@@ -294,20 +316,30 @@ k_convect(ConvArgs o) {
           vout[pos] = val[q];
         }
       }
+      // the next building's draw becomes this one's BEFORE the stores below are issued: the wait for its loads would
+      // otherwise also wait for them (memory operations complete in order) -- an HBM write round trip per room and building
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { val[q] = val_n[q]; oth[q] = oth_n[q]; }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(val[q]), "+v"(oth[q]));
+      }
       __syncthreads();
+      double vo[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int i = tid + q * kConvThreads;
+        vo[q] = vout[i < n ? i : 0];
+      }
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int i = tid + q * kConvThreads;
         if (i < n) {
-          st[c_b[q] & 0x1fffffu] = vout[i];
+          st[c_b[q] & 0x1fffffu] = vo[q];
           head[i] = kConvEnd; // for the next building (the follow phase is over: every lane is past the barrier above)
         }
       }
       __syncthreads();
-      if (more) {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) { val[q] = val_n[q]; oth[q] = oth_n[q]; }
-      }
     }
   }
 }

@@ -82,6 +82,7 @@ struct sb_handle {
   int device = 0, cus = 256;
   bool was_reset = false; // the first sb_reset also sets the construction-time device state
   int steps_since_reset = 0; // how far a reset rewinds the clock (the boiler's action age, scal[19])
+  void *counters_zeroed_on = (void *)(uintptr_t)1; // the stream on which k_pre has zeroed the sweep kernel's draw counters since the last sweep launch (1: none)
   sb_launch_info info{};
   DevBuf<uint8_t> cls, tcls, tcset;
   DevBuf<double> abuf; // step_stream.hip: A = ap*Tprev + g of the buildings in flight

@@ -1473,11 +1473,16 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
   if (phases & SB_PHASE_PRE) {
     hipLaunchKernelGGL(k_pre, dim3(blocks), dim3(16 * kRowsPerBlock), 0, (hipStream_t)stream, d, s, -1);
     SB_HIP(hipGetLastError());
+    h->counters_zeroed_on = stream; // k_pre zeroes the sweep kernel's draw counters
   }
   if (phases & SB_PHASE_SWEEP) {
-    if (!(phases & SB_PHASE_PRE)) // k_pre zeroes the sweep kernel's draw counter; without it in this call:
+    // without a k_pre in front of it ON THIS STREAM since the last sweep launch (phase by phase: bench.py brackets the
+    // sweep with events, so k_pre came with the previous call), the counters are zeroed here -- two more dispatches
+    if (h->counters_zeroed_on != stream) {
       SB_HIP(hipMemsetAsync(d.next_b, 0, sizeof(int), (hipStream_t)stream));
-    if (!(phases & SB_PHASE_PRE) && d.redo_ctr) SB_HIP(hipMemsetAsync(d.redo_ctr, 0, 2 * sizeof(int), (hipStream_t)stream));
+      if (d.redo_ctr) SB_HIP(hipMemsetAsync(d.redo_ctr, 0, 2 * sizeof(int), (hipStream_t)stream));
+    }
+    h->counters_zeroed_on = (void *)(uintptr_t)1; // (no stream)
     const int e = d.reg ? (d.P == 6   ? (d.stream_ms ? launch_sweep_stream_ms(d, h->abuf.p, h->ebuf.p, h->info.waves_per_workgroup, (hipStream_t)stream)
                                                      : launch_sweep_stream(d, h->abuf.p, h->info.waves_per_workgroup, (hipStream_t)stream))
                        : d.P == 5 ? launch_sweep_band(d, (hipStream_t)stream)
