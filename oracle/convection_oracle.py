@@ -11,9 +11,9 @@ the other (the device follows every value through the sequence instead); the dra
 device's: a counter-based mixer -- MurmurHash3's 32-bit finaliser -- over (stream, cell, word number):
 stream = (s0, s1) = conv_stream(seed, global building, call number), word k of the cell with grid index g0 =
 fmix32((s0 ^ g0 * 0x9E3779B1) + s1 + k * 0x6C8E9CF5); word 0 -> inclusion (u = (x >> 8) / 2**24, included
-unless u > p), word 1 -> order (swaps by increasing ((x >> 12) << 11 | the cell's rank in the room)),
-word 2 -> the partner ((x * count) >> 32 among the valid offsets in (dx, dy) raster order); wide windows:
-words 2, 3, .. -> candidates until one is accepted.  The reference draws from Python's
+unless u > p; not formed when p >= 1), word 1 -> order (swaps by increasing ((x >> 12) << 11 | the cell's rank in the
+room)) AND the partner (((x & 0xfff) * count) >> 12 among the valid offsets in (dx, dy) raster order: one mixer round
+for both since round 5); wide windows: words 2, 3, .. -> candidates until one is accepted.  The reference draws from Python's
 global `random`, which no counter-based generator reproduces: what is pinned against the reference is the
 displacement statistics (tests/golden/convection_stats.npz)."""
 from __future__ import annotations
@@ -153,9 +153,10 @@ class ConvectionOracle:
     seq = []
     for i in range(n):
       g0 = int(cells[i])
-      u = (conv_word(stream, g0, 0) >> 8) / 16777216.0
-      if u > self.p:
-        continue
+      if self.p < 1.0:       # (u < 1: with p >= 1 every cell is included and the device does not form word 0)
+        u = (conv_word(stream, g0, 0) >> 8) / 16777216.0
+        if u > self.p:
+          continue
       x, y = divmod(g0, self.W)
 
       def accept(dx, dy, x=x, y=y):
@@ -168,7 +169,7 @@ class ConvectionOracle:
         other = i if hit is None else (int(self.local[hit[1]]) if hit[0] == "cell" else hit[1])
       else:                  # uniform over the valid offsets, in (dx, dy) raster order ((0, 0) always is one)
         cand = [j for j in (accept(dx, dy) for dx, dy in self.off) if j >= 0]
-        other = cand[(conv_word(stream, g0, 2) * len(cand)) >> 32]
+        other = cand[((conv_word(stream, g0, 1) & 0xfff) * len(cand)) >> 12]   # word 1's low 12 bits (its top 20: the time stamp)
       if other != i:
         seq.append(((((conv_word(stream, g0, 1) >> 12) << 11) | int(rank[i])) + 1, i, other))
     seq.sort()

@@ -127,10 +127,12 @@ constexpr int kConvMaxRoom = 2047; // a cell's index in its room fits 11 bits ne
 // (seed, global building, call number) folded once per building into TWO 32-bit words (s0, s1) by two independent
 // functions (round 5, ADVICE r4: one word gave 65,536 buildings 0.5 colliding pairs per call -- whole buildings making
 // identical draws; now each word is a bijection of the building's number); a cell's key (index g0 in the CALLER's grid) = (s0 ^ g0 * 0x9E3779B1) + s1 (an xor and an
-// add: two buildings' keys agree on every cell only when both words do; a mixer round here cost k_convect 13 %),
+// add: two buildings' keys agree on every cell only when both words do),
 // word k of the cell = fmix32(key + k * 0x6C8E9CF5).  Word 0 -> inclusion (u = (x >> 8) / 2^24,
-// included unless u > p), word 1 -> the swap's time stamp (its top 20 bits; ties by the cell's rank in the
-// room), words 2.. -> partner candidates until one is accepted.  Known answers: tests/test_convection.py;
+// included unless u > p; not formed when p >= 1), word 1 -> the swap's time stamp (its top 20 bits; ties by the cell's
+// rank in the room) and, from its low 12 bits, the pick among the cell's partner list (round 5: one mixer round for
+// both -- v_mul_lo_u32 is a quarter-rate instruction and the draws were a third of the kernel's VALU time), words 2.. ->
+// partner candidates of the wide windows until one is accepted.  Known answers: tests/test_convection.py;
 // restated in oracle/convection_oracle.py.  (Occupancy and the whole-room permutation keep Philox.)
 __host__ __device__ inline uint32_t fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -210,9 +212,10 @@ k_convect(ConvArgs o) {
           if (i < n) {
             val[q] = st[c_b[q] & 0x1fffffu];
             const uint32_t key = conv_key(stream, c_a[q] & 0xfffffu);
-            const double u = (double)(conv_word(key, 0) >> 8) * (1.0 / 16777216.0);
+            bool in = true; // :119 (u < 1: with p >= 1 every cell starts a swap and word 0 is not formed)
+            if (o.p < 1.0) in = !((double)(conv_word(key, 0) >> 8) * (1.0 / 16777216.0) > o.p);
             int other = i;
-            if (!(u > o.p) && o.wide) { // :119, a window too large for an offset table: the partner by rejection --
+            if (in && o.wide) { // :119, a window too large for an offset table: the partner by rejection --
               // uniform over the reference's candidate list (:122-131; the cell itself is a candidate)
               const int span = 2 * o.wide_r + 1, W0 = o.transposed ? o.H : o.W; // W0: row length of the caller's grid
               if (n < span * span) { // the room has fewer cells than the window's box: a cell of the room (by rank), kept when inside the disc
@@ -235,10 +238,11 @@ k_convect(ConvArgs o) {
                   }
                 }
               }
-            } else if (!(u > o.p)) { // :119: uniform over the room's cells inside the offset window -- the cell's own
-              // partner list (the valid offsets in (dx, dy) raster order, as list indices; built by sb_convection_attach)
+            } else if (in) { // :119: uniform over the room's cells inside the offset window -- the cell's own
+              // partner list (the valid offsets in (dx, dy) raster order, as list indices; built by sb_convection_attach);
+              // the pick from the low 12 bits of the word whose top 20 are the time stamp (at most 64 offsets)
               const int cnt = (int)(c_a[q] >> 20);
-              const int pick = (int)(((unsigned long long)conv_word(key, 2) * (unsigned long long)cnt) >> 32);
+              const int pick = (int)(((conv_word(key, 1) & 0xfffu) * (uint32_t)cnt) >> 12);
 #if defined(SB_CONV_ABL) && (SB_CONV_ABL & 2) // ... without the partner table's gather
               other = (i + 1 + pick) % n;
 #else
