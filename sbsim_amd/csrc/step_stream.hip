@@ -15,16 +15,28 @@
 // lower neighbours come by DPP from the neighbouring lanes.  Everything a lane reads from global
 // memory was written by its own wavefront; the rows at a seam between two wavefronts (row 64 w - 1's
 // new values, row 64 w's old ones) travel through LDS under a progress counter per wavefront.
-// Registers: ~100 -- several buildings per CU, the memory latency is hidden by occupancy, not by
-// unrolling.  Bound: HBM / L2 bandwidth (28 B per cell and sweep), not instruction issue.
+// Bound: HBM / L2 bandwidth (28 B per cell and sweep) -- in practice memory LATENCY times occupancy: a wavefront has kPF
+// steps of loads in flight, so what counts is wavefronts per CU (round 5: 128 registers per lane -- 132-144 B of them spilled
+// -- for four wavefronts per SIMD and a zone-sum scratch of 8 instead of 16 columns so that three workgroups of a
+// 299 x 401 plan share a CU instead of two: 1.0e11 -> 1.35e11 cell-sweeps/s at 3,072 buildings).
 #include "sb_device.h"
 
 namespace sb {
 namespace {
 
 constexpr int kSets = 32;   // entries of the coefficient-set table (at LDS address 0)
-constexpr int kPF = 8;      // steps between a global load and its use
-constexpr int kZC = 17;     // columns of the zone-sum scratch per zone (16 lane columns + 1: odd stride)
+// (developer knobs of tools/build_variant.sh: prefetch depth, zone-sum columns, wavefronts per SIMD asked of the compiler)
+#ifndef SB_STREAM_PF
+#define SB_STREAM_PF 8
+#endif
+#ifndef SB_STREAM_ZC
+#define SB_STREAM_ZC 9
+#endif
+#ifndef SB_STREAM_WPE
+#define SB_STREAM_WPE 4
+#endif
+constexpr int kPF = SB_STREAM_PF; // steps between a global load and its use
+constexpr int kZC = SB_STREAM_ZC; // columns of the zone-sum scratch per zone (16 lane columns + 1: odd stride)
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef const d2 __attribute__((address_space(3))) *lds_d2;
@@ -42,7 +54,9 @@ extern __shared__ __attribute__((aligned(16))) double lds[];
 // LDS (doubles): [tabc 4 kSets][tapg 2 ts] | r_seam: up [W][NS + 8], dn [W][NS + 8] | r_xchg: progress
 // [16] ints, max|delta| parts [16] | r_A: zone sums [Z + 1][kZC]
 template <int WMAX> // wavefronts per workgroup <= WMAX: the register budget follows the launch bound
-__global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf) {
+__global__ void __launch_bounds__(64 * WMAX)
+__attribute__((amdgpu_waves_per_eu(WMAX == 2 ? 3 : SB_STREAM_WPE)))
+k_sweep_stream(Dev a, double *Abuf) {
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int W = (int)(blockDim.x >> 6), NS = a.NR, RS = a.RS, NSP = NS + 8;
   double *tabc = lds;
@@ -64,8 +78,12 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
   const sb_params &p = a.p;
   const int row = wv * 64 + lane;
   const int NW = NS + 63;                                          // steps of a wavefront per sweep
-  const unsigned *cmap = (const unsigned *)a.cmapS + (size_t)wv * NW * 64 + lane; // [W][NW][64]: set offset | class * 16 << 16
-  const unsigned short *zmap = (const unsigned short *)a.zmapS + (size_t)wv * NS * 64 + lane; // [W][NS][64]: zone (Z: none)
+  // global addresses as a UNIFORM base (scalar registers; the slot / step part is scalar arithmetic) + a 32-bit per-lane
+  // byte offset: the loads and stores take the `saddr + voffset` form, no 64-bit address pair per stream in vector registers
+  const unsigned *cmap_u = (const unsigned *)a.cmapS + (size_t)wv * NW * 64; // [W][NW][64]: set offset | class * 16 << 16
+  const unsigned short *zmap_u = (const unsigned short *)a.zmapS + (size_t)wv * NS * 64; // [W][NS][64]: zone (Z: none)
+  const unsigned lane4 = (unsigned)lane * 4u, lane2 = (unsigned)lane * 2u, row8 = (unsigned)row * 8u;
+  auto cmap_at = [&](int step) { return *(const unsigned *)((const char *)(cmap_u + (size_t)step * 64) + lane4); };
   lds_vi prog_mine = (lds_vi)(unsigned)(size_t)(__attribute__((address_space(3))) int *)(prog + wv);
   lds_vi prog_prev = (lds_vi)(unsigned)(size_t)(__attribute__((address_space(3))) int *)(prog + (wv > 0 ? wv - 1 : 0));
   const double *up_prev = up + (size_t)(wv > 0 ? wv - 1 : 0) * NSP;  // lane 0's upper neighbours
@@ -79,8 +97,10 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
 
   for (int b = blockIdx.x, bn = 0; b < a.B; b = bn) {
     if (threadIdx.x == 0) misc[0] = a.sweep_wgs + atomicAdd(a.next_b, 1);
-    double *E = a.temp + (size_t)b * a.state_doubles + row;   // [NS][RS], this lane's column of rows
-    double *Ab = Abuf + (size_t)blockIdx.x * a.state_doubles + row; // one A grid per resident workgroup
+    double *Eu = a.temp + (size_t)b * a.state_doubles;          // [NS][RS]; this lane: + row
+    double *Au = Abuf + (size_t)blockIdx.x * a.state_doubles;   // one A grid per resident workgroup
+    auto E_at = [&](int slot) -> double & { return *(double *)((char *)(Eu + (size_t)slot * RS) + row8); };
+    auto A_at = [&](int slot) -> double & { return *(double *)((char *)(Au + (size_t)slot * RS) + row8); };
     const double t_now = a.bld[b].t_now;
     const double ring_lo = a.scal[(size_t)b * kNScal + 16], ring_hi = a.scal[(size_t)b * kNScal + 17];
     // exterior-space cells outside the trim box all become t_now in the first sweep
@@ -95,10 +115,10 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
     for (int s = 0; s < NS; ++s) {
       int t = s - lane;           // the lane's column at slot s
       if (t < 0) t += NS;
-      const unsigned cw = cmap[(size_t)(t + lane) * 64]; // step t + lane: column t
+      const unsigned cw = cmap_u[(size_t)(t + lane) * 64 + lane]; // step t + lane: column t
       const d2 pg = *(const d2 *)((const char *)tapg + (cw >> 16));
-      const double v = E[(size_t)s * RS];
-      Ab[(size_t)s * RS] = fma(pg.x, v, pg.y);
+      const double v = E_at(s);
+      A_at(s) = fma(pg.x, v, pg.y);
       if (lane == 0) dn_mine[s] = v; // lane 0: column s sits in slot s
     }
     int n_sweeps = 0, converged = 0;
@@ -114,12 +134,12 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
 #pragma unroll
       for (int k = 0; k < kPF; ++k) { // steps 0 .. kPF-1
         const int s0 = k % NS, s1 = (k + 1) % NS;
-        ring_e[k] = E[(size_t)s1 * RS];
-        ring_a[k] = Ab[(size_t)s0 * RS];
-        ring_c[k] = cmap[(size_t)k * 64];
+        ring_e[k] = E_at(s1);
+        ring_a[k] = A_at(s0);
+        ring_c[k] = cmap_at(k);
       }
       sl = kPF % NS;
-      double old = E[0];      // the lane's own old value at step 0 (slot 0)
+      double old = E_at(0);   // the lane's own old value at step 0 (slot 0)
       double nv = 0.0;        // the lane's previous result (left-hand neighbour)
       for (int t0 = 0; t0 < NW; t0 += kPF) {
         // the wavefront above must have published row 63's new values for the columns lane 0 reaches here
@@ -141,9 +161,9 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
             const int tn = t + kPF;
             int s1 = sl + 1;
             if (s1 >= NS) s1 -= NS;
-            ring_e[k] = E[(size_t)s1 * RS];
-            ring_a[k] = Ab[(size_t)sl * RS];
-            ring_c[k] = cmap[(size_t)min(tn, NW - 1) * 64];
+            ring_e[k] = E_at(s1);
+            ring_a[k] = A_at(sl);
+            ring_c[k] = cmap_at(min(tn, NW - 1));
             sl = s1;
           }
           const lds_d2 st = (lds_d2)(cw & 0xffffu);
@@ -162,7 +182,7 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
           // a lane outside its row stores the slot's unchanged content back (`old` is that content)
           const double out = act ? res : old;
           acc = fmax(acc, fabs(out - old));
-          E[(size_t)s * RS] = out;
+          E_at(s) = out;
           *((act && pub_seam) ? pub_seam + t : pub_dummy) = out;
           nv = act ? res : nv;
           old = eR;
@@ -186,9 +206,9 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
     // zone sums and the grid sum of the lane's row (row Z of the scratch: cells outside every zone)
     __syncthreads();
     for (int s = 0; s < NS; ++s) {
-      const double v = E[(size_t)s * RS];
-      const int z = (int)zmap[(size_t)s * 64];
-      __hip_atomic_fetch_add(zs + z * kZC + (lane & 15), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const double v = E_at(s);
+      const int z = (int)*(const unsigned short *)((const char *)(zmap_u + (size_t)s * 64) + lane2);
+      __hip_atomic_fetch_add(zs + z * kZC + (lane & (kZC - 2)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     if (wv == 0) {
@@ -197,7 +217,7 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream(Dev a, double *Abuf)
         const int zz = zb + lane;
         double v = 0.0;
         if (zz <= a.Z)
-          for (int k = 0; k < 16; ++k) v += zs[zz * kZC + k];
+          for (int k = 0; k < kZC - 1; ++k) v += zs[zz * kZC + k];
         if (zz < a.Z) a.zsum[(size_t)b * a.Z + zz] = v;
         gacc += v;
       }

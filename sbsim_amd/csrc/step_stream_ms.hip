@@ -33,7 +33,7 @@ namespace {
 constexpr int kSets = 32;   // entries of the coefficient-set table (at LDS address 0)
 constexpr int kPF = 8;      // steps between sweep 0's global loads and their use
 constexpr int kQF = 4;      // ... the later sweeps' (A, class word): L1 / L2 hits
-constexpr int kZC = 17;     // columns of the zone-sum scratch per zone (16 lane columns + 1: odd stride)
+constexpr int kZC = 9;      // columns of the zone-sum scratch per zone (8 lane columns + 1: odd stride) -- step_stream.hip's (the planner asks it)
 #ifndef SB_STREAM_S
 #define SB_STREAM_S 4
 #endif
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream_ms(Dev a, double *Ab
     for (int s = 0; s < NS; ++s) {
       const double v = Eout[(size_t)s * RS + row];
       const int z = (int)zmap[(size_t)s * 64];
-      __hip_atomic_fetch_add(zs + z * kZC + (lane & 15), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(zs + z * kZC + (lane & (kZC - 2)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     if (wv == 0) {
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64 * WMAX) k_sweep_stream_ms(Dev a, double *Ab
         const int zz = zb + lane;
         double v = 0.0;
         if (zz <= a.Z)
-          for (int k = 0; k < 16; ++k) v += zs[zz * kZC + k];
+          for (int k = 0; k < kZC - 1; ++k) v += zs[zz * kZC + k];
         if (zz < a.Z) a.zsum[(size_t)b * a.Z + zz] = v;
         gacc += v;
       }
@@ -380,6 +380,7 @@ int dispatch(const Dev &d, double *abuf, double *ebuf, int waves, hipStream_t st
 
 } // namespace
 
+static_assert(kZC == 9, "sweep_stream_zone_columns() of step_stream.hip");
 int sweep_stream_ms_sweeps() { return kS; }
 // LDS doubles of the seam rows (kS sweeps + the input grid's) and of the exchange area, W wavefronts, NS slots
 int sweep_stream_ms_seam_doubles(int NS, int W) { return (kS + 1) * W * (NS + 8); }

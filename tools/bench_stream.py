@@ -14,6 +14,8 @@ from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan  # 
 dev = torch.device("cuda", 0)
 K = int(os.environ.get("K", "6"))
 CASES = [("299x401 / 126 zones", (14, 9), (20, 43), int(os.environ.get("B_BIG", "1024")), False),
+         ("299x401 / 126 zones", (14, 9), (20, 43), 3 * int(os.environ.get("B_BIG", "1024")), False),   # a multiple of the resident workgroups (768)
+         ("150x118 / 35 zones, forced", (7, 5), (20, 22), 4096, True),
          ("R9 68x98 / 9 zones, forced", (3, 3), (20, 30), 16384, True),
          ("R9 68x98 / 9 zones, k_sweep_roll", (3, 3), (20, 30), 16384, False)]
 for name, rooms, shape, B, force in CASES:
