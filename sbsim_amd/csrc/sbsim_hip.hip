@@ -19,6 +19,13 @@
 
 #include "sb_host.h"
 
+// step_stream.hip's overlapped-sweeps kernel (Dev::stream_ms == 2; declared here: sb_device.h is part of the traffic profile's source hash)
+namespace sb {
+int launch_sweep_stream_roll(const Dev &d, double *abuf, double *ebuf, int waves, hipStream_t stream);
+int prepare_sweep_stream_roll(const Dev &d, int waves);
+int sweep_stream_roll_xchg_extra_doubles();
+} // namespace sb
+
 using namespace sb;
 
 namespace {
@@ -618,13 +625,17 @@ bool plan_stream(const sb_plan_desc *plan, RegPlan &r, std::string &why) {
     r.stream_ms = env_flag("SBSIM_STREAM_MS") && ms_off * 8 <= kLdsCap && 64 * NWV - Hs >= sweep_stream_ms_sweeps() - 1 &&
                   NWV <= 8; // (its 256 registers: two wavefronts per SIMD, workgroups of at most 8)
   }
-  r.r_seam = off; off += r.stream_ms ? sweep_stream_ms_seam_doubles(NS, NWV) : 2 * NWV * (NS + 8);
-  r.r_xchg = off; off += r.stream_ms ? sweep_stream_ms_xchg_doubles(NWV) : 32 + 64 * NWV; // progress, max|delta| parts, the publish scratch
+  r.r_seam = off; off += r.stream_ms == 1 ? sweep_stream_ms_seam_doubles(NS, NWV) : 2 * NWV * (NS + 8);
+  // overlapped sweeps (step_stream.hip's k_sweep_stream_roll, round 5) -- OPT-IN, SBSIM_STREAM_ROLL=1: stream_ms == 2.  Exact
+  // (tests/test_gpu_parity.py), 9 % faster on R9 forced here, 9 % SLOWER on the 299 x 401 plan it was written for: with three
+  // workgroups per CU another workgroup already fills a wavefront's idle steps, and the sweep started in vain is traffic
+  if (!r.stream_ms && env_flag("SBSIM_STREAM_ROLL")) r.stream_ms = 2;
+  r.r_xchg = off; off += r.stream_ms == 1 ? sweep_stream_ms_xchg_doubles(NWV) : 32 + 64 * NWV + (r.stream_ms == 2 ? sweep_stream_roll_xchg_extra_doubles() : 0); // progress, max|delta| parts, the publish scratch
   r.r_A = off; off += (Z + 1) * ZC;
   r.lds_bytes = off * 8;
   if (r.lds_bytes > kLdsCap) { why = "the seam rows (rows / 64 x columns x 16 bytes) and the zone sums do not fit in 160 KiB of LDS"; r.csetab.clear(); return false; }
   // workgroups per CU: LDS, threads (2,048 per CU) and registers (<= 128 per lane: four wavefronts per SIMD)
-  r.wg_per_cu = std::max(1, std::min({kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule), 32 / NWV, (r.stream_ms ? 8 : 16) / NWV}));
+  r.wg_per_cu = std::max(1, std::min({kLdsCap / ((r.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule), 32 / NWV, (r.stream_ms == 1 ? 8 : 16) / NWV}));
   r.NR = NS; r.P = 6; r.RS = RS; r.Ws = Ws; r.r0 = x0; r.c0 = y0; r.n_ring = N - Hs * Ws;
   r.T = 0; r.ts = ts; r.AS = 0;
   r.state_doubles = NS * RS;
@@ -1393,7 +1404,7 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     if (alloc_zero(h->dbg, 16 + (d.dbg_timeline ? 2048 : 0)) == SB_OK) d.dbg = h->dbg.p;
   }
 
-  const int e = d.reg ? (d.P == 6 ? (d.stream_ms ? prepare_sweep_stream_ms(d, h->info.waves_per_workgroup) : prepare_sweep_stream(d, h->info.waves_per_workgroup)) : d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
+  const int e = d.reg ? (d.P == 6 ? (d.stream_ms == 1 ? prepare_sweep_stream_ms(d, h->info.waves_per_workgroup) : d.stream_ms == 2 ? prepare_sweep_stream_roll(d, h->info.waves_per_workgroup) : prepare_sweep_stream(d, h->info.waves_per_workgroup)) : d.P == 5 ? prepare_sweep_band(d) : d.P == 4 ? prepare_sweep_two(d) : d.P == 3 ? prepare_sweep_roll(d) : prepare_sweep_reg(d))
                       : prepare_sweep_lds((size_t)h->info.lds_bytes_per_workgroup);
   if (e != (int)hipSuccess) {
     delete h;
@@ -1483,7 +1494,8 @@ int sb_step_phases(sb_handle *h, const float *actions_dev, const sb_step_in *in,
       if (d.redo_ctr) SB_HIP(hipMemsetAsync(d.redo_ctr, 0, 2 * sizeof(int), (hipStream_t)stream));
     }
     h->counters_zeroed_on = (void *)(uintptr_t)1; // (no stream)
-    const int e = d.reg ? (d.P == 6   ? (d.stream_ms ? launch_sweep_stream_ms(d, h->abuf.p, h->ebuf.p, h->info.waves_per_workgroup, (hipStream_t)stream)
+    const int e = d.reg ? (d.P == 6   ? (d.stream_ms == 1 ? launch_sweep_stream_ms(d, h->abuf.p, h->ebuf.p, h->info.waves_per_workgroup, (hipStream_t)stream)
+                                   : d.stream_ms == 2 ? launch_sweep_stream_roll(d, h->abuf.p, h->ebuf.p, h->info.waves_per_workgroup, (hipStream_t)stream)
                                                      : launch_sweep_stream(d, h->abuf.p, h->info.waves_per_workgroup, (hipStream_t)stream))
                        : d.P == 5 ? launch_sweep_band(d, (hipStream_t)stream)
                        : d.P == 4 ? launch_sweep_two(d, (hipStream_t)stream)

@@ -911,19 +911,21 @@ def _check_plan_against_oracle(file_plan, n_zones, orientation, path, monkeypatc
     ((2, 2), (5, 9), "rows", 1),        # 15 x 23: one wavefront, no seam
     ((10, 2), (19, 40), "rows", 4),     # 203 x 85 inside the ring: four wavefronts
 ])
-@pytest.mark.parametrize("multi_sweep", [False, True])
+@pytest.mark.parametrize("multi_sweep", [False, True, "overlapped"])
 def test_streaming_kernel_against_oracle(rooms, room_shape, orientation, waves, multi_sweep, monkeypatch):
   """step_stream.hip (the grid stays in global memory, up to 16 wavefronts per building, seam rows through
   LDS) forced onto floor plans the other kernels own: sweep counts EQUAL, temperatures within 1e-8 K of
   the CPU-oracle twins."""
   from sbsim_amd.floorplan import rectangular_floor_plan
-  if multi_sweep:   # step_stream_ms.hip: up to four sweeps per pass over the grid (parallelogram tiling; opt-in)
+  if multi_sweep == "overlapped":   # step_stream.hip's k_sweep_stream_roll: sweeps overlapped on two grids that take turns (opt-in)
+    monkeypatch.setenv("SBSIM_STREAM_ROLL", "1")
+  elif multi_sweep:   # step_stream_ms.hip: up to four sweeps per pass over the grid (parallelogram tiling; opt-in)
     monkeypatch.setenv("SBSIM_STREAM_MS", "1")
   _check_plan_against_oracle(rectangular_floor_plan(rooms, room_shape), rooms[0] * rooms[1], orientation, 2, monkeypatch,
                              expect_kernel=6, expect_waves=waves)
 
 
-@pytest.mark.parametrize("multi_sweep", [False, True])
+@pytest.mark.parametrize("multi_sweep", [False, True, "overlapped"])
 def test_floor_plan_beyond_one_cu_against_oracle(multi_sweep, monkeypatch):
   """A floor plan no CU can hold (missing #1): 299 x 401 control volumes, 126 zones -- 0.96 MB of
   float64 state per building.  The library picks the streaming kernel by itself (five wavefronts per
@@ -931,7 +933,9 @@ def test_floor_plan_beyond_one_cu_against_oracle(multi_sweep, monkeypatch):
   from sbsim_amd.floorplan import rectangular_floor_plan
   fp = rectangular_floor_plan((14, 9), (20, 43))
   assert fp.shape == (299, 401)
-  if multi_sweep:
+  if multi_sweep == "overlapped":
+    monkeypatch.setenv("SBSIM_STREAM_ROLL", "1")
+  elif multi_sweep:
     monkeypatch.setenv("SBSIM_STREAM_MS", "1")
   _check_plan_against_oracle(fp, 126, "rows", 2, monkeypatch, expect_kernel=6, expect_waves=5, B=2, T=3)
 
