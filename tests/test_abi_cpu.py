@@ -104,7 +104,8 @@ def test_plan_info_picks_the_step_kernel_without_a_gpu():
 
 def test_plan_info_for_plans_beyond_one_cu_and_the_opt_in_kernel(monkeypatch):
   """Host-only planning of this round's kernels: a 299 x 401 plan (0.96 MB of state) goes to the streaming
-  kernel on five wavefronts, its LDS (seam rows + zone sums) leaves room for two workgroups per CU; a plan
+  kernel on five wavefronts, its LDS (seam rows + zone sums) leaves room for three workgroups per CU (round 5: an
+  8-column zone-sum scratch and 128 registers per lane); a plan
   of more than 1,024 rows in one orientation still runs in the other and is SB_ERR_TOO_LARGE when both
   are too long; SBSIM_BAND_PATH=1 puts a 107-row plan on two wavefronts (step_band.hip), two buildings per CU."""
   import numpy as np
@@ -114,8 +115,8 @@ def test_plan_info_for_plans_beyond_one_cu_and_the_opt_in_kernel(monkeypatch):
   rc, info = _plan_info(big, n_obs=397, n_buildings=4096)
   assert rc == 0 and info["path"] == 2 and info["kernel"] == 6 and info["waves_per_building"] == 5
   assert info["sweep_steps"] == 64 * 4 + 400 + 63
-  assert 2 * ((info["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
-  assert info["workgroups"] == 512 and info["algorithmic_bytes_per_env_step"] == 8 * 299 * 401 + 24 * 126 + 8 + 4 * 397 + 44
+  assert 3 * ((info["lds_bytes_per_workgroup"] + 1279) // 1280 * 1280) <= 160 * 1024
+  assert info["workgroups"] == 768 and info["algorithmic_bytes_per_env_step"] == 8 * 299 * 401 + 24 * 126 + 8 + 4 * 397 + 44
   tall = FloorPlan.from_file_input(rectangular_floor_plan((1, 1), (1119, 20)), Materials.sb1(), 10.0, 300.0)   # 1,125 x 26
   rc, t_rows = _plan_info(tall, n_obs=22)
   assert rc == -4 and b"1,024 rows" in _ffi.load().sb_last_error()      # SB_ERR_TOO_LARGE in this orientation ...
