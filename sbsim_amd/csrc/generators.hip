@@ -260,6 +260,22 @@ k_convect(ConvArgs o) {
     for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(val[q]), "+v"(oth[q])); // waited for here, not at the loop's top (see the hand-over below)
     for (int b = blockIdx.x; b < o.B; b += gridDim.x) {
       double *st = o.temp + (size_t)b * o.stride;
+#if defined(SB_CONV_ABL) && (SB_CONV_ABL & 8) // ... nothing but the loads and the stores (no barrier, no LDS): the memory pattern's own time
+      {
+        const bool more8 = b + (int)gridDim.x < o.B;
+        if (more8) draw(b + (int)gridDim.x, val_n, oth_n);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int i = tid + q * kConvThreads;
+          if (i < n) st[c_b[q] & 0x1fffffu] = val[q] + (double)(oth[q] - i) * 1e-300;
+        }
+        if (more8) {
+#pragma unroll
+          for (int q = 0; q < Q; ++q) { val[q] = val_n[q]; oth[q] = oth_n[q]; }
+        }
+        continue;
+      }
+#endif
       const ConvStream stream = conv_stream(o.seed, (uint64_t)(o.first_building + b), o.call); // (scalar: cheaper formed again than carried from the draw)
       // the records and the list links (LDS atomics): the lane's Q exchanges first, their results read after the time
       // stamps are formed (an exchange whose result is used under its own branch is waited for there: Q round trips in a row)
