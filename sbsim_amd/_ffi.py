@@ -131,6 +131,10 @@ def load():
     raise SbsimError(
         f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
         "(hipcc --offload-arch=gfx950).  sbsim_amd has no CPU fallback.")
+  # torch FIRST: it ships its own HIP runtime, and the device memory this library works on is torch's.  Loaded before torch,
+  # the library binds the system's libamdhip64 instead -- a second runtime in the process that sees no device
+  # (`sb_create: no HIP device visible` after __graft_entry__.build() and smoke() in one process)
+  import torch  # noqa: F401
   L = C.CDLL(LIB_PATH)
   vp = C.c_void_p
   L.sb_abi_version.restype = C.c_int

@@ -19,6 +19,7 @@ def _declared():
 
 def test_library_builds_and_exports_every_declared_symbol():
   path = build.build()
+  import torch  # noqa: F401  (before the library: see _ffi.load)
   lib = C.CDLL(path)
   names = _declared()
   assert set(names) == set(_ffi.EXPORTS), (names, _ffi.EXPORTS)
