@@ -101,6 +101,8 @@ struct Dev {
   int nslots;              // chunk slots (barriers) per sweep
   float pred_haste;        // mode 4: when may the next sweep overlap (step_two.hip may_roll)
   float pred_slack;
+  int two_skip;            // mode 4: rolling periods far from the step's last sweep run without max|delta| (step_two_impl.h, Hist; the planner checks the coefficients)
+  float skip_kappa;        // mode 4: the next measurement is due this fraction of the predicted sweeps-to-go ahead
   int pred_first;          // mode 4: a step's first block rolls pred_first - 1 periods unseen when the previous step took >= 6 sweeps (1: never)
   int lds_reg_bytes;       // dynamic LDS per workgroup (one building; mode 3: four)
   int wg_per_cu;

@@ -1225,6 +1225,19 @@ int sb_create(const sb_plan_desc *plan, const sb_params *params, const sb_obs_la
     d.pred_haste = 1.0f; d.pred_slack = 1.0f; // measured (tools/bench_two_rows.py); developer knobs: speed only,
     if (const char *e = getenv("SBSIM_DEBUG_PRED_HASTE")) d.pred_haste = (float)atof(e); // never the result
     if (const char *e = getenv("SBSIM_DEBUG_PRED_SLACK")) d.pred_slack = (float)atof(e);
+    // measure-free rolling periods (step_two_impl.h, Hist): only when max|delta| provably never grows from one sweep to
+    // the next -- every neighbour coefficient >= 0 and every class's four summing to <= 1 (then ||(I - L)^-1 U||_inf <= 1)
+    d.two_skip = 0; d.skip_kappa = 0.9f;
+    if (r.P == 4 && !env_flag("SBSIM_TWO_NO_SKIP")) {
+      bool mono = true;
+      for (int c = 0; c < plan->n_classes; ++c) {
+        double sum = 0.0;
+        for (int j = 0; j < 4; ++j) { mono = mono && plan->class_coef[c * 8 + j] >= 0.0; sum += plan->class_coef[c * 8 + j]; }
+        mono = mono && sum <= 1.0;
+      }
+      d.two_skip = mono ? 1 : 0;
+    }
+    if (const char *e = getenv("SBSIM_DEBUG_SKIP_KAPPA")) d.skip_kappa = (float)atof(e); // speed only
     d.pred_first = r.P == 5 ? 2 : 3; // step_two.hip: periods a first block rolls unseen (+ 1); step_band.hip: its first block aims at the previous step's count - (pred_first - 2) (measured: 2 beats 3 and 4 by 2-4 %; 1: it never rolls unseen)
     if (const char *e = getenv("SBSIM_DEBUG_PRED_FIRST")) d.pred_first = std::max(1, atoi(e));
     SB_TRY(upload(h->zone_cells_l, plan->zone_cells, (size_t)plan->zone_off[plan->Z]));

@@ -43,7 +43,10 @@ namespace {
 using namespace sweep;
 using namespace two;
 
-constexpr int kWA = 3;     // class words (four steps each) are read this many words ahead
+#ifndef SB_TWO_WA
+#define SB_TWO_WA 3
+#endif
+constexpr int kWA = SB_TWO_WA; // class words (four steps each) are read this many words ahead
 constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in the hand-over
 
 // Slots of A kept in LDS (template parameter NL).  The others -- the last NR - NL slots of every period --
@@ -60,7 +63,11 @@ constexpr int kZA = 8;     // zone-offset words (four slots each) read ahead in 
 #define SB_TWO_PD 1
 #endif
 constexpr int kPD = SB_TWO_PD, kPB = kPD == 1 ? 2 : 4; // a step's LDS reads are issued this many steps ahead, into a ring of kPB buffers (NR % kPB == 0)
-constexpr int kAD = 6, kAR = 8; // global slots of A: read this many steps ahead, into a ring of this many register pairs
+#ifndef SB_TWO_AD
+#define SB_TWO_AD 6
+#define SB_TWO_AR 8
+#endif
+constexpr int kAD = SB_TWO_AD, kAR = SB_TWO_AR; // global slots of A: read this many steps ahead, into a ring of this many register pairs
 
 template <bool SYM>
 struct StepBuf {         // LDS values of one step
@@ -273,8 +280,11 @@ __device__ __forceinline__ void load_step(StepBuf<SYM> &p, Ctx &x, const d2 (&ri
 //   63 <= S < NR       all 64 lanes are in the same sweep
 //   NR <= S < NR + 63  ROLL: lanes <= S - NR are in the next sweep; else they have finished (masked)
 // Association order of the four products as in step_lds.hip / step_reg.hip / step_roll.hip.
-template <int NR, int S, bool TAIL, bool ROLL, bool SYM, int NV>
+// MEAS = false (rolling periods only): no |delta| at all -- a period of a sweep that is known not to be the step's last
+// (measure-free periods, below).
+template <int NR, int S, bool TAIL, bool ROLL, bool SYM, bool MEAS, int NV>
 __device__ __forceinline__ void step(Grid<NR, NV> &g, Win &w, const StepBuf<SYM> &p, Acc &acc) {
+  static_assert(MEAS || ROLL, "only rolling periods run without max|delta|");
   constexpr int r = S % NR, rp = (S + 1) % NR;
   const double na = g.template get<2 * rp>(), nb = g.template get<2 * rp + 1>(); // old values one column ahead
   const double U = wave_shift1<0x13c, false>(w.pb, 0.0); // lane 0 sees the last row's latest value (times bU = 0; SYM: lane 0's upper cell is a pad row)
@@ -302,7 +312,9 @@ __device__ __forceinline__ void step(Grid<NR, NV> &g, Win &w, const StepBuf<SYM>
     sr = wave_shift1<0x138, true>(sr, U);
   }
   double sa = nva, sb = nvb;
-  if constexpr (ROLL && S >= NR) {
+  if constexpr (!MEAS) {
+    // nothing to measure: every lane keeps its new values (ROLL: no lane is masked)
+  } else if constexpr (ROLL && S >= NR) {
     constexpr int J = S - NR;
     // the lane's two cells are in the same sweep: one |d| for both, + in the lanes still in sweep k,
     // - in the lanes already in sweep k+1
@@ -326,7 +338,7 @@ __device__ __forceinline__ void step(Grid<NR, NV> &g, Win &w, const StepBuf<SYM>
     acc.cur = fmax(acc.cur, fabs(sa - w.ca));
     acc.cur = fmax(acc.cur, fabs(sb - w.cb));
   }
-  asm volatile("" : "+v"(acc.cur)); // here, not after the sweep (the maxima would keep every delta of the sweep alive)
+  if constexpr (MEAS) asm volatile("" : "+v"(acc.cur)); // here, not after the sweep (the maxima would keep every delta of the sweep alive)
   g.template set<2 * r>(sa);
   g.template set<2 * r + 1>(sb);
   w.pa = sa;
@@ -338,7 +350,7 @@ __device__ __forceinline__ void step(Grid<NR, NV> &g, Win &w, const StepBuf<SYM>
 // Steps S .. S1 - 1; the LDS reads of step S + 1 are issued before the arithmetic of step S (the
 // caller issues those of the first step; a period's last step reads nothing ahead).
 // last_step: the step at which the last lane that owns a row finishes (NR + lanes - 2).
-template <int NR, int S, int S1, bool TAIL, bool ROLL, int NL, bool SYM, int NV>
+template <int NR, int S, int S1, bool TAIL, bool ROLL, int NL, bool SYM, bool MEAS, int NV>
 __device__ __forceinline__ void run_steps(Grid<NR, NV> &g, Win &w, d2 (&ring)[kAR], StepBuf<SYM> (&pb)[kPB], Ctx &x,
                                           Acc &acc, int last_step) {
   if constexpr (S < S1) {
@@ -347,21 +359,49 @@ __device__ __forceinline__ void run_steps(Grid<NR, NV> &g, Win &w, d2 (&ring)[kA
     prefetch_a<NR, S, NL>(ring, x);
     if constexpr (S + kPD < NR + 63) load_step<NR, S + kPD, TAIL, NL, SYM>(pb[(S + kPD) % kPB], x, ring);
     __builtin_amdgcn_sched_barrier(0);
-    step<NR, S, TAIL, ROLL, SYM>(g, w, pb[S % kPB], acc);
+    step<NR, S, TAIL, ROLL, SYM, MEAS>(g, w, pb[S % kPB], acc);
     __builtin_amdgcn_sched_barrier(0);
-    run_steps<NR, S + 1, S1, TAIL, ROLL, NL, SYM>(g, w, ring, pb, x, acc, last_step);
+    run_steps<NR, S + 1, S1, TAIL, ROLL, NL, SYM, MEAS>(g, w, ring, pb, x, acc, last_step);
   }
 }
 
+// The step's last two MEASURED sweeps, for the prediction: sweep sa with max|delta| da, then sweep sb with db.
+//
+// Measure-free periods.  Within an env step the sweeps are a stationary iteration x' = L x' + U x + c (the
+// coefficients and A are fixed), so delta_{k+1} = G delta_k with G = (I - L)^-1 U; every coefficient is >= 0 and
+// every cell's four sum to <= 1 (the planner checks both: Dev::two_skip), hence ||G||_inf <= 1 and max|delta| never
+// grows from one sweep to the next.  So a sweep whose max|delta| is above the threshold proves that every EARLIER
+// sweep's was, too, and the reference's answer -- the first sweep at or below the threshold, simulator.py:360 -- only
+// needs measurements close to the end: far from it (by the same extrapolation that decides whether a period may
+// roll) the rolling periods run WITHOUT the seven |delta| instructions per step.  A measuring period behind a
+// measure-free one sees only the late part of its sweep: a lower bound, which still proves "above".  Anything
+// else -- a first measurement that is already at or below the threshold (within 1e-9 K above it: rounding) -- and
+// the block is run again from the stored grid, measuring from the last proven sweep on.  Speed only: the iterates
+// and the sweep count are those of the plain schedule.
+struct Hist {
+  float da, db;
+  int sa, sb, n; // n: measurements so far (0, 1, 2 = two or more)
+  __device__ __forceinline__ void push(int s, float d) {
+    da = db; sa = sb;
+    db = d; sb = s;
+    n = n < 2 ? n + 1 : 2;
+  }
+};
+
 // May the sweep after the last one run overlapped, i.e. is it safe to assume that it will NOT be the
-// step's last?  d1 -> d0: max|delta| of the last two sweeps.  Extrapolates the last decay (`haste` x
-// as fast, in the exponent) to the threshold: r sweeps to go; the next sweep may overlap if r > slack
+// step's last?  da -> db: max|delta| of the last two measured sweeps (sb - sa sweeps apart).  Extrapolates that
+// decay (`haste` x as fast, in the exponent) to the threshold: r sweeps to go; the next sweep may overlap if r > slack
 // (Dev::pred_haste, Dev::pred_slack: 1.0, 1.0 -- the decay slows down as the fast modes die out, so
 // the extrapolation errs on the short side).  Speed only: a wrong yes is found out and repaired.
-__device__ __forceinline__ bool may_roll(float d1, float d0, float thr, float haste, float slack) {
-  if (!(d0 > thr)) return false;
-  if (!(d0 < d1)) return true; // not decaying
-  return __log2f(thr / d0) < slack * haste * __log2f(d0 / d1); // r = log(thr/d0) / (haste log(d0/d1)) > slack; both logarithms are negative
+__device__ __forceinline__ bool may_roll(const Hist &h, float thr, float haste, float slack) {
+  if (!(h.db > thr)) return false;
+  if (!(h.db < h.da)) return true; // not decaying
+  // r = gap log(thr/db) / (haste log(db/da)) > slack; both logarithms are negative
+  return __log2f(thr / h.db) * (float)(h.sb - h.sa) < slack * haste * __log2f(h.db / h.da);
+}
+__device__ __forceinline__ float sweeps_to_go(const Hist &h, float thr) { // (two measurements, the last one above the threshold)
+  if (!(h.db < h.da)) return 1.0f; // not decaying: nothing to extrapolate -- keep measuring
+  return fminf(__log2f(thr / h.db) * (float)(h.sb - h.sa) / __log2f(h.db / h.da), 1000.0f);
 }
 
 // A = ap*Tprev + g for the lane's cells (e = Tprev before the first sweep): the pair of slot j to
@@ -583,8 +623,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         return md;
       };
       const float thr = (float)p.conv_threshold;
+      const double thr_far = p.conv_threshold + 1e-9; // a measured max|delta| above this proves the unmeasured sweeps before it (Hist, above)
       const int prev_sweeps = __builtin_amdgcn_readfirstlane(a.nsw[b] & 0xffff); // of this building's previous step
-      float d1 = 0.0f, d0 = 0.0f; // max |delta| of the last two sweeps
+      const bool skip_on = a.two_skip != 0;
+      Hist hist{0.0f, 0.0f, 0, 0, 0}; // the step's last two measured sweeps
+      int proven = 0;                 // every sweep up to this one is known to have max|delta| > threshold
 #pragma nounroll
       for (;;) { // simulator.py:348-368
         // a block: ramp-up, rolling periods while the next sweep cannot be the last one, final period.
@@ -592,7 +635,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         // decay) if the building's previous step took six sweeps or more -- a hint; a step that
         // converges sooner is found out and run again from Tprev.
         const int n0 = n_sweeps;
-        int roll0 = n0 >= 2 ? (int)may_roll(d1, d0, thr, a.pred_haste, a.pred_slack) : (int)(n0 == 0 && prev_sweeps >= 6 && a.pred_first > 1);
+        int roll0 = hist.n >= 2 ? (int)may_roll(hist, thr, a.pred_haste, a.pred_slack) : (int)(n0 == 0 && prev_sweeps >= 6 && a.pred_first > 1);
         roll0 = __builtin_amdgcn_readfirstlane(roll0) && n0 + 2 <= p.iter_limit;
         SB_COUNT(roll0 ? 13 : 14); // developer aid: blocks / single sweeps
         if (roll0 && n0 > 0) { // the grid as of n0 sweeps, should the block overrun (before any sweep: Tprev is still there)
@@ -602,10 +645,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           for (int t = 0; t < kTailMax; ++t)
             if (TAIL && t < a.T && tactive) *(d2 *)(Ttail + (unsigned)opaque(tc0 * 8) + (unsigned)(t * NR) * 8u) = d2{tv[t][0], tv[t][1]};
         }
+        const Hist hist0 = hist; // as of the stored grid
+        const int proven0 = proven;
         double md = 0.0;
-        int m = 0; // > 0: the block is being run again and ends with its m-th sweep
+        int m = 0;         // > 0: the block is being run again and ends with its m-th sweep
+        int all_meas = 0;  // the block is being run again because a measurement came too late to say WHICH sweep was the
+                           // last one: this time every period measures
 #pragma nounroll
-        for (;;) { // at most twice
+        for (;;) { // at most three times
           __builtin_amdgcn_sched_barrier(0);
 #ifdef SB_PHASE_STAMPS
 #define SB_STAMP2(i) do { if (a.dbg && blockIdx.x == 0 && iter == 3 && n_sweeps == 4 && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -621,40 +668,100 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           w.pb = g.template get<NE - 1>();
           w.ca = g.template get<0>();
           w.cb = g.template get<1>();
-          run_steps<NR, 0, 63, TAIL, false, kNL, SYM>(g, w, ring, pb, x, acc, last_step); // ramp-up; reads ahead for step 63
-          bool overrun = false;
+          run_steps<NR, 0, 63, TAIL, false, kNL, SYM, true>(g, w, ring, pb, x, acc, last_step); // ramp-up (always measured); reads ahead for step 63
+          bool again = false;
+          int next_meas = 0; // the next measurement is due at this sweep
+          int pending = 0;   // the last measurement saw a part of its sweep and proved nothing
+          // Every turn of this loop: the measure-free periods that are due (none, close to the end), then ONE period that
+          // measures -- so a block never ends behind a period that did not measure, and the two period bodies follow each
+          // other (as the two arms of a branch inside one loop they cost 1.2 KB of scratch per lane).
 #pragma nounroll
-          for (int q = 1;; ++q) {
+          for (;;) {
+            const int s = n_sweeps + 1, q = s - n0; // the sweep the next period would finish (it starts sweep s + 1)
             int go;
             if (m > 0) go = q < m;
             else if (!roll0 || n_sweeps + 2 > p.iter_limit) go = 0; // the final period must fit under the limit
-            else if (q == 1) go = 1;
-            else go = n_sweeps >= 2 ? (int)may_roll(d1, d0, thr, a.pred_haste, a.pred_slack) : (int)(q < a.pred_first);
-            if (!__builtin_amdgcn_readfirstlane(go)) break;
+            else if (q == 1 || pending) go = 1;
+            else go = hist.n >= 2 ? (int)may_roll(hist, thr, a.pred_haste, a.pred_slack) : (int)(q < a.pred_first);
+            if (!__builtin_amdgcn_readfirstlane(go)) {
+              if (pending) { // (the iteration limit, behind a measurement that proved nothing: every period measures, then)
+                again = true;
+                all_meas = 1;
+              }
+              break;
+            }
+            int nskip = 0; // measure-free periods first: they finish sweeps s .. s + nskip - 1
+            if (m > 0) nskip = (n0 + m - 1) - s; // the final period needs the early part of its sweep: period m - 1 measures
+            else if (skip_on && !all_meas && hist.n >= 2) nskip = min(next_meas, p.iter_limit - 1) - s;
+            nskip = __builtin_amdgcn_readfirstlane(nskip);
+#pragma nounroll
+            for (int i = 0; i < nskip; ++i) {
+              SB_COUNT(6);
+              asm volatile("" : "+v"(x.arow), "+v"(x.seam)); // (as below)
+              __builtin_amdgcn_sched_barrier(0);
+              run_steps<NR, 63, NR + 63, TAIL, true, kNL, SYM, false>(g, w, ring, pb, x, acc, last_step);
+              __builtin_amdgcn_sched_barrier(0);
+              (void)sweep_end(); // the tail rows' pass; nothing was measured
+              static_for<0, kPD>([&](auto kc) { load_step<NR, 63 + decltype(kc)::value, TAIL, kNL, SYM>(pb[(63 + decltype(kc)::value) % kPB], x, ring); });
+            }
+            const bool whole = nskip <= 0; // else a lower bound: the early part of the sweep went unmeasured
+            if (!whole) {
+              acc.cur = 0.0;
+              acc.neg = 0.0;
+              acc.sg = lane == 0 ? (int)0x80000000 : 0;
+            }
+            SB_COUNT(7);
             // A does not change during the sweeps: unless its address does (as far as the compiler can
             // tell), every ds_read of the period is hoisted out of this loop -- into scratch
             asm volatile("" : "+v"(x.arow), "+v"(x.seam));
             __builtin_amdgcn_sched_barrier(0);
-            run_steps<NR, 63, NR + 63, TAIL, true, kNL, SYM>(g, w, ring, pb, x, acc, last_step);
+            run_steps<NR, 63, NR + 63, TAIL, true, kNL, SYM, true>(g, w, ring, pb, x, acc, last_step);
             __builtin_amdgcn_sched_barrier(0);
             md = sweep_end();
-            d1 = d0;
-            d0 = (float)md;
-            if (md <= p.conv_threshold) { // sweep n0 + q was the last one, and the next has been started
-              overrun = true;
-              m = q;
-              break;
+            // the started sweep's part so far, formed HERE: behind the decisions below hipcc 7.2 negates it on the
+            // path of a block that is being run again only (the other path kept the finished sweep's maximum)
+            double started = -acc.neg;
+            asm volatile("" : "+v"(started));
+            if (m == 0) {
+              const int sm = n_sweeps; // the sweep just measured
+              pending = 0;
+              if (md > p.conv_threshold && (proven == sm - 1 || md > thr_far)) {
+                // sweep sm was not the last one -- nor was any sweep before it: max|delta| does not grow from one
+                // sweep to the next (Hist)
+                proven = sm;
+                if (whole) { // (a part's maximum proves, but does not predict: the next period measures the whole of its sweep)
+                  hist.push(sm, (float)md);
+                  if (hist.n >= 2) {
+                    const int ahead = (int)(a.skip_kappa * sweeps_to_go(hist, thr)) - 1;
+                    next_meas = sm + (ahead > 1 ? ahead : 1);
+                  }
+                }
+              } else if (!whole) {
+                pending = 1; // at or below the threshold, but of a part of the sweep: the next sweep's maximum will tell
+              } else if (md <= p.conv_threshold && proven == sm - 1) { // sweep sm was the last one, and the next has been started
+                again = true;
+                m = sm - n0;
+                break;
+              } else { // at or below the threshold (or within 1e-9 K above it) behind sweeps that went unmeasured: too late to
+                       // say which sweep was the last one
+                SB_COUNT(8);
+                again = true;
+                all_meas = 1;
+                break;
+              }
             }
-            acc.cur = -acc.neg;
+            acc.cur = started;
             acc.neg = 0.0;
             acc.sg = lane == 0 ? (int)0x80000000 : 0;
             // after the tail scan: lane 63's lower neighbour is new
             static_for<0, kPD>([&](auto kc) { load_step<NR, 63 + decltype(kc)::value, TAIL, kNL, SYM>(pb[(63 + decltype(kc)::value) % kPB], x, ring); });
           }
-          if (!overrun) break;
-          // back to the stored grid; this time the block ends with sweep n0 + m
+          if (!again) break;
+          // back to the stored grid; this time the block ends with sweep n0 + m (or every period measures)
           SB_COUNT(15);
           n_sweeps = n0;
+          hist = hist0;
+          proven = proven0;
           {
             const unsigned lo8 = (unsigned)opaque(lane * 8);
             static_for<0, NE>([&](auto Jc) { g.template load_async<decltype(Jc)::value>(tp, lo8); });
@@ -670,15 +777,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
-        run_steps<NR, 63, NR + 63, TAIL, false, kNL, SYM>(g, w, ring, pb, x, acc, last_step); // the block's last sweep
+        run_steps<NR, 63, NR + 63, TAIL, false, kNL, SYM, true>(g, w, ring, pb, x, acc, last_step); // the block's last sweep
         __builtin_amdgcn_sched_barrier(0);
         first_words<NR>(x, lane); // the next block's first class words
         SB_STAMP2(11);
-        md = sweep_end();
+        md = sweep_end(); // whole: the period before it measured (or was the ramp-up)
         SB_STAMP2(12);
-        d1 = d0;
-        d0 = (float)md;
+        hist.push(n_sweeps, (float)md);
         converged = md <= p.conv_threshold;
+        if (!converged) proven = n_sweeps;
         if (converged || n_sweeps >= p.iter_limit) break;
       }
     }

@@ -23,6 +23,7 @@ and metrics writing are out of scope.
 from __future__ import annotations
 
 import collections
+import copy
 import ctypes as C
 import dataclasses
 import datetime as dt
@@ -702,7 +703,10 @@ class MixedBatchedEnvironment:
   mixed observation is ``[B_total, max width]``; a building's row holds its class's fields first (the layout
   of ``BatchedEnvironment.field_names`` of its class, ``self.envs[k].field_names``) and zeros after
   ``self.observation_widths[k]``; ``self.class_of_building`` ([B_total] int32 in HBM) and ``self.slices``
-  say which class a building belongs to.  Every keyword argument goes to each class's ``BatchedEnvironment``.
+  say which class a building belongs to.  Every keyword argument goes to each class's ``BatchedEnvironment``;
+  a seeded per-building generator among them (``convection_simulator``, randomized ``occupancy``) gets its
+  ``first_building`` moved to the class's first GLOBAL building on this rank, so every building of the mixed batch
+  draws from its own stream whatever the sharding.
 
   Several GPUs (``rank``, ``world``): the counts in ``classes`` are the GLOBAL ones and every class
   is block-partitioned over the ranks on its own (``sbsim_amd.distributed.class_shard_ranges``), so each rank
@@ -724,14 +728,26 @@ class MixedBatchedEnvironment:
     self.rank, self.world = int(rank), int(world)
     self.class_totals = [int(n) for _, n in classes]
     self.class_ranges = _sd.class_shard_ranges(self.class_totals, self.rank, self.world)
-    if any(hi <= lo_ for lo_, hi in self.class_ranges):
-      raise ValueError(f"rank {rank} of {world} would hold no building of some class: {self.class_ranges}")
+    # the same test on every rank (a rank that raised alone would leave the others in their first collective)
+    if any(n < self.world for n in self.class_totals):
+      raise ValueError(f"every class needs at least one building per rank: totals {self.class_totals}, {world} ranks")
     classes = [(plan, hi - lo_) for (plan, _), (lo_, hi) in zip(classes, self.class_ranges)]
     lo = 0
-    for plan, n in classes:
+    for k, (plan, n) in enumerate(classes):
+      # per-building generators (convection shuffle, randomized occupancy) draw from streams keyed by the GLOBAL
+      # building index: class k's building i is building sum(totals[:k]) + i of the whole mixed batch, on whichever
+      # rank it lives -- so the draws do not depend on the sharding, and no two buildings share a stream
+      first = sum(self.class_totals[:k]) + self.class_ranges[k][0]
+      kw = dict(env_kwargs)
+      for key in ("convection_simulator", "occupancy"):
+        gen = kw.get(key)
+        if gen is not None and hasattr(gen, "first_building"):
+          gen = copy.copy(gen)
+          gen.first_building = int(gen.first_building) + first
+          kw[key] = gen
       stream = torch.cuda.Stream(device=self.tdev)
       with torch.cuda.stream(stream):
-        env = BatchedEnvironment(plan, int(n), device=self.device, **env_kwargs)
+        env = BatchedEnvironment(plan, int(n), device=self.device, **kw)
       self.envs.append(env)
       self.streams.append(stream)
       self.slices.append((lo, lo + env.batch_size))

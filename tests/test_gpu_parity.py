@@ -803,6 +803,24 @@ def test_block_kernels_tail_rows_and_overrun_blocks(haste, slack, kern, monkeypa
                              expect_kernel=kern)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("rooms,shape,zones", [((14, 9), (8, 7), 126), ((8, 5), (12, 14), 40)])
+@pytest.mark.parametrize("kappa", ["off", "0.9", "2.5", "40"])
+def test_two_rows_kernel_measure_free_periods(kappa, rooms, shape, zones, monkeypatch):
+  """step_two_impl.h (round 6): rolling periods far from a step's last sweep run without max|delta| (max|delta| never
+  grows from one sweep to the next, so one measurement above the threshold proves every sweep before it).  With the
+  next measurement placed far too late (kappa 2.5 / 40: the first measurement behind a measure-free stretch is
+  already at or below the threshold) the block is run again with every period measuring; switched off
+  (SBSIM_TWO_NO_SKIP=1) the kernel is round 5's.  Sweep counts EQUAL to the oracle's and grids within 1e-8 K either
+  way: the schedule decides the speed, never the result."""
+  from sbsim_amd.floorplan import rectangular_floor_plan
+  if kappa == "off":
+    monkeypatch.setenv("SBSIM_TWO_NO_SKIP", "1")
+  else:
+    monkeypatch.setenv("SBSIM_DEBUG_SKIP_KAPPA", kappa)
+  _check_plan_against_oracle(rectangular_floor_plan(rooms, shape), zones, "auto", 1, monkeypatch, expect_kernel=4, T=16)
+
+
 @pytest.mark.parametrize("kern", [5, 4])
 @pytest.mark.parametrize("limit", [1, 2, 3, 7, 12])
 def test_block_kernels_iteration_limit(limit, kern, monkeypatch):
@@ -1007,6 +1025,49 @@ def _run_bench(args, timeout=600):
   lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
   assert len(lines) == 1, out.stdout[-2000:]
   return json.loads(lines[0])
+
+
+def test_mixed_environment_gives_every_building_its_own_generator_stream():
+  """a seeded convection shuffle handed to MixedBatchedEnvironment must not repeat its streams from class
+  to class or from rank to rank -- class k's building i draws as building sum(totals[:k]) + (its index inside the
+  class) of the whole mixed batch.  Two classes of the SAME plan: class 1 equals a BatchedEnvironment whose generator
+  starts at building 4, and differs from class 0; rank 1 of 2 continues where rank 0 stopped."""
+  _need_gpu()
+  from sbsim_amd import host_inputs
+  from sbsim_amd.environment import BatchedEnvironment, MixedBatchedEnvironment
+  from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan
+  plan = FloorPlan.from_file_input(rectangular_floor_plan((2, 2), (8, 9)), Materials.sb1(), 10.0, 300.0)
+  conv = lambda first=0: host_inputs.StochasticConvectionSimulator(1.0, 3, 77, first_building=first)
+  kw = dict(holiday_calendar=None)
+  a = torch.zeros((4, 2), device="cuda")
+
+  def grids(env, n=6):
+    env.reset()
+    for _ in range(n):
+      env.step(a[:env.batch_size])
+    return env.sim.temps()
+
+  menv = MixedBatchedEnvironment([(plan, 4), (plan, 4)], convection_simulator=conv(), **kw)
+  menv.reset()
+  for _ in range(6):
+    menv.step(torch.zeros((8, 2), device="cuda"))
+  g0, g1 = menv.envs[0].sim.temps(), menv.envs[1].sim.temps()
+  assert not torch.equal(g0, g1)
+  ref0 = BatchedEnvironment(plan, 4, convection_simulator=conv(0), **kw)
+  ref1 = BatchedEnvironment(plan, 4, convection_simulator=conv(4), **kw)
+  assert torch.equal(g0, grids(ref0)) and torch.equal(g1, grids(ref1))
+  menv.close()
+  # rank 1 of 2: class 0's buildings 2..3 and class 1's buildings 2..3 = global buildings 2..3 and 6..7
+  m1 = MixedBatchedEnvironment([(plan, 4), (plan, 4)], rank=1, world=2, convection_simulator=conv(), **kw)
+  m1.reset()
+  for _ in range(6):
+    m1.step(torch.zeros((4, 2), device="cuda"))
+  assert torch.equal(m1.envs[0].sim.temps(), g0[2:]) and torch.equal(m1.envs[1].sim.temps(), g1[2:])
+  with pytest.raises(ValueError, match="at least one building per rank"):
+    MixedBatchedEnvironment([(plan, 4), (plan, 1)], rank=0, world=2, **kw)
+  m1.close()
+  ref0.close()
+  ref1.close()
 
 
 def test_mixed_environment_equals_its_classes_stepped_alone():

@@ -50,7 +50,8 @@ for name, rooms, shape in bench.MIXED_CLASSES[1:]:
     _ffi.check(_ffi.load().sb_debug_phase_cycles(env.sim._h, buf), "dbg")
     d = list(buf)
     line += f", blocks {d[13] / (B * (K + 4)):.2f} + single sweeps {d[14] / (B * (K + 4)):.2f} per building-step"
-    line += f", spins w0 {d[6] / (B * (K + 4)):.0f} w1 {d[7] / (B * (K + 4)):.0f} md {d[8] / (B * (K + 4)):.0f} per building-step"
+    # step_two_impl.h: measure-free / measuring rolling periods, blocks run again because a measurement came too late (step_band.hip: spins)
+    line += f", periods measure-free {d[6] / (B * (K + 4)):.2f} measuring {d[7] / (B * (K + 4)):.2f} late measurements {d[8] / (B * (K + 4)):.4f} per building-step"
     line += f", overrun blocks {d[15]} ({d[15] / (B * (K + 4)):.3f} per building-step), stamps {[d[i] - d[0] for i in (1, 2, 3, 4, 5)]}, period {d[11] - d[10]} end+decision+next period {d[12] - d[11]}, n_sweeps {d[9]}"
   print(line)
   env.close() if hasattr(env, "close") else None
