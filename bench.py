@@ -25,8 +25,12 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
+# the CPU baseline's OpenMP threads (oracle/sb_oracle_batch.c): pinned, neighbours first -- before any OpenMP runtime starts
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "threads")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -39,7 +43,9 @@ from sbsim_amd.floorplan import FloorPlan, Materials, rectangular_floor_plan  # 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
-KERNEL_SOURCES = ("sbsim_amd/csrc/step_roll.hip", "sbsim_amd/csrc/sweep_common.h", "sbsim_amd/csrc/sb_device.h")
+# what decides the sweep kernel's memory behaviour: its sources, the planner (LDS layout, tables) and the build flags
+KERNEL_SOURCES = ("sbsim_amd/csrc/step_roll.hip", "sbsim_amd/csrc/sweep_common.h", "sbsim_amd/csrc/sb_device.h",
+                  "sbsim_amd/csrc/sbsim_hip.hip", "sbsim_amd/build.py")
 
 
 def kernel_source_sha256() -> str:
@@ -80,7 +86,7 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
       eco_lo=c.eco_temp_window[0], eco_hi=c.eco_temp_window[1],
       blr_heating_rate=c.boiler_heating_rate, blr_cooling_rate=c.boiler_cooling_rate, ahu_has_weather=1)
   threads = max(1, min(orc.lib().sbo_max_threads(), os.cpu_count() or 1))
-  nb = min(init.shape[0], max(8, 16 * threads))   # >= 16 buildings per thread and step: ms of work between barriers
+  nb = min(init.shape[0], max(8, 64 * threads))   # >= 64 buildings per thread and step: tens of ms of work between two barriers
   batch = orc.OracleBatch(oplan, oprm, init[:nb])
   lo, hi = c.action_ranges
   ts = env._start_timestamp
@@ -129,23 +135,37 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
   env._prev_thermostat_ts = None
   zones = oplan.Z
   n_timed = len(step_times)
-  # median step time: a sub-second sample on a shared 128-thread host is noisy in the mean
-  value = nb * zones / float(np.median(step_times))
+  # the rate is the MEAN step's (what a user of the CPU path gets); the median step's rate next to it says how much of
+  # the difference is the host (other tenants' threads stretch single steps)
+  mean_s, median_s = float(np.mean(step_times)), float(np.median(step_times))
+  value = nb * zones / mean_s
+  single = nb * zones / float(min(single_times)) if single_times else None
   grids = np.stack([b.grid() for b in batch.buildings])
   try:
     affinity = len(os.sched_getaffinity(0))
   except (AttributeError, OSError):
     affinity = None
-  return dict(value=value, unit="zone-updates/s", cores=threads, kind="port",
+  try:
+    cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+  except (OSError, StopIteration):
+    cpu_model = None
+  load1 = os.getloadavg()[0]
+  # a host with other work on it: its load before the sample was already more than a few CPUs' worth
+  quiet = load0 < 0.05 * (os.cpu_count() or 1) + 1.0
+  return dict(value=value, unit="zone-updates/s", cores=threads, kind="port", cpu_model=cpu_model,
+              value_from_median_step=nb * zones / median_s, step_ms_mean=mean_s * 1e3, step_ms_median=median_s * 1e3,
+              # value / (one thread's rate x threads): what OpenMP over buildings makes of the host's cores
+              parallel_efficiency=(value / (single * threads) if single else None), host_quiet=quiet,
               # what really ran: CPU seconds the process burnt inside the timed steps / their wall time (= threads that were
               # actually on a core: a shared host gives fewer than it advertises), the CPUs this process may use, the host's load
               threads_effective=cpu_s / t_cpu if t_cpu > 0 else None, cpus_allowed=affinity, host_cpus=os.cpu_count(),
-              host_loadavg_1min_before_after=[load0, os.getloadavg()[0]],
+              host_loadavg_1min_before_after=[load0, load1], omp={k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY")},
               sample=f"{nb} buildings x {n_timed} steps of the bench workload after {warmup} untimed "
                      f"warm-up steps ({sweeps / (nb * n_timed):.2f} sweeps/step), oracle/sb_oracle.c "
-                     f"with OpenMP over buildings, {t_cpu:.2f} s wall x {threads} threads; rate from the median step",
-              env_steps_per_s=nb / float(np.median(step_times)),
-              single_thread_value=(nb * zones / float(min(single_times)) if single_times else None)), grids, n_steps, nb
+                     f"with OpenMP over buildings (schedule(dynamic, 1)), {t_cpu:.2f} s wall x {threads} threads; rate from the MEAN step"
+                     + ("" if quiet else "; the host was NOT quiet (load average before the sample above)"),
+              env_steps_per_s=nb / mean_s,
+              single_thread_value=single), grids, n_steps, nb
 
 
 def launch_ranks_if_needed(args) -> None:
