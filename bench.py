@@ -25,12 +25,8 @@ import subprocess
 import sys
 import time
 
-# the CPU baseline's OpenMP threads (oracle/sb_oracle_batch.c): pinned, neighbours first -- before any OpenMP runtime starts
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "threads")
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+import numpy as np
+import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -86,7 +82,19 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
       eco_lo=c.eco_temp_window[0], eco_hi=c.eco_temp_window[1],
       blr_heating_rate=c.boiler_heating_rate, blr_cooling_rate=c.boiler_cooling_rate, ahu_has_weather=1)
   threads = max(1, min(orc.lib().sbo_max_threads(), os.cpu_count() or 1))
-  nb = min(init.shape[0], max(8, 64 * threads))   # >= 64 buildings per thread and step: tens of ms of work between two barriers
+  quota = None   # a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota): more threads than that only get throttled
+  try:
+    q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+    quota = None if q == "max" else float(q) / float(per)
+  except (OSError, ValueError):
+    try:
+      q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+      quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) if q > 0 else None
+    except (OSError, ValueError):
+      pass
+  if quota is not None:
+    threads = max(1, min(threads, int(quota + 0.5)))
+  nb = min(init.shape[0], max(8, 32 * threads))   # >= 32 buildings per thread and step: tens of ms of work between two barriers
   batch = orc.OracleBatch(oplan, oprm, init[:nb])
   lo, hi = c.action_ranges
   ts = env._start_timestamp
@@ -159,7 +167,11 @@ def cpu_baseline(env: BatchedEnvironment, plan: FloorPlan, init: np.ndarray, act
               # what really ran: CPU seconds the process burnt inside the timed steps / their wall time (= threads that were
               # actually on a core: a shared host gives fewer than it advertises), the CPUs this process may use, the host's load
               threads_effective=cpu_s / t_cpu if t_cpu > 0 else None, cpus_allowed=affinity, host_cpus=os.cpu_count(),
-              host_loadavg_1min_before_after=[load0, load1], omp={k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY")},
+              cgroup_cpu_quota=quota,   # CPUs' worth of time the container may use: the thread count above is capped to it
+              host_loadavg_1min_before_after=[load0, load1],
+              # (OMP_PROC_BIND=close / OMP_PLACES=threads was tried on the round's shared 256-CPU hosts: 5 x SLOWER -- the pinned
+              # threads land on CPUs other tenants keep busy; unbound, the kernel moves them)
+              omp={k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY")},
               sample=f"{nb} buildings x {n_timed} steps of the bench workload after {warmup} untimed "
                      f"warm-up steps ({sweeps / (nb * n_timed):.2f} sweeps/step), oracle/sb_oracle.c "
                      f"with OpenMP over buildings (schedule(dynamic, 1)), {t_cpu:.2f} s wall x {threads} threads; rate from the MEAN step"
@@ -517,6 +529,15 @@ def policy_config(args, ctx=None, emit=True):
   mine = time.perf_counter() - t0
   per_rank = sd.all_ranks(mine / K * 1e3, dev)
   elapsed = sd.max_over_ranks(mine, dev)
+  # after the timed region: eight more steps with HIP events around the sweep kernel (BatchedSimulator.sweep_events) --
+  # the kernel's own time in this regime (a smooth policy: ~2 sweeps per step) and the HBM rate it sustains there
+  env.sim.sweep_events = []
+  for _ in range(8):
+    ts = step_once(obs)
+    obs = ts.observation
+  torch.cuda.synchronize(dev)
+  sweep_ms = float(np.mean([a.elapsed_time(b) for a, b in env.sim.sweep_events]))
+  env.sim.sweep_events = None
   gather_ms, n_gathered = 0.0, B
   if distributed:
     g0 = time.perf_counter()
@@ -545,6 +566,9 @@ def policy_config(args, ctx=None, emit=True):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?"),
+                     "sweep_kernel_ms": sweep_ms,   # eight profiled steps after the timed region
+                     "hbm_TBps_real": li["state_bytes_per_env_step"] * B / (sweep_ms * 1e-3) / 1e12,   # the state, read once and written once
+                     "sweep_kernel_frac": li["algorithmic_bytes_per_env_step"] * B / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "note": "over the whole env step including the policy network (a smooth policy needs fewer "
                              "Gauss-Seidel sweeps per step than random actions)"}}
     if emit:
@@ -553,6 +577,55 @@ def policy_config(args, ctx=None, emit=True):
   if emit and distributed:
     dist.destroy_process_group()
   return result
+
+
+LARGE_PLANS = [("299x401 / 126 zones", (14, 9), (20, 43), 1536, 6, "k_sweep_stream"),   # beyond one CU: the grid streams from HBM / L2
+               ("205x89 / 40 zones", (10, 4), (19, 20), 4096, 5, "k_sweep_band")]          # 203 rows inside the ring: four wavefronts per building
+
+
+def large_plans_leg(dev, n_twins: int = 8, steps: int = 6, warmup: int = 2) -> dict:
+  """The kernels no BASELINE config runs -- k_sweep_stream (floor plans beyond one CU: the SB1 blobs' scale, which the
+  reference's repository no longer ships) and k_sweep_band (131-258 rows) -- on one synthetic plan each through
+  `BatchedEnvironment.step()`: rate, sweep-kernel time and `n_twins` oracle twins (sweep counts EQUAL, zone temperatures
+  within 1e-8 K), so that the driver's record has a parity + rate line for them too.  Bounded: a few seconds."""
+  out = {}
+  for name, rooms, shape, B, kern_id, kern in LARGE_PLANS:
+    plan = FloorPlan.from_file_input(rectangular_floor_plan(rooms, shape), Materials.sb1(), 10.0, 300.0)
+    env = BatchedEnvironment(plan, B, device=dev.index, holiday_calendar="us", collect_info=True, num_days_in_episode=3)
+    H, Wd = plan.shape
+    rs = np.random.RandomState(7)
+    t_init = np.clip(294.0 + rs.randn(B), 285.0, 305.0)
+    env.reset()
+    env.sim.reset(temps=torch.tensor(t_init, dtype=torch.float64, device=dev)[:, None].expand(B, H * Wd).contiguous())
+    check = TwinCheck(env, plan, t_init[:n_twins], n_twins)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    acts = torch.rand((warmup + steps, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+    env.sim.sweep_events = []
+    sweeps = []
+    torch.cuda.synchronize(dev)
+    for t in range(warmup + steps):
+      if t == warmup:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+      si = env.make_step_in(env.current_simulation_timestamp)
+      env.step(acts[t])
+      check.record(si, acts[t])
+      sweeps.append(env.info[:, 4].mean())
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    ms = float(np.mean([a.elapsed_time(b) for a, b in env.sim.sweep_events[warmup:]]))
+    li = env.sim.launch_info
+    sw = float(torch.stack(sweeps[warmup:]).mean())
+    out[name] = {"kernel": _ffi.SWEEP_KERNELS.get(li.get("kernel", -1), "?"), "expected_kernel": kern, "buildings": B, "grid": [H, Wd],
+                 "zones": env.sim.Z, "steps": steps, "warmup": warmup, "ms_per_step": wall / steps * 1e3,
+                 "zone_updates_per_s": B * env.sim.Z * steps / wall, "sweep_kernel_ms": ms, "mean_sweeps_per_env_step": sw,
+                 "cell_sweeps_per_s": B * H * Wd * sw / (ms * 1e-3),
+                 "roofline_frac": li["algorithmic_bytes_per_env_step"] * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "waves_per_building": li["waves_per_building"], "parity_vs_oracle": check.verify()}
+    assert li.get("kernel") == kern_id, (name, li)
+    env.close()
+  return out
 
 
 def also_legs(args, dev, pf) -> dict:
@@ -578,12 +651,22 @@ def also_legs(args, dev, pf) -> dict:
                           for k, v in r["config"]["classes"].items()}
       else:
         leg["kernel"] = r["roofline"]["kernel"]
+        leg["sweep_kernel_ms"] = r["roofline"].get("sweep_kernel_ms")
+        leg["hbm_TBps_real"] = r["roofline"].get("hbm_TBps_real")
+        leg["mean_sweeps_per_env_step"] = r["config"].get("mean_sweeps_per_env_step_last")
         leg["parity_vs_oracle"] = r["config"].get("parity_vs_oracle")
         leg["mean_return_per_step"] = r["config"]["mean_return_per_step"]
     except Exception as exc:   # noqa: BLE001 -- the headline line must still be printed
       leg = {"error": f"{type(exc).__name__}: {exc}", "trace": traceback.format_exc()[-600:]}
     leg["leg_wall_s"] = time.perf_counter() - t0
     out[name] = leg
+  t0 = time.perf_counter()
+  try:   # the kernels beyond the BASELINE configs' plans: one bounded parity + rate line each
+    leg = large_plans_leg(dev)
+  except Exception as exc:   # noqa: BLE001
+    leg = {"error": f"{type(exc).__name__}: {exc}", "trace": traceback.format_exc()[-600:]}
+  leg["leg_wall_s"] = time.perf_counter() - t0
+  out["large_plans"] = leg
   return out
 
 
@@ -712,6 +795,35 @@ def main() -> None:
     n_gathered = int(all_returns.numel())
     assert n_gathered == world * B
 
+  steady = None
+  if world == 1 and not args.no_also and not args.through_env_api and args.iteration_limit == 100:
+    # the same loop in its steady state: the timed window above is a transient -- steps W .. W + K after
+    # a reset to per-building-uniform temperatures, sweeps per step still falling -- so: on to 100 steps since the reset
+    # (untimed), then 24 timed steps, the same events
+    n_more, n_t = max(0, 100 - total), 24
+    acts2 = torch.rand((n_more + n_t, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+    actions = torch.cat([actions, acts2], dim=0)
+    sev = new_events(n_t, 2)
+    scratch = new_events(1, 2)[0]
+    for t in range(n_more):
+      one_step(total + t, scratch)
+    nsw2 = torch.zeros((n_t, B), dtype=torch.float32, device=dev)
+    barrier()
+    s0 = time.perf_counter()
+    for t in range(n_t):
+      one_step(total + n_more + t, sev[t])
+      nsw2[t].copy_(env._info[:, 4])
+    barrier()
+    s_el = time.perf_counter() - s0
+    s_ms = [e[0].elapsed_time(e[1]) for e in sev]
+    li_ = env.sim.launch_info
+    steady = {"steps_since_reset_before_timing": total + n_more, "steps": n_t, "ms_per_step": s_el / n_t * 1e3,
+              "value": B * Z * n_t / s_el, "unit": "zone-updates/s",
+              "mean_sweeps_per_env_step": float(nsw2.double().mean()), "sweep_kernel_ms": float(np.mean(s_ms)),
+              "roofline_frac": li_["algorithmic_bytes_per_env_step"] * B / (float(np.mean(s_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+              "hbm_TBps_real": li_["state_bytes_per_env_step"] * B / (float(np.mean(s_ms)) * 1e-3) / 1e12}
+    actions = actions[:total]
+
   if rank == 0:
     li = env.sim.launch_info
     env_steps_per_s = world * B * K / elapsed
@@ -776,7 +888,7 @@ def main() -> None:
                                                 f"{str(t.get('kernel_source_sha256'))[:12]} (this run: {src_now[:12]}), "
                                                 f"{t.get('state_bytes_per_building')} state bytes per building, 65,536 buildings: not this run")
     if world == 1 and not args.no_cpu_baseline:
-      nb_s = 2048
+      nb_s = 4096
       # the CPU leg goes on past the GPU's K timed steps (same action distribution, same generator)
       # until its sample is a few seconds of wall time
       more = torch.rand((400, nb_s, 2), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
@@ -798,6 +910,7 @@ def main() -> None:
   if rank == 0:
     if world == 1 and not args.no_also and not args.through_env_api and B == 65536:
       result["also"] = also_legs(args, dev, pf)   # after the headline (and its CPU leg): configs[2] and configs[4], bounded
+      result["also"]["steady"] = steady
     print(json.dumps(result))
   if distributed:
     dist.destroy_process_group()

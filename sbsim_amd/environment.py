@@ -356,6 +356,7 @@ class BatchedSimulator:
     info = _ffi.LaunchInfo()
     _ffi.check(self._lib.sb_get_launch_info(self._h, C.byref(info)), "sb_get_launch_info")
     self.launch_info = {f[0]: getattr(info, f[0]) for f in _ffi.LaunchInfo._fields_}
+    self.sweep_events = None   # a list: step() appends (start, end) HIP events of every sweep-kernel launch (bench.py)
 
   def close(self) -> None:
     if getattr(self, "_h", None):
@@ -432,10 +433,20 @@ class BatchedSimulator:
         raise ValueError(f"actions must be float32 [{self.B}, {self.n_actions}]")
       if not actions.is_contiguous():
         actions = actions.contiguous()
-    _ffi.check(self._lib.sb_step_phases(
-        self._h, C.c_void_p(actions.data_ptr()) if actions is not None else None, C.byref(step_in),
-        C.c_void_p(obs.data_ptr()) if obs is not None else None, C.c_void_p(reward.data_ptr()),
-        C.c_void_p(info.data_ptr()) if info is not None else None, self._stream(), int(phases)), "sb_step")
+    args = (self._h, C.c_void_p(actions.data_ptr()) if actions is not None else None, C.byref(step_in),
+            C.c_void_p(obs.data_ptr()) if obs is not None else None, C.c_void_p(reward.data_ptr()),
+            C.c_void_p(info.data_ptr()) if info is not None else None, self._stream())
+    if self.sweep_events is not None and phases == 7:
+      # measurement aid (bench.py): the step's three launches one by one, HIP events around the sweep kernel on its stream
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      _ffi.check(self._lib.sb_step_phases(*args, 1), "sb_step")
+      e0.record()
+      _ffi.check(self._lib.sb_step_phases(*args, 2), "sb_step")
+      e1.record()
+      _ffi.check(self._lib.sb_step_phases(*args, 4), "sb_step")
+      self.sweep_events.append((e0, e1))
+      return
+    _ffi.check(self._lib.sb_step_phases(*args, int(phases)), "sb_step")
 
   # ---- parity taps ----
   def _get(self, fn, shape, dtype):
