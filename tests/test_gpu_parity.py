@@ -1161,6 +1161,27 @@ def test_bench_two_ranks_sharing_one_gpu(monkeypatch):
     assert par["sweep_count_mismatches"] == 0 and par["max_abs_dT_zone_K"] < T_TOL, (name, par)
 
 
+def test_bench_eight_ranks_sharing_one_gpu(monkeypatch):
+  """The driver's 8-GPU line rehearsed on real HIP state: eight ranks of bench.py under
+  torch.distributed.run, all on device 0 (SBSIM_BENCH_SHARE_GPU=1: gloo with host-staged collectives -- RCCL refuses two
+  ranks on one device), 8,192 buildings per rank: eight library handles and eight streams on one device, per-rank
+  shards and seeds, the preflight, barrier-bracketed timing, the gather of 65,536 returns -- and configs[2] with every
+  class sharded eight ways and gathered by class.  What the first real 8-GPU run adds to this is RCCL and nothing else."""
+  _need_gpu()
+  monkeypatch.setenv("SBSIM_BENCH_SHARE_GPU", "1")
+  d = _run_bench(["--gpus", "8", "--buildings", "8192", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"])
+  assert d["n_gpus"] == 8 and d["gathered_returns"] == 65536 and d["scaling"] == "weak" and d["rccl_ranks"] == 8
+  assert d["preflight"]["ok"] is True and d["preflight"]["devices"] == ["cuda:0"] * 8
+  assert len(d["per_rank_ms_per_step"]) == 8 and len(d["per_rank_sweep_kernel_ms"]) == 8 and d["value"] > 1e6
+  m = _run_bench(["--config", "mixed", "--gpus", "8", "--buildings", "3072", "--steps", "2", "--warmup", "1", "--check-buildings", "2"])
+  assert m["n_gpus"] == 8 and m["gathered_returns"] == 8 * 3 * 1024 and m["rccl_ranks"] == 8
+  assert m["config"]["class_totals"] == [8192] * 3 and m["config"]["class_ranges_rank0"] == [[0, 1024]] * 3
+  assert len(m["per_rank_ms_per_step"]) == 8
+  for name, c in m["config"]["classes"].items():
+    par = c["parity_vs_oracle"]
+    assert c["buildings"] == 1024 and par["sweep_count_mismatches"] == 0 and par["max_abs_dT_zone_K"] < T_TOL, (name, par)
+
+
 def test_bench_through_the_public_env_api_costs_the_same():
   """The headline line steps through BatchedSimulator.step(phases=...) so that HIP events can bracket the
   sweep kernel; `--through-env-api` times BatchedEnvironment.step() itself (host-side step inputs, sb_step,
