@@ -200,6 +200,10 @@ typedef struct sb_launch_info {
 } sb_launch_info;
 
 int sb_abi_version(void);
+/* 1 when the library was built with SBSIM_BUILD_EXPERIMENTAL=1: the opt-in sweep kernels SBSIM_STREAM_MS=1 /
+ * SBSIM_STREAM_ROLL=1 ask for are compiled in (exact, tested, slower than the default ones); 0: the flags are ignored.
+ * (No reference counterpart: a build property.) */
+int sb_has_experimental_kernels(void);
 const char *sb_last_error(void);
 
 /* What sb_create would choose for this floor plan (no device needed): the host uses it to

@@ -108,7 +108,7 @@ SWEEP_KERNELS = {0: "k_sweep_lds", 1: "k_sweep_reg", 2: "k_sweep_reg (two wavefr
                  5: "k_sweep_band", 6: "k_sweep_stream"}
 
 
-EXPORTS = ("sb_abi_version", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",
+EXPORTS = ("sb_abi_version", "sb_has_experimental_kernels", "sb_last_error", "sb_plan_info", "sb_create", "sb_destroy", "sb_get_launch_info",
            "sb_reset", "sb_observe", "sb_observe_occupancy", "sb_occupancy_attach", "sb_occupancy_peek", "sb_convection_attach", "sb_step", "sb_step_phases", "sb_get_temps", "sb_set_temps", "sb_get_zone_temps",
            "sb_get_scalars", "sb_get_modes", "sb_get_zone_power", "sb_debug_phase_cycles",
            "sb_floorplan_padded_shape", "sb_floorplan_preprocess", "sb_floorplan_diffusers", "sb_debug_numpy_choice", "sb_pb_reward_info", "sb_pb_reward_response",

@@ -12,13 +12,22 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["sbsim_hip.hip", "step_reg.hip", "step_roll.hip", "step_two.hip", "step_two_64.hip", "step_two_76.hip", "step_two_80.hip", "step_band.hip", "step_band_68.hip", "step_band_72.hip", "step_band_76.hip", "step_band_80.hip", "step_band_84.hip", "step_band_88.hip", "step_band_92.hip", "step_band_96.hip", "step_stream.hip", "step_stream_ms.hip", "step_lds.hip",    # one translation unit per step kernel
+SOURCES = ["sbsim_hip.hip", "step_reg.hip", "step_roll.hip", "step_two.hip", "step_two_64.hip", "step_two_76.hip", "step_two_80.hip", "step_band.hip", "step_band_68.hip", "step_band_72.hip", "step_band_76.hip", "step_band_80.hip", "step_band_84.hip", "step_band_88.hip", "step_band_92.hip", "step_band_96.hip", "step_stream.hip", "step_lds.hip",    # one translation unit per step kernel
            "generators.hip",                                 # occupancy / convection generators
            "floorplan.cpp", "episode.cpp"]                   # host-only: floor-plan preprocessing, episode shards
 HEADERS = [os.path.join(CSRC, "sb_device.h"), os.path.join(CSRC, "sb_host.h"), os.path.join(CSRC, "sweep_common.h"), os.path.join(CSRC, "step_two_impl.h"), os.path.join(CSRC, "step_two_cfg.h"), os.path.join(CSRC, "step_band_impl.h"), os.path.join(CSRC, "step_band_cfg.h"),
            os.path.join(ROOT, "include", "sbsim_amd.h")]
-OBJ_DIR = os.path.join(CSRC, "_obj")
-LIB = os.path.join(_HERE, "libsbsim_amd.so")
+# SBSIM_BUILD_EXPERIMENTAL=1: also the sweep kernels that are exact and tested but slower than what they were meant to replace
+# (step_stream_ms.hip: several sweeps per pass; step_stream.hip's k_sweep_stream_roll: overlapped sweeps) -- opt-in at run time
+# (SBSIM_STREAM_MS=1 / SBSIM_STREAM_ROLL=1), not part of the default library
+EXPERIMENTAL = os.environ.get("SBSIM_BUILD_EXPERIMENTAL", "") == "1"
+if EXPERIMENTAL:
+  SOURCES = SOURCES + ["step_stream_ms.hip"]
+  HIPCC_FLAGS_EXTRA = ["-DSB_EXPERIMENTAL"]
+else:
+  HIPCC_FLAGS_EXTRA = []
+OBJ_DIR = os.path.join(CSRC, "_obj" + ("_exp" if EXPERIMENTAL else ""))
+LIB = os.path.join(_HERE, "libsbsim_amd_exp.so" if EXPERIMENTAL else "libsbsim_amd.so")   # (the experimental library is used through SBSIM_LIB=...)
 # -amdgpu-atomic-optimizer-strategy=None: the optimizer turns the sweep kernels' one-lane draw (`if (lane == 0) atomicAdd(next_b, 1)`)
 # into a wave reduction that reads the atomic's result AT ONCE -- an s_waitcnt vmcnt(0), i.e. a wait for the next building's rows
 # (all in flight at that point) at the top of every building (step_roll.hip)
@@ -50,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs.append(obj)
     if not force and _newer(obj, [src] + HEADERS):
       continue
-    cmd = [cc, *HIPCC_FLAGS, *os.environ.get("SBSIM_EXTRA_HIPCC_FLAGS", "").split(), *inc, "-c", src, "-o", obj]   # developer builds
+    cmd = [cc, *HIPCC_FLAGS, *HIPCC_FLAGS_EXTRA, *os.environ.get("SBSIM_EXTRA_HIPCC_FLAGS", "").split(), *inc, "-c", src, "-o", obj]   # developer builds
     if verbose:
       cmd.append("-Rpass-analysis=kernel-resource-usage")
     procs.append((cmd, subprocess.Popen(cmd)))

@@ -26,6 +26,22 @@ int prepare_sweep_stream_roll(const Dev &d, int waves);
 int sweep_stream_roll_xchg_extra_doubles();
 } // namespace sb
 
+// The experimental sweep kernels (step_stream_ms.hip, step_stream.hip's k_sweep_stream_roll: exact, tested, slower than what
+// they were meant to replace) are in the library only when it is built with SBSIM_BUILD_EXPERIMENTAL=1 (-DSB_EXPERIMENTAL,
+// sbsim_amd/build.py); the default build answers for step_stream_ms.hip's entry points here and never plans them.
+#ifdef SB_EXPERIMENTAL
+constexpr bool kExperimental = true;
+#else
+constexpr bool kExperimental = false;
+namespace sb {
+int launch_sweep_stream_ms(const Dev &, double *, double *, int, hipStream_t) { return (int)hipErrorNotSupported; }
+int prepare_sweep_stream_ms(const Dev &, int) { return (int)hipErrorNotSupported; }
+int sweep_stream_ms_sweeps() { return 1; }
+int sweep_stream_ms_seam_doubles(int, int) { return 0; }
+int sweep_stream_ms_xchg_doubles(int) { return 0; }
+} // namespace sb
+#endif
+
 using namespace sb;
 
 namespace {
@@ -622,14 +638,14 @@ bool plan_stream(const sb_plan_desc *plan, RegPlan &r, std::string &why) {
   // and the last wavefront to own the spare rows its bands need (the band of sweep j sits j rows further up).
   {
     const int ms_off = off + sweep_stream_ms_seam_doubles(NS, NWV) + sweep_stream_ms_xchg_doubles(NWV) + (Z + 1) * ZC;
-    r.stream_ms = env_flag("SBSIM_STREAM_MS") && ms_off * 8 <= kLdsCap && 64 * NWV - Hs >= sweep_stream_ms_sweeps() - 1 &&
+    r.stream_ms = kExperimental && env_flag("SBSIM_STREAM_MS") && ms_off * 8 <= kLdsCap && 64 * NWV - Hs >= sweep_stream_ms_sweeps() - 1 &&
                   NWV <= 8; // (its 256 registers: two wavefronts per SIMD, workgroups of at most 8)
   }
   r.r_seam = off; off += r.stream_ms == 1 ? sweep_stream_ms_seam_doubles(NS, NWV) : 2 * NWV * (NS + 8);
   // overlapped sweeps (step_stream.hip's k_sweep_stream_roll, round 5) -- OPT-IN, SBSIM_STREAM_ROLL=1: stream_ms == 2.  Exact
   // (tests/test_gpu_parity.py), 9 % faster on R9 forced here, 9 % SLOWER on the 299 x 401 plan it was written for: with three
   // workgroups per CU another workgroup already fills a wavefront's idle steps, and the sweep started in vain is traffic
-  if (!r.stream_ms && env_flag("SBSIM_STREAM_ROLL")) r.stream_ms = 2;
+  if (kExperimental && !r.stream_ms && env_flag("SBSIM_STREAM_ROLL")) r.stream_ms = 2;
   r.r_xchg = off; off += r.stream_ms == 1 ? sweep_stream_ms_xchg_doubles(NWV) : 32 + 64 * NWV + (r.stream_ms == 2 ? sweep_stream_roll_xchg_extra_doubles() : 0); // progress, max|delta| parts, the publish scratch
   r.r_A = off; off += (Z + 1) * ZC;
   r.lds_bytes = off * 8;
@@ -1113,6 +1129,7 @@ int choose_kernel(const sb_plan_desc *plan, const LdsPlan &q, RegPlan &r) {
 extern "C" {
 
 int sb_abi_version(void) { return SB_ABI_VERSION; }
+int sb_has_experimental_kernels(void) { return kExperimental ? 1 : 0; }
 const char *sb_last_error(void) { return sb::host::g_err.c_str(); }
 
 int sb_plan_info(const sb_plan_desc *plan, int32_t n_obs, int32_t n_buildings, sb_launch_info *out) {

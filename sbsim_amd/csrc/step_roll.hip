@@ -574,7 +574,9 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
       }
       __builtin_amdgcn_sched_barrier(0);
       roll_pairs<NR, 1, kWin, false, EXACT, true>(e, bk, Areg, pb, x, acc, ap); // ramp-up (+ A of the slots from kA0 on); reads ahead for the first pairs of the period
+#ifndef SB_STAMP_NEXT
       SB_STAMP(15);
+#endif
 #pragma nounroll
       for (;;) { // simulator.py:348-368
         __builtin_amdgcn_sched_barrier(0);
@@ -582,7 +584,13 @@ __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_e
 #ifndef SB_STAMP_SWEEP
 #define SB_STAMP_SWEEP 1 // which sweep of the building the period's stamps are taken in (0: the first one, right after the ramp-up)
 #endif
-#define SB_STAMP2(i) do { if (a.dbg && gw == 0 && iter == 10 && n_sweeps == SB_STAMP_SWEEP && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+// (sweep_idx: the sweep's number at the period's top -- n_sweeps is incremented before the decision's stamp, which until round 6
+// was therefore taken one sweep early: "decide" came out negative)
+#define SB_STAMP2(i) do { if (a.dbg && gw == 0 && iter == 10 && sweep_idx == SB_STAMP_SWEEP && lane == 0) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+        const int sweep_idx = n_sweeps;
+#ifdef SB_STAMP_NEXT // [15] = the NEXT period's top instead of the ramp-up's end: [15] - [14] is the loop's back edge
+        if (a.dbg && gw == 0 && iter == 10 && sweep_idx == SB_STAMP_SWEEP + 1 && lane == 0) a.dbg[15] = (long long)__builtin_readcyclecounter();
+#endif
 #else
 #define SB_STAMP2(i) do { } while (0)
 #endif

@@ -233,6 +233,9 @@ k_sweep_stream(Dev a, double *Abuf) {
 }
 
 // ---------------------------------------------------------------- overlapped sweeps (round 5)
+// EXPERIMENTAL (exact, tested, slower on the plan it was written for: DESIGN.md 5.4b): compiled with -DSB_EXPERIMENTAL only
+// (SBSIM_BUILD_EXPERIMENTAL=1, sbsim_amd/build.py); the default library carries stubs.
+#ifdef SB_EXPERIMENTAL
 // k_sweep_stream's wavefront w starts a sweep 64 steps after wavefront w - 1 and the workgroup meets at a barrier after every
 // sweep: of the NW + 64 (W - 1) steps a sweep takes, a wavefront works NW (299 x 401: 464 of 720) -- and an idle wavefront has
 // no loads in flight, which is what this kernel's speed is made of.  Here wavefront w goes on into sweep j + 1 as soon as it
@@ -453,6 +456,8 @@ int dispatch_roll(const Dev &d, double *abuf, double *ebuf, int waves, hipStream
   return go_roll<16>(d, abuf, ebuf, waves, stream, prepare);
 }
 
+#endif // SB_EXPERIMENTAL
+
 template <int WMAX>
 int go(const Dev &d, double *abuf, int waves, hipStream_t stream, bool prepare) {
   if (prepare)
@@ -472,9 +477,15 @@ int dispatch(const Dev &d, double *abuf, int waves, hipStream_t stream, bool pre
 int sweep_stream_set_table() { return kSets; }
 int sweep_stream_zone_columns() { return kZC; }
 
+#ifdef SB_EXPERIMENTAL
 int sweep_stream_roll_xchg_extra_doubles() { return 16; } // the odd sweeps' max |delta| parts behind the publish scratch
 int prepare_sweep_stream_roll(const Dev &d, int waves) { return dispatch_roll(d, nullptr, nullptr, waves, nullptr, true); }
 int launch_sweep_stream_roll(const Dev &d, double *abuf, double *ebuf, int waves, hipStream_t stream) { return dispatch_roll(d, abuf, ebuf, waves, stream, false); }
+#else // the planner never asks for it (sbsim_hip.hip: kExperimental)
+int sweep_stream_roll_xchg_extra_doubles() { return 0; }
+int prepare_sweep_stream_roll(const Dev &, int) { return (int)hipErrorNotSupported; }
+int launch_sweep_stream_roll(const Dev &, double *, double *, int, hipStream_t) { return (int)hipErrorNotSupported; }
+#endif
 int prepare_sweep_stream(const Dev &d, int waves) { return dispatch(d, nullptr, waves, nullptr, true); }
 int launch_sweep_stream(const Dev &d, double *abuf, int waves, hipStream_t stream) { return dispatch(d, abuf, waves, stream, false); }
 

@@ -18,7 +18,7 @@ for src in ${srcs//,/ }; do
 done
 wait
 objs=""
-for o in sbsim_hip step_reg step_roll step_two step_two_64 step_two_76 step_two_80 step_band step_band_68 step_band_72 step_band_76 step_band_80 step_band_84 step_band_88 step_band_92 step_band_96 step_stream step_stream_ms step_lds generators floorplan episode; do
+for o in sbsim_hip step_reg step_roll step_two step_two_64 step_two_76 step_two_80 step_band step_band_68 step_band_72 step_band_76 step_band_80 step_band_84 step_band_88 step_band_92 step_band_96 step_stream step_lds generators floorplan episode; do
   case " $bases " in *" $o "*) objs="$objs $obj/${o}_$name.o";; *) objs="$objs $obj/$o.o";; esac
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $root/tools/libexp_$name.so

@@ -40,6 +40,7 @@ if os.environ.get("SBSIM_PHASE_TIMING"):
     _ffi.check(_ffi.load().sb_debug_phase_cycles(env.sim._h, buf), "dbg")
     d = [buf[i + 1] - buf[i] for i in range(8)]
     print(f"step {t}: sweeps={buf[9]} " + " ".join(f"{n}={v}" for n, v in zip(names, d)) + f" total={buf[8]-buf[0]}"
-          + (f" ramp-up={buf[15]-buf[2]}" if buf[15] > buf[2] else ""))
+          + (f" ramp-up={buf[15]-buf[2]}" if buf[15] > buf[2] and not os.environ.get("SB_STAMP_NEXT") else ""))
     if buf[9] >= 2 and buf[11] > buf[10]:   # the second sweep's period (k_sweep_roll): 96 steps | publish row 63 | tail scan | decision
-      print(f"        second sweep: steps={buf[11]-buf[10]} publish={buf[12]-buf[11]} tail={buf[13]-buf[12]} decide={buf[14]-buf[13]}")
+      print(f"        second sweep: steps={buf[11]-buf[10]} publish={buf[12]-buf[11]} tail={buf[13]-buf[12]} decide={buf[14]-buf[13]}"
+            + (f" back edge (to the next period's top; -DSB_STAMP_NEXT builds)={buf[15]-buf[14]}" if os.environ.get("SB_STAMP_NEXT") and buf[15] > buf[14] else ""))
