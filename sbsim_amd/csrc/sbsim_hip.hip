@@ -1470,6 +1470,7 @@ int sb_reset(sb_handle *h, double initial_temp, const double *temps_dev, void *s
                      temps_dev, h->was_reset ? 0 : 1, h->steps_since_reset, 0);
   h->was_reset = true;
   h->steps_since_reset = 0;
+  h->counters_zeroed_on = (void *)(uintptr_t)1; // (whatever came before a reset is no promise about the draw counters)
   SB_HIP(hipGetLastError());
   return SB_OK;
 }
@@ -1596,6 +1597,7 @@ int sb_tap_pre(sb_handle *h, int32_t building, const double *zone_temps, const i
   const Dev &d = h->d;
   if (building < 0 || building >= d.B) return fail(SB_ERR_INVALID, "sb_tap_pre: building out of range");
   SB_ON_DEVICE(h->device);
+  h->counters_zeroed_on = (void *)(uintptr_t)1; // the tap's k_pre runs on one building: the next sweep launch zeroes its counters itself
   SB_HIP(hipDeviceSynchronize());
   const size_t zb = (size_t)building * d.Z;
   SB_HIP(hipMemcpy(d.zmean + zb, zone_temps, sizeof(double) * d.Z, hipMemcpyHostToDevice));
