@@ -1140,7 +1140,8 @@ def test_bench_policy_config_line_and_its_twins():
   d = _run_bench(["--config", "policy", "--steps", "2", "--warmup", "2", "--check-buildings", "64"])
   assert d["n_gpus"] == 1 and d["gathered_returns"] == 65536 and d["value"] > 1e7
   par = d["config"]["parity_vs_oracle"]
-  assert par["buildings"] == 64 and par["steps"] == 4
+  assert par["buildings"] == 64 and par["steps"] == 2 + 2 + 8   # warm-up + timed + the eight profiled steps behind them (sweep_kernel_ms)
+  assert d["roofline"]["sweep_kernel_ms"] > 0 and 0.5 < d["roofline"]["hbm_TBps_real"] < 8.0
   assert par["sweep_count_mismatches"] == 0 and par["max_abs_dT_zone_K"] < T_TOL, par
 
 
