@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     nx_tnow = a.bld[(bb)].t_now;                                                                \
     nx_lo = a.scal[(size_t)(bb) * kNScal + 16];                                                 \
     nx_hi = a.scal[(size_t)(bb) * kNScal + 17];                                                 \
-    for (int c = lane; c <= a.ncls; c += 64) tapg[2 * c + 1] = a.gtabg[(size_t)(bb) * a.ts + c]; \
+    for (int c = opaque(lane); c <= a.ncls; c += 64) tapg[2 * c + 1] = a.gtabg[(size_t)(bb) * a.ts + c]; /* (opaque: the lane's addresses are formed here, not kept for the kernel's lifetime -- in scratch) */ \
   } while (0)
   if ((int)blockIdx.x < a.B) {
     const double *tp_ = a.temp + (size_t)blockIdx.x * a.state_doubles;
@@ -804,7 +804,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       for (int g = 0; g < kZA; ++g) zw[g] = zm[g * 64];
       __builtin_amdgcn_sched_barrier(0);
       double *tp = a.temp + (size_t)b * a.state_doubles;
-      for (int i = lane; i < zs_n; i += 64) zs[i] = 0.0;
+      for (int i = opaque(lane); i < zs_n; i += 64) zs[i] = 0.0;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int t = 0; t < kTailMax; ++t) // the tail rows hold no zone cells (sb_create checks): all into row Z
@@ -841,7 +841,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       }
       const double gsum = wave_sum(gacc);
       if (lane == 0) {
-        a.gsum[b] = gsum + (double)a.n_ring * t_now;
+        a.gsum[b] = gsum + a.n_ring_f64 * t_now; // (n_ring_f64: a kernel argument, not a conversion the compiler keeps in a VGPR pair for the kernel's lifetime)
         a.nsw[b] = n_sweeps | (converged << 16);
       }
       SB_STAMP(5);
