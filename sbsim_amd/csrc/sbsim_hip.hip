@@ -633,7 +633,7 @@ bool plan_stream(const sb_plan_desc *plan, RegPlan &r, std::string &why) {
   const int ZC = sweep_stream_zone_columns();
   int off = 4 * sweep_stream_set_table() + 2 * ts;
   // step_stream_ms.hip (several sweeps per pass over the grid: a seam row per sweep) -- OPT-IN, SBSIM_STREAM_MS=1: correct
-  // (bit-identical iterates, tests/test_gpu_parity.py) but not faster yet (256 registers leave two
+  // (bit-identical iterates, tests/test_gpu_parity.py) but not faster yet (LABNOTES.md 5.4c: 256 registers leave two
   // wavefronts per SIMD, and a step of four sweep slots takes 3.3x a step of step_stream.hip's one).  Needs its LDS to fit
   // and the last wavefront to own the spare rows its bands need (the band of sweep j sits j rows further up).
   {

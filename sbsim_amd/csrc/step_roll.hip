@@ -26,7 +26,7 @@
 //     sets in LDS (a byte per step and lane, 6 KB): a ds_read_b64 per eight steps.  (Read from global
 //     memory, a word per four steps, the class words cost 11 % of the step: a load is three issue slots,
 //     and behind another wavefront's hand-over in the CU's one vector-memory queue an L1 hit takes
-//     longer than the twelve steps the reads ran ahead -- tools/exp_fixed_sweeps.py)
+//     longer than the twelve steps the reads ran ahead -- tools/exp_fixed_sweeps.py, LABNOTES.md 5.2)
 //   * window steps route |delta| to the accumulator of the lane's own sweep by its SIGN: a lane
 //     mask that one DPP shift per step maintains is OR-ed into the high word, one running max
 //     (sweep k) and one running min (sweep k+1) -- no lane compare, no select

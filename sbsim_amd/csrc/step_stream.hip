@@ -233,7 +233,7 @@ k_sweep_stream(Dev a, double *Abuf) {
 }
 
 // ---------------------------------------------------------------- overlapped sweeps (round 5)
-// EXPERIMENTAL (exact, tested, slower on the plan it was written for: DESIGN.md 5.4b): compiled with -DSB_EXPERIMENTAL only
+// EXPERIMENTAL (exact, tested, slower on the plan it was written for: LABNOTES.md 5.4b): compiled with -DSB_EXPERIMENTAL only
 // (SBSIM_BUILD_EXPERIMENTAL=1, sbsim_amd/build.py); the default library carries stubs.
 #ifdef SB_EXPERIMENTAL
 // k_sweep_stream's wavefront w starts a sweep 64 steps after wavefront w - 1 and the workgroup meets at a barrier after every
